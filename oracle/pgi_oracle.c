@@ -1,0 +1,888 @@
+/*
+ * pgi_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See pgi_oracle.h for scope, the "parity unpinned" statement and citations.
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -mfma -mavx2 -fopenmp -fPIC -shared
+ * Every FP statement is one IEEE op in a fixed order (the HIP kernels mirror it).
+ */
+#include "pgi_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================= */
+/* reference in-tree arithmetic (f64)                                       */
+/* ======================================================================= */
+
+/* graph_traversal.h:86-116 -- same operand order, plain mul/add (no fma)  */
+double pgo_ref_sampson_sq(const double s[4], const double E[9]) {
+    const double x1 = s[0], y1 = s[1], x2 = s[2], y2 = s[3];
+    const double e11 = E[0], e12 = E[1], e13 = E[2], e21 = E[3], e22 = E[4], e23 = E[5],
+                 e31 = E[6], e32 = E[7], e33 = E[8];
+    double rxc = e11 * x2 + e21 * y2 + e31;
+    double ryc = e12 * x2 + e22 * y2 + e32;
+    double rwc = e13 * x2 + e23 * y2 + e33;
+    double r = (x1 * rxc + y1 * ryc + rwc);
+    double rx = e11 * x1 + e12 * y1 + e13;
+    double ry = e21 * x1 + e22 * y1 + e23;
+    return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+}
+
+/* graph_traversal.h:136-168: squared residual compared with the UN-squared
+ * threshold (line 164 uses kThreshold_, not kSquaredThreshold of line 149). */
+uint32_t pgo_ref_get_inliers(const double* c, uint32_t n, const double E[9], double thr,
+                             uint32_t* idx) {
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (pgo_ref_sampson_sq(c + 4 * (size_t)i, E) < thr) idx[k++] = i;
+    return k;
+}
+
+/* pose_utils.h:74-86: E = [t]x R */
+void pgo_ref_essential_from_pose(const double R[9], const double t[3], double E[9]) {
+    const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += tx[3 * i + k] * R[3 * k + j];
+            E[3 * i + j] = s;
+        }
+}
+
+/* graph_traversal.h:194-233: squared threshold, early exit at min_inl */
+int pgo_ref_pose_test(const double* c, uint32_t n, const double R[9], const double t[3],
+                      double thr, uint32_t min_inl, uint32_t* n_inl) {
+    double E[9];
+    pgo_ref_essential_from_pose(R, t, E);
+    const double thr2 = thr * thr;
+    *n_inl = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (pgo_ref_sampson_sq(c + 4 * (size_t)i, E) < thr2) {
+            ++*n_inl;
+            if (*n_inl >= min_inl) return 1;
+        }
+    return 0;
+}
+
+/* graph_traversal.h:340-344: pose = T_edge * pose, or T_edge^-1 * pose */
+void pgo_ref_chain_pose(const double Re[9], const double te[3], int inverted, double R[9],
+                        double t[3]) {
+    double A[9], a[3];
+    if (inverted) { /* inverse of (Re,te) = (Re^T, -Re^T te) */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A[3 * i + j] = Re[3 * j + i];
+        for (int i = 0; i < 3; ++i)
+            a[i] = -(A[3 * i] * te[0] + A[3 * i + 1] * te[1] + A[3 * i + 2] * te[2]);
+    } else {
+        memcpy(A, Re, sizeof A);
+        memcpy(a, te, sizeof a);
+    }
+    double Rn[9], tn[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j];
+        tn[i] = A[3 * i] * t[0] + A[3 * i + 1] * t[1] + A[3 * i + 2] * t[2] + a[i];
+    }
+    memcpy(R, Rn, sizeof Rn);
+    memcpy(t, tn, sizeof tn);
+}
+
+/* pose_graph_builder.h:864-938 */
+void pgo_ref_normalize_corr(const float* ks, const float* kd, const uint32_t* ms,
+                            const uint32_t* md, uint32_t m, double f_src, double w_src,
+                            double h_src, double f_dst, double w_dst, double h_dst,
+                            int src_for_dst, double thr_px, double* c, double* thr_norm) {
+    /* K = [f,0,w/2; 0,f,h/2; 0,0,1]  (pose_graph_builder.h:286) */
+    const double sfx = f_src, sfy = f_src, spx = w_src / 2.0, spy = h_src / 2.0;
+    double dfx = f_dst, dfy = f_dst, dpx = w_dst / 2.0, dpy = h_dst / 2.0;
+    if (src_for_dst) { dfx = sfx; dfy = sfy; dpx = spx; dpy = spy; } /* :908-912 */
+    for (uint32_t i = 0; i < m; ++i) {
+        c[4 * i + 0] = ((double)ks[2 * ms[i] + 0] - spx) / sfx;
+        c[4 * i + 1] = ((double)ks[2 * ms[i] + 1] - spy) / sfy;
+        c[4 * i + 2] = ((double)kd[2 * md[i] + 0] - dpx) / dfx;
+        c[4 * i + 3] = ((double)kd[2 * md[i] + 1] - dpy) / dfy;
+    }
+    *thr_norm = thr_px / ((sfx + sfy + dfx + dfy) / 4.0); /* :934-937 */
+}
+
+/* ======================================================================= */
+/* engine spec                                                              */
+/* ======================================================================= */
+
+void pgo_default_params(pgo_params* p) {
+    p->confidence = 0.99;
+    p->max_iters = 1000;
+    p->round_size = 32;
+    p->lo_iters = 2;
+    p->min_inliers = 20;
+    p->fixed_budget = 0;
+    p->guess_quirk = 1;
+    p->vote_all_rows = 0;
+    p->reserved = 0;
+}
+
+uint64_t pgo_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* five distinct indices; counter-based, independent of execution order */
+void pgo_sample5(uint64_t seed, uint64_t pair_id, uint32_t hyp, uint32_t n, uint32_t idx[5]) {
+    const uint64_t base = pgo_mix64(seed ^ pgo_mix64(pair_id));
+    uint32_t k = 0, got = 0;
+    while (got < 5) {
+        const uint64_t u = pgo_mix64(base ^ (((uint64_t)hyp << 16) | k));
+        ++k;
+        const uint32_t j = (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
+        int dup = 0;
+        for (uint32_t q = 0; q < got; ++q) dup |= (idx[q] == j);
+        if (!dup || k >= 64) idx[got++] = j; /* k>=64: give up on distinctness */
+    }
+}
+
+/* ---- scoring (f32) ---------------------------------------------------- */
+static inline void sampson_terms(const float e[9], float x1, float y1, float x2, float y2,
+                                 float* r2, float* den) {
+    const float rxc = fmaf(e[0], x2, fmaf(e[3], y2, e[6]));
+    const float ryc = fmaf(e[1], x2, fmaf(e[4], y2, e[7]));
+    const float rwc = fmaf(e[2], x2, fmaf(e[5], y2, e[8]));
+    const float r = fmaf(x1, rxc, fmaf(y1, ryc, rwc));
+    const float rx = fmaf(e[0], x1, fmaf(e[1], y1, e[2]));
+    const float ry = fmaf(e[3], x1, fmaf(e[4], y1, e[5]));
+    *den = fmaf(rxc, rxc, fmaf(ryc, ryc, fmaf(rx, rx, ry * ry)));
+    *r2 = r * r;
+}
+
+void pgo_score_model(const float E[9], const float* x1, const float* y1, const float* x2,
+                     const float* y2, uint32_t n, double thr, uint32_t* score,
+                     uint32_t* n_inl) {
+    const float thr2 = (float)(thr * thr);
+    uint32_t s = 0, c = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        float r2, den;
+        sampson_terms(E, x1[i], y1[i], x2[i], y2[i], &r2, &den);
+        const float t = thr2 * den;
+        /* levels at sampson distance {0.5, 0.75, 1, 1.5} * thr */
+        s += (r2 < 0.25f * t) + (r2 < 0.5625f * t) + (r2 < t) + (r2 < 2.25f * t);
+        c += (r2 < t);
+    }
+    *score = s;
+    *n_inl = c;
+}
+
+uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, const float* x2,
+                        const float* y2, uint32_t n, float tau2, uint8_t* mask) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        float r2, den;
+        sampson_terms(E, x1[i], y1[i], x2[i], y2[i], &r2, &den);
+        const uint8_t in = r2 < tau2 * den;
+        mask[i] = in;
+        c += in;
+    }
+    return c;
+}
+
+/* ---- pivot key: high word of |a| with the row packed into the low 4 bits */
+static inline int32_t pivot_key(double a, int row) {
+    uint64_t b;
+    memcpy(&b, &a, 8);
+    const uint32_t hi = (uint32_t)(b >> 32) & 0x7FFFFFFFu;
+    return (int32_t)((hi & 0xFFFFFFF0u) | (uint32_t)(15 - row));
+}
+
+/* Gauss-Jordan with partial pivoting on an R x C matrix over the first P
+ * columns; prow[k] = row holding the pivot of column k. */
+static void gauss_jordan(double* a, int R, int C, int P, int* prow) {
+    int used[16] = {0};
+    for (int k = 0; k < P; ++k) {
+        int p = 0;
+        int32_t best = -1;
+        for (int r = 0; r < R; ++r) {
+            const int32_t key = used[r] ? -1 : pivot_key(a[r * C + k], r);
+            if (key > best) { best = key; p = r; }
+        }
+        used[p] = 1;
+        prow[k] = p;
+        const double inv = 1.0 / a[p * C + k];
+        for (int j = k + 1; j < C; ++j) a[p * C + j] = a[p * C + j] * inv;
+        for (int r = 0; r < R; ++r) {
+            if (r == p) continue;
+            const double f = a[r * C + k];
+            for (int j = k + 1; j < C; ++j) a[r * C + j] = fma(-f, a[p * C + j], a[r * C + j]);
+        }
+    }
+}
+
+/* ---- 5x9 null space ---------------------------------------------------- */
+static inline void epi_row(const float p[4], double a[9]) {
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
+    a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
+    a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+}
+
+static void orthonormalise4(double v[4][9]) {
+    for (int f = 0; f < 4; ++f) {
+        for (int g = 0; g < f; ++g) {
+            double d = 0;
+            for (int i = 0; i < 9; ++i) d = fma(v[g][i], v[f][i], d);
+            for (int i = 0; i < 9; ++i) v[f][i] = fma(-d, v[g][i], v[f][i]);
+        }
+        double nn = 0;
+        for (int i = 0; i < 9; ++i) nn = fma(v[f][i], v[f][i], nn);
+        const double inv = 1.0 / sqrt(nn);
+        for (int i = 0; i < 9; ++i) v[f][i] = v[f][i] * inv;
+    }
+}
+
+void pgo_nullspace5(const float pts[5][4], double basis[36]) {
+    double a[5 * 9];
+    int prow[5];
+    for (int r = 0; r < 5; ++r) epi_row(pts[r], a + 9 * r);
+    gauss_jordan(a, 5, 9, 5, prow);
+    double v[4][9];
+    for (int f = 0; f < 4; ++f) {
+        for (int k = 0; k < 5; ++k) v[f][k] = -a[prow[k] * 9 + 5 + f];
+        for (int g = 0; g < 4; ++g) v[f][5 + g] = (g == f) ? 1.0 : 0.0;
+    }
+    orthonormalise4(v);
+    memcpy(basis, v, sizeof v);
+}
+
+/* ---- Nister back-end ---------------------------------------------------- */
+/* lin: [x,y,z,1]; quad: [x2,xy,xz,x,y2,yz,y,z2,z,1];
+ * cubic (Nister's order): x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1 */
+static const int QI[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+static const int CI[10][4] = {{0, 2, 4, 5},     {2, 3, 8, 9},     {4, 8, 10, 11}, {5, 9, 11, 12},
+                              {3, 1, 6, 7},     {8, 6, 13, 14},   {9, 7, 14, 15}, {10, 13, 16, 17},
+                              {11, 14, 17, 18}, {12, 15, 18, 19}};
+/* phase-1 quads: up to 3 terms (entryA, entryB, sign); sign 0 = unused */
+static const int QT[9][3][3] = {
+    {{0, 0, 1}, {1, 1, 1}, {2, 2, 1}}, /* Q0 = EEt_00 */
+    {{0, 3, 1}, {1, 4, 1}, {2, 5, 1}}, /* Q1 = EEt_01 */
+    {{0, 6, 1}, {1, 7, 1}, {2, 8, 1}}, /* Q2 = EEt_02 */
+    {{3, 3, 1}, {4, 4, 1}, {5, 5, 1}}, /* Q3 = EEt_11 */
+    {{3, 6, 1}, {4, 7, 1}, {5, 8, 1}}, /* Q4 = EEt_12 */
+    {{6, 6, 1}, {7, 7, 1}, {8, 8, 1}}, /* Q5 = EEt_22 */
+    {{4, 8, 1}, {5, 7, -1}, {0, 0, 0}}, /* Q6 = E11E22 - E12E21 */
+    {{3, 8, 1}, {5, 6, -1}, {0, 0, 0}}, /* Q7 = E10E22 - E12E20 */
+    {{3, 7, 1}, {4, 6, -1}, {0, 0, 0}}, /* Q8 = E10E21 - E11E20 */
+};
+/* phase-2 cubic rows: 3 terms (quad index, entry index, sign).  Quads 0,3,5
+ * are read as Lambda_ii = Q - tr/2 for rows 1..9. */
+static const int LAM[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+
+static void build_constraints(const double basis[36], double cons[10][20]) {
+    double L[9][4];
+    for (int e = 0; e < 9; ++e)
+        for (int b = 0; b < 4; ++b) L[e][b] = basis[9 * b + e];
+    double Q[9][10];
+    for (int q = 0; q < 9; ++q) {
+        for (int c = 0; c < 10; ++c) Q[q][c] = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            const int sg = QT[q][t][2];
+            if (!sg) continue;
+            const double* A = L[QT[q][t][0]];
+            const double* B = L[QT[q][t][1]];
+            for (int a = 0; a < 4; ++a) {
+                const double av = sg > 0 ? A[a] : -A[a];
+                for (int b = 0; b < 4; ++b) Q[q][QI[a][b]] = fma(av, B[b], Q[q][QI[a][b]]);
+            }
+        }
+    }
+    double tr[10], Lam[6][10];
+    for (int c = 0; c < 10; ++c) tr[c] = (Q[0][c] + Q[3][c]) + Q[5][c];
+    for (int q = 0; q < 6; ++q)
+        for (int c = 0; c < 10; ++c)
+            Lam[q][c] = (q == 0 || q == 3 || q == 5) ? Q[q][c] - 0.5 * tr[c] : Q[q][c];
+    for (int row = 0; row < 10; ++row) {
+        double* c = cons[row];
+        for (int m = 0; m < 20; ++m) c[m] = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double* Qk;
+            const double* Lk;
+            int sg = 1;
+            if (row == 0) {
+                Qk = Q[6 + k];
+                Lk = L[k];
+                sg = (k == 1) ? -1 : 1;
+            } else {
+                const int i = (row - 1) / 3, j = (row - 1) % 3;
+                Qk = Lam[LAM[i][k]];
+                Lk = L[3 * k + j];
+            }
+            for (int q = 0; q < 10; ++q)
+                for (int l = 0; l < 4; ++l) {
+                    const double lv = sg > 0 ? Lk[l] : -Lk[l];
+                    c[CI[q][l]] = fma(Qk[q], lv, c[CI[q][l]]);
+                }
+        }
+    }
+}
+
+static inline double grid_point(int j) { /* z = u/(1-u^2), u uniform in (-1,1) */
+    const double u = (double)(2 * j - PGO_GRID) / (double)(PGO_GRID + 1);
+    return u / (1.0 - u * u);
+}
+
+static inline double horner10(const double p[11], double x) {
+    double v = p[10];
+    for (int c = 9; c >= 0; --c) v = fma(v, x, p[c]);
+    return v;
+}
+
+static double refine_root(const double p[11], double lo, double hi, int slo) {
+    /* safeguarded Newton; returns the evaluated iterate with the smallest |p| */
+    double x = 0.5 * (lo + hi), xbest = x, vbest = INFINITY;
+    for (int it = 0; it < PGO_NEWTON_ITERS; ++it) {
+        double v = p[10], d = 0.0;
+        for (int c = 9; c >= 0; --c) {
+            d = fma(d, x, v);
+            v = fma(v, x, p[c]);
+        }
+        const double av = fabs(v);
+        if (av < vbest) { vbest = av; xbest = x; }
+        if ((v < 0.0) == slo) lo = x; else hi = x;
+        double xn = x - v / d;
+        if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+        x = xn;
+    }
+    return xbest;
+}
+
+static inline void cross3(const double a[3], const double b[3], double c[3]) {
+    c[0] = fma(a[1], b[2], -(a[2] * b[1]));
+    c[1] = fma(a[2], b[0], -(a[0] * b[2]));
+    c[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+
+/* oriented epipolar constraint on the minimal sample: all five
+ * (e2 x x2) . (E x1) must share one strict sign */
+static int orientation_ok(const double E[9], const float (*s)[4], uint32_t ns) {
+    const double c0[3] = {E[0], E[3], E[6]}, c1[3] = {E[1], E[4], E[7]}, c2[3] = {E[2], E[5], E[8]};
+    double e01[3], e02[3], e12[3];
+    cross3(c0, c1, e01);
+    cross3(c0, c2, e02);
+    cross3(c1, c2, e12);
+    const double n01 = fma(e01[0], e01[0], fma(e01[1], e01[1], e01[2] * e01[2]));
+    const double n02 = fma(e02[0], e02[0], fma(e02[1], e02[1], e02[2] * e02[2]));
+    const double n12 = fma(e12[0], e12[0], fma(e12[1], e12[1], e12[2] * e12[2]));
+    const double* ep = e01;
+    double nb = n01;
+    if (n02 > nb) { nb = n02; ep = e02; }
+    if (n12 > nb) { nb = n12; ep = e12; }
+    uint32_t npos = 0, nneg = 0;
+    for (uint32_t i = 0; i < ns; ++i) {
+        const double x1 = s[i][0], y1 = s[i][1], x2 = s[i][2], y2 = s[i][3];
+        const double l0 = fma(E[0], x1, fma(E[1], y1, E[2]));
+        const double l1 = fma(E[3], x1, fma(E[4], y1, E[5]));
+        const double l2 = fma(E[6], x1, fma(E[7], y1, E[8]));
+        /* c = ep x (x2,y2,1) */
+        const double cx = fma(ep[1], 1.0, -(ep[2] * y2));
+        const double cy = fma(ep[2], x2, -(ep[0] * 1.0));
+        const double cz = fma(ep[0], y2, -(ep[1] * x2));
+        const double sgn = fma(cx, l0, fma(cy, l1, cz * l2));
+        npos += sgn > 0.0;
+        nneg += sgn < 0.0;
+    }
+    return npos == ns || nneg == ns;
+}
+
+uint32_t pgo_backend(const double basis[36], const float (*sample)[4], uint32_t n_sample,
+                     float models[PGO_MAX_MODELS][9], pgo_backend_dbg* dbg) {
+    double cons[10][20];
+    build_constraints(basis, cons);
+    if (dbg) memcpy(dbg->cons, cons, sizeof cons);
+    int prow[10];
+    gauss_jordan(&cons[0][0], 10, 20, 10, prow);
+    /* right block by pivot column */
+    double red[10][10];
+    for (int k = 0; k < 10; ++k)
+        for (int m = 0; m < 10; ++m) red[k][m] = cons[prow[k]][10 + m];
+    if (dbg) memcpy(dbg->red, red, sizeof red);
+    /* B(z): rows from (e,f) = (4,5),(6,7),(8,9) */
+    double bx[3][4], by[3][4], bc[3][5];
+    for (int i = 0; i < 3; ++i) {
+        const double* e = red[4 + 2 * i];
+        const double* f = red[5 + 2 * i];
+        bx[i][0] = e[2]; bx[i][1] = e[1] - f[2]; bx[i][2] = e[0] - f[1]; bx[i][3] = -f[0];
+        by[i][0] = e[5]; by[i][1] = e[4] - f[5]; by[i][2] = e[3] - f[4]; by[i][3] = -f[3];
+        bc[i][0] = e[9]; bc[i][1] = e[8] - f[9]; bc[i][2] = e[7] - f[8];
+        bc[i][3] = e[6] - f[7]; bc[i][4] = -f[6];
+    }
+    /* det B = bc0*(bx1 by2 - by1 bx2) - bc1*(bx0 by2 - by0 bx2) + bc2*(bx0 by1 - by0 bx1) */
+    static const int MN[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+    double T[3][11];
+    for (int i = 0; i < 3; ++i) {
+        const int r = MN[i][0], s = MN[i][1];
+        double m[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) m[a + b] = fma(bx[r][a], by[s][b], m[a + b]);
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) m[a + b] = fma(-by[r][a], bx[s][b], m[a + b]);
+        for (int c = 0; c < 11; ++c) T[i][c] = 0.0;
+        for (int a = 0; a < 5; ++a)
+            for (int b = 0; b < 7; ++b) T[i][a + b] = fma(bc[i][a], m[b], T[i][a + b]);
+    }
+    double poly[11];
+    for (int c = 0; c < 11; ++c) poly[c] = (T[0][c] - T[1][c]) + T[2][c];
+    if (dbg) memcpy(dbg->poly, poly, sizeof poly);
+    /* bracket sign changes on the fixed grid, refine */
+    double roots[PGO_MAX_MODELS], rpoly[11];
+    for (int c = 0; c < 11; ++c) rpoly[c] = poly[10 - c];
+    uint32_t nr = 0;
+    double gprev = grid_point(0);
+    int sprev = horner10(poly, gprev) < 0.0;
+    for (int j = 1; j <= PGO_GRID; ++j) {
+        const double g = grid_point(j);
+        const int s = horner10(poly, g) < 0.0;
+        if (s != sprev && nr < PGO_MAX_MODELS) {
+            if (gprev >= 1.0 || g <= -1.0) { /* |z|>1: refine w = 1/z on the reversed polynomial */
+                const double w = refine_root(rpoly, 1.0 / g, 1.0 / gprev, s);
+                roots[nr++] = 1.0 / w;
+            } else {
+                roots[nr++] = refine_root(poly, gprev, g, sprev);
+            }
+        }
+        gprev = g;
+        sprev = s;
+    }
+    if (dbg) {
+        dbg->n_roots = nr;
+        for (uint32_t i = 0; i < PGO_MAX_MODELS; ++i) dbg->roots[i] = i < nr ? roots[i] : 0.0;
+    }
+    /* back-substitute */
+    uint32_t nm = 0;
+    for (uint32_t ri = 0; ri < nr; ++ri) {
+        const double z = roots[ri];
+        double rw[3][3];
+        for (int i = 0; i < 3; ++i) {
+            rw[i][0] = fma(fma(fma(bx[i][3], z, bx[i][2]), z, bx[i][1]), z, bx[i][0]);
+            rw[i][1] = fma(fma(fma(by[i][3], z, by[i][2]), z, by[i][1]), z, by[i][0]);
+            rw[i][2] = fma(fma(fma(fma(bc[i][4], z, bc[i][3]), z, bc[i][2]), z, bc[i][1]), z, bc[i][0]);
+        }
+        double c01[3], c02[3], c12[3];
+        cross3(rw[0], rw[1], c01);
+        cross3(rw[0], rw[2], c02);
+        cross3(rw[1], rw[2], c12);
+        const double* cb = c01;
+        double wb = fabs(c01[2]);
+        if (fabs(c02[2]) > wb) { wb = fabs(c02[2]); cb = c02; }
+        if (fabs(c12[2]) > wb) { wb = fabs(c12[2]); cb = c12; }
+        const double x = cb[0] / cb[2], y = cb[1] / cb[2];
+        double E[9], n2 = 0.0;
+        for (int m = 0; m < 9; ++m) {
+            E[m] = fma(x, basis[m], fma(y, basis[9 + m], fma(z, basis[18 + m], basis[27 + m])));
+            n2 = fma(E[m], E[m], n2);
+        }
+        if (!(n2 > 0.0) || !(n2 < 1.0e300)) continue; /* NaN / inf / zero */
+        const double inv = 1.0 / sqrt(n2);
+        for (int m = 0; m < 9; ++m) E[m] = E[m] * inv;
+        if (n_sample && !orientation_ok(E, sample, n_sample)) continue;
+        for (int m = 0; m < 9; ++m) models[nm][m] = (float)E[m];
+        ++nm;
+    }
+    return nm;
+}
+
+uint32_t pgo_five_point(const float pts[5][4], float models[PGO_MAX_MODELS][9],
+                        pgo_backend_dbg* dbg) {
+    double basis[36];
+    pgo_nullspace5(pts, basis);
+    return pgo_backend(basis, pts, 5, models, dbg);
+}
+
+/* ---- n-point refit ------------------------------------------------------ */
+/* Summands are rounded to multiples of 2^-34 ((t+M)-M with M = 1.5*2^18), so
+ * the f64 sums are exact and independent of summation order as long as
+ * |partial sums| < 2^18 (normalised image coordinates, |x|,|y| <~ 2). */
+#define PGO_QMAGIC 393216.0
+void pgo_normal_matrix(const float* x1, const float* y1, const float* x2, const float* y2,
+                       const uint8_t* mask, uint32_t n, double A[81]) {
+    double S[9][9];
+    memset(S, 0, sizeof S);
+    for (uint32_t p = 0; p < n; ++p) {
+        if (mask && !mask[p]) continue;
+        const float pt[4] = {x1[p], y1[p], x2[p], y2[p]};
+        double a[9];
+        epi_row(pt, a);
+        for (int i = 0; i < 9; ++i)
+            for (int j = i; j < 9; ++j) {
+                double t = a[i] * a[j];
+                t = (t + PGO_QMAGIC) - PGO_QMAGIC;
+                S[i][j] = S[i][j] + t;
+            }
+    }
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) A[9 * i + j] = (i <= j) ? S[i][j] : S[j][i];
+}
+
+/* cyclic Jacobi, tournament order: round r pairs {(r+m)%9,(r-m)%9}, m=1..4.
+ * All four (c,s) come from A before the step; column phase (A<-AJ, V<-VJ),
+ * then row phase (A<-J^T A). */
+void pgo_jacobi9(double A[81], double V[81]) {
+    for (int i = 0; i < 81; ++i) V[i] = 0.0;
+    for (int i = 0; i < 9; ++i) V[10 * i] = 1.0;
+    for (int sw = 0; sw < PGO_JACOBI9_SWEEPS; ++sw)
+        for (int r = 0; r < 9; ++r) {
+            int P[4], Q[4];
+            double C[4], S[4];
+            for (int m = 1; m <= 4; ++m) {
+                int p = (r + m) % 9, q = (r + 9 - m) % 9;
+                if (p > q) { int tq = p; p = q; q = tq; }
+                P[m - 1] = p;
+                Q[m - 1] = q;
+                const double apq = A[9 * p + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double tau = (A[10 * q] - A[10 * p]) / (2.0 * apq);
+                    const double den = fabs(tau) + sqrt(fma(tau, tau, 1.0));
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / den;
+                    c = 1.0 / sqrt(fma(t, t, 1.0));
+                    s = t * c;
+                }
+                C[m - 1] = c;
+                S[m - 1] = s;
+            }
+            for (int m = 0; m < 4; ++m) {
+                const int p = P[m], q = Q[m];
+                const double c = C[m], s = S[m];
+                for (int l = 0; l < 9; ++l) {
+                    const double ap = A[9 * l + p], aq = A[9 * l + q];
+                    A[9 * l + p] = fma(c, ap, -(s * aq));
+                    A[9 * l + q] = fma(s, ap, c * aq);
+                    const double vp = V[9 * l + p], vq = V[9 * l + q];
+                    V[9 * l + p] = fma(c, vp, -(s * vq));
+                    V[9 * l + q] = fma(s, vp, c * vq);
+                }
+            }
+            for (int m = 0; m < 4; ++m) {
+                const int p = P[m], q = Q[m];
+                const double c = C[m], s = S[m];
+                for (int l = 0; l < 9; ++l) {
+                    const double ap = A[9 * p + l], aq = A[9 * q + l];
+                    A[9 * p + l] = fma(c, ap, -(s * aq));
+                    A[9 * q + l] = fma(s, ap, c * aq);
+                }
+            }
+        }
+}
+
+/* basis = eigenvectors of the 4 smallest eigenvalues: W = smallest, then Z, Y, X */
+void pgo_basis_from_eigen(const double A[81], const double V[81], double basis[36]) {
+    int taken[9] = {0};
+    for (int rank = 0; rank < 4; ++rank) {
+        int bi = -1;
+        for (int i = 0; i < 9; ++i) {
+            if (taken[i]) continue;
+            if (bi < 0 || A[10 * i] < A[10 * bi]) bi = i;
+        }
+        taken[bi] = 1;
+        double* dst = basis + 9 * (3 - rank);
+        for (int l = 0; l < 9; ++l) dst[l] = V[9 * l + bi];
+    }
+}
+
+uint32_t pgo_npoint(const float* x1, const float* y1, const float* x2, const float* y2,
+                    const uint8_t* mask, uint32_t n, float models[PGO_MAX_MODELS][9]) {
+    double A[81], V[81], basis[36];
+    pgo_normal_matrix(x1, y1, x2, y2, mask, n, A);
+    pgo_jacobi9(A, V);
+    pgo_basis_from_eigen(A, V, basis);
+    return pgo_backend(basis, NULL, 0, models, NULL);
+}
+
+/* ---- decomposition ------------------------------------------------------ */
+/* one-sided Jacobi on the columns of G = E*V; sigma sorted descending;
+ * U2 = U0 x U1 (det U = +1); det V fixed by flipping V2 (pose_utils.h:157-163) */
+void pgo_svd3(const double E[9], double U[9], double S[3], double V[9]) {
+    double G[9];
+    memcpy(G, E, sizeof G);
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sw = 0; sw < PGO_SVD3_SWEEPS; ++sw)
+        for (int k = 0; k < 3; ++k) {
+            const int p = PQ[k][0], q = PQ[k][1];
+            const double al = fma(G[p], G[p], fma(G[3 + p], G[3 + p], G[6 + p] * G[6 + p]));
+            const double be = fma(G[q], G[q], fma(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
+            const double ga = fma(G[p], G[q], fma(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
+            if (ga == 0.0) continue;
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+            const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;
+            for (int l = 0; l < 3; ++l) {
+                const double gp = G[3 * l + p], gq = G[3 * l + q];
+                G[3 * l + p] = fma(c, gp, -(s * gq));
+                G[3 * l + q] = fma(s, gp, c * gq);
+                const double vp = V[3 * l + p], vq = V[3 * l + q];
+                V[3 * l + p] = fma(c, vp, -(s * vq));
+                V[3 * l + q] = fma(s, vp, c * vq);
+            }
+        }
+    double sg[3];
+    for (int j = 0; j < 3; ++j)
+        sg[j] = sqrt(fma(G[j], G[j], fma(G[3 + j], G[3 + j], G[6 + j] * G[6 + j])));
+    int ord[3] = {0, 1, 2};
+    /* stable selection sort, descending */
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (sg[ord[b]] > sg[ord[a]]) { int tq = ord[a]; ord[a] = ord[b]; ord[b] = tq; }
+    double Gs[9], Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = sg[ord[j]];
+        for (int l = 0; l < 3; ++l) {
+            Gs[3 * l + j] = G[3 * l + ord[j]];
+            Vs[3 * l + j] = V[3 * l + ord[j]];
+        }
+    }
+    for (int j = 0; j < 2; ++j) {
+        const double inv = 1.0 / S[j];
+        for (int l = 0; l < 3; ++l) U[3 * l + j] = Gs[3 * l + j] * inv;
+    }
+    const double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+    double u2[3];
+    cross3(u0, u1, u2);
+    U[2] = u2[0]; U[5] = u2[1]; U[8] = u2[2];
+    const double v0[3] = {Vs[0], Vs[3], Vs[6]}, v1[3] = {Vs[1], Vs[4], Vs[7]};
+    double vc[3];
+    cross3(v0, v1, vc);
+    const double dv = fma(vc[0], Vs[2], fma(vc[1], Vs[5], vc[2] * Vs[8]));
+    if (dv < 0.0) { Vs[2] = -Vs[2]; Vs[5] = -Vs[5]; Vs[8] = -Vs[8]; }
+    memcpy(V, Vs, sizeof Vs);
+}
+
+/* pose_utils.h:144-169 (R1 = U D V^T, R2 = U D^T V^T, t = U[:,2]) and
+ * :172-252 (candidates 0:(R1,+t) 1:(R1,-t) 2:(R2,+t) 3:(R2,-t); vote; first
+ * max wins).  Cheirality: depth signs from lambda2*x2 = lambda1*R*x1 + t
+ * (the reference's raw projected.z<0 test on a sign-ambiguous homogeneous
+ * point is NOT reproduced -- SURVEY §8a-9 landmine, DESIGN.md deviations). */
+void pgo_decompose(const double E[9], const float* x1, const float* y1, const float* x2,
+                   const float* y2, const uint8_t* mask, uint32_t n, int vote_all, double R[9],
+                   double t[3], uint32_t votes[4], uint32_t* cand) {
+    double U[9], S[3], V[9];
+    pgo_svd3(E, U, S, V);
+    double Rc[2][9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double a = U[3 * i + 1] * V[3 * j + 0]; /* U1 V0^T */
+            const double b = U[3 * i + 0] * V[3 * j + 1]; /* U0 V1^T */
+            const double c = U[3 * i + 2] * V[3 * j + 2]; /* U2 V2^T */
+            Rc[0][3 * i + j] = (b - a) + c;
+            Rc[1][3 * i + j] = (a - b) + c;
+        }
+    double tt[3] = {U[2], U[5], U[8]};
+    const double tn = 1.0 / sqrt(fma(tt[0], tt[0], fma(tt[1], tt[1], tt[2] * tt[2])));
+    for (int i = 0; i < 3; ++i) tt[i] = tt[i] * tn;
+    votes[0] = votes[1] = votes[2] = votes[3] = 0;
+    for (uint32_t p = 0; p < n; ++p) {
+        if (!vote_all && mask && !mask[p]) continue;
+        const double X1[3] = {x1[p], y1[p], 1.0}, X2[3] = {x2[p], y2[p], 1.0};
+        double x2t[3];
+        cross3(X2, tt, x2t);
+        for (int rI = 0; rI < 2; ++rI) {
+            const double* Rm = Rc[rI];
+            double a[3], nn[3], at[3];
+            for (int i = 0; i < 3; ++i)
+                a[i] = fma(Rm[3 * i], X1[0], fma(Rm[3 * i + 1], X1[1], Rm[3 * i + 2]));
+            cross3(a, X2, nn);
+            cross3(a, tt, at);
+            const double d1 = fma(x2t[0], nn[0], fma(x2t[1], nn[1], x2t[2] * nn[2]));
+            const double d2 = fma(at[0], nn[0], fma(at[1], nn[1], at[2] * nn[2]));
+            votes[2 * rI + 0] += (d1 > 0.0) && (d2 > 0.0);
+            votes[2 * rI + 1] += (d1 < 0.0) && (d2 < 0.0);
+        }
+    }
+    uint32_t best = 0;
+    for (uint32_t c = 1; c < 4; ++c)
+        if (votes[c] > votes[best]) best = c;
+    *cand = best;
+    memcpy(R, Rc[best >> 1], 9 * sizeof(double));
+    for (int i = 0; i < 3; ++i) t[i] = (best & 1) ? -tt[i] : tt[i];
+}
+
+/* ---- robust estimator ---------------------------------------------------- */
+static double pow_uint(double q, uint32_t k) { /* binary exponentiation, fixed order */
+    double r = 1.0, b = q;
+    while (k) {
+        if (k & 1u) r = r * b;
+        b = b * b;
+        k >>= 1;
+    }
+    return r;
+}
+
+typedef struct {
+    float E[9];
+    uint32_t score, n_inl;
+    int valid;
+} best_t;
+
+/* n-point refits while they improve (at most lo_iters) */
+static void local_optimise(const float* x1, const float* y1, const float* x2, const float* y2,
+                           uint32_t n, double thr, const pgo_params* prm, best_t* best,
+                           uint8_t* mask, uint32_t* lo_runs) {
+    const float thr2 = (float)(thr * thr);
+    for (uint32_t it = 0; it < prm->lo_iters; ++it) {
+        const uint32_t ni = pgo_mask_model(best->E, x1, y1, x2, y2, n, thr2, mask);
+        if (ni < 5) break;
+        float models[PGO_MAX_MODELS][9];
+        const uint32_t nm = pgo_npoint(x1, y1, x2, y2, mask, n, models);
+        ++*lo_runs;
+        int improved = 0;
+        uint32_t bs = best->score, bi = 0, bn = 0;
+        for (uint32_t m = 0; m < nm; ++m) {
+            uint32_t s, c;
+            pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
+            if (s > bs) { bs = s; bi = m; bn = c; improved = 1; }
+        }
+        if (!improved) break;
+        memcpy(best->E, models[bi], sizeof best->E);
+        best->score = bs;
+        best->n_inl = bn;
+    }
+}
+
+void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, const float* y2,
+                          uint32_t n, double thr, const pgo_params* prm, uint64_t seed,
+                          uint64_t pair_id, pgo_edge* out, uint8_t* mask) {
+    memset(out, 0, sizeof *out);
+    memset(mask, 0, n);
+    if (n < 5) { out->status = PGO_FAIL_FEW_POINTS; return; }
+    best_t best;
+    memset(&best, 0, sizeof best);
+    const uint32_t rs = prm->round_size ? prm->round_size : 32;
+    const uint32_t budget = prm->fixed_budget ? prm->fixed_budget : prm->max_iters;
+    uint32_t hyps = 0, lo_runs = 0;
+    while (hyps < budget) {
+        /* one round: rs hypotheses, best by (score desc, hyp asc, root asc) */
+        best_t rb;
+        memset(&rb, 0, sizeof rb);
+        for (uint32_t h = hyps; h < hyps + rs; ++h) {
+            uint32_t idx[5];
+            float pts[5][4], models[PGO_MAX_MODELS][9];
+            pgo_sample5(seed, pair_id, h, n, idx);
+            for (int k = 0; k < 5; ++k) {
+                pts[k][0] = x1[idx[k]]; pts[k][1] = y1[idx[k]];
+                pts[k][2] = x2[idx[k]]; pts[k][3] = y2[idx[k]];
+            }
+            const uint32_t nm = pgo_five_point(pts, models, NULL);
+            for (uint32_t m = 0; m < nm; ++m) {
+                uint32_t s, c;
+                pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
+                if (!rb.valid || s > rb.score) {
+                    memcpy(rb.E, models[m], sizeof rb.E);
+                    rb.score = s; rb.n_inl = c; rb.valid = 1;
+                }
+            }
+        }
+        hyps += rs;
+        if (rb.valid && (!best.valid || rb.score > best.score)) {
+            best = rb;
+            local_optimise(x1, y1, x2, y2, n, thr, prm, &best, mask, &lo_runs);
+        }
+        if (!prm->fixed_budget && best.valid && best.n_inl >= 5) {
+            const double rho = (double)best.n_inl / (double)n;
+            const double r5 = ((rho * rho) * (rho * rho)) * rho;
+            const double q = 1.0 - r5;
+            if (pow_uint(q, hyps) <= 1.0 - prm->confidence) break;
+        }
+    }
+    out->iters = hyps;
+    out->lo_runs = lo_runs;
+    if (!best.valid) { out->status = PGO_FAIL_FEW_INLIERS; memset(mask, 0, n); return; }
+    const float thr2 = (float)(thr * thr);
+    out->n_inl = pgo_mask_model(best.E, x1, y1, x2, y2, n, thr2, mask);
+    out->score = best.score;
+    for (int m = 0; m < 9; ++m) out->E[m] = (double)best.E[m];
+    out->status = out->n_inl >= prm->min_inliers ? PGO_OK : PGO_FAIL_FEW_INLIERS;
+}
+
+static int has_nan(const double* v, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!(v[i] == v[i])) return 1;
+    return 0;
+}
+
+/* pose_graph_builder.h:940-1078 */
+void pgo_estimate_pose(const float* x1, const float* y1, const float* x2, const float* y2,
+                       uint32_t n, double thr, const double* guess, const pgo_params* prm,
+                       uint64_t seed, uint64_t pair_id, pgo_edge* out, uint8_t* mask) {
+    memset(out, 0, sizeof *out);
+    int success = 0;
+    float Ebest[9];
+    if (guess && n >= 5) { /* :974-1029 */
+        double Eg[9], n2 = 0.0;
+        pgo_ref_essential_from_pose(guess, guess + 9, Eg);
+        for (int m = 0; m < 9; ++m) n2 = fma(Eg[m], Eg[m], n2);
+        const double inv = 1.0 / sqrt(n2);
+        float Ef[9];
+        for (int m = 0; m < 9; ++m) Ef[m] = (float)(Eg[m] * inv);
+        const double trunc = 1.5 * thr; /* :963-964 */
+        const float tau2 = prm->guess_quirk ? (float)trunc : (float)(trunc * trunc);
+        const uint32_t ni = pgo_mask_model(Ef, x1, y1, x2, y2, n, tau2, mask); /* :985-1009 */
+        if (ni >= 5) {
+            float models[PGO_MAX_MODELS][9]; /* :1013-1020: all-inlier refit */
+            const uint32_t nm = pgo_npoint(x1, y1, x2, y2, mask, n, models);
+            uint32_t bs = 0, bn = 0;
+            int have = 0;
+            for (uint32_t m = 0; m < nm; ++m) {
+                uint32_t s, c;
+                pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
+                if (!have || s > bs) { bs = s; bn = c; have = 1; memcpy(Ebest, models[m], sizeof Ebest); }
+            }
+            (void)bn;
+            out->lo_runs = 1;
+            if (have && ni >= prm->min_inliers) { /* :1022-1028 */
+                success = 1;
+                out->n_inl = ni; /* count of the guess's inliers */
+                out->score = bs;
+                out->used_guess = 1;
+                for (int m = 0; m < 9; ++m) out->E[m] = (double)Ebest[m];
+            }
+        }
+    }
+    if (!success) { /* :1031-1055 */
+        pgo_ransac_essential(x1, y1, x2, y2, n, thr, prm, seed, pair_id, out, mask);
+        if (out->status != PGO_OK) return;
+    }
+    /* :1057-1075 */
+    uint32_t votes[4], cand;
+    pgo_decompose(out->E, x1, y1, x2, y2, mask, n, (int)prm->vote_all_rows, out->R, out->t,
+                  votes, &cand);
+    out->votes = votes[cand];
+    out->cand = cand;
+    out->status = (has_nan(out->R, 9) || has_nan(out->t, 3)) ? PGO_FAIL_NAN : PGO_OK;
+}
+
+int pgo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void pgo_estimate_pose_batch(const float* x1, const float* y1, const float* x2,
+                             const float* y2, const uint64_t* off, uint32_t n_pairs,
+                             const double* thr, const double* guesses,
+                             const uint8_t* has_guess, const pgo_params* prm, uint64_t seed,
+                             uint64_t pair_id_base, pgo_edge* out, uint8_t* masks,
+                             int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+        const uint64_t o = off[p];
+        const uint32_t n = (uint32_t)(off[p + 1] - o);
+        const double* g = (guesses && has_guess && has_guess[p]) ? guesses + 12 * p : NULL;
+        pgo_estimate_pose(x1 + o, y1 + o, x2 + o, y2 + o, n, thr[p], g, prm, seed,
+                          pair_id_base + (uint64_t)p, out + p, masks + o);
+    }
+    (void)threads;
+}

@@ -1,0 +1,108 @@
+"""Synthetic two-view correspondences (SURVEY.md §8d / BASELINE.md §2).
+
+Neither 1DSfM data nor OpenCV exists on either box, so every test and bench
+input is generated here.  Pair p uses its own Philox stream keyed by
+``seed_base + p`` so any subset of pairs (a rank's shard, a small parity case)
+is bit-identical to the same pairs inside the full configuration.
+
+Convention: x_dst ~ R x_src + t  (T_dst_src; reference pose.h:14, pose_utils.h:74-86).
+Coordinates are normalised (pixel / focal, principal point removed) exactly as
+createCorrespondenceMatrix hands them to estimatePose (pose_graph_builder.h:917-931).
+"""
+import numpy as np
+
+SEED_BASE = 0x5EED0000
+FOCAL_PX = 1000.0
+DEFAULT_THR_PX = 0.75
+
+
+def rodrigues(axis, angle):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def make_pair(pair_id, n, inlier_ratio=0.5, noise_px=0.25, max_angle_deg=30.0,
+              seed_base=SEED_BASE):
+    """Returns dict(x1,y1,x2,y2 float32[n], R[3,3], t[3], inlier bool[n])."""
+    rng = np.random.Generator(np.random.Philox(key=seed_base + int(pair_id)))
+    axis = rng.standard_normal(3)
+    angle = np.deg2rad(rng.uniform(0.0, max_angle_deg))
+    t = rng.standard_normal(3)
+    t /= np.linalg.norm(t)
+    R = rodrigues(axis, angle)
+    n_in = int(round(n * inlier_ratio))
+    p1 = np.zeros((0, 2))
+    p2 = np.zeros((0, 2))
+    tries = 0
+    while len(p1) < n_in:
+        m = 4 * max(n_in, 16)
+        z = rng.uniform(2.0, 8.0, m)
+        X = np.stack([rng.uniform(-0.45, 0.45, m) * z, rng.uniform(-0.45, 0.45, m) * z, z], 1)
+        Y = X @ R.T + t
+        ok = (Y[:, 2] > 0.5)
+        q = Y[:, :2] / np.where(ok, Y[:, 2], 1.0)[:, None]
+        ok &= (np.abs(q) < 0.5).all(1)
+        p1 = np.concatenate([p1, (X[:, :2] / X[:, 2:3])[ok]])
+        p2 = np.concatenate([p2, q[ok]])
+        tries += 1
+        if tries % 8 == 0:  # views barely overlap: halve the rotation, keep the stream
+            angle *= 0.5
+            R = rodrigues(axis, angle)
+            p1 = np.zeros((0, 2))
+            p2 = np.zeros((0, 2))
+    p1, p2 = p1[:n_in], p2[:n_in]
+    n_out = n - n_in
+    o1 = rng.uniform(-0.45, 0.45, (n_out, 2))
+    o2 = rng.uniform(-0.5, 0.5, (n_out, 2))
+    c = np.concatenate([np.concatenate([p1, p2], 1), np.concatenate([o1, o2], 1)])
+    c += rng.standard_normal(c.shape) * (noise_px / FOCAL_PX)
+    inl = np.zeros(n, bool)
+    inl[:n_in] = True
+    perm = rng.permutation(n)
+    c, inl = c[perm].astype(np.float32), inl[perm]
+    return dict(x1=c[:, 0].copy(), y1=c[:, 1].copy(), x2=c[:, 2].copy(), y2=c[:, 3].copy(),
+                R=R, t=t, inlier=inl)
+
+
+def make_batch(pair_ids, n, inlier_ratio=0.5, noise_px=0.25, max_angle_deg=30.0,
+               seed_base=SEED_BASE):
+    """Flattened (pair, corr) SoA.  ``n`` is an int or a per-pair sequence."""
+    pair_ids = np.asarray(pair_ids, np.int64)
+    ns = np.broadcast_to(np.asarray(n, np.int64), pair_ids.shape)
+    off = np.zeros(len(pair_ids) + 1, np.uint64)
+    off[1:] = np.cumsum(ns)
+    tot = int(off[-1])
+    out = dict(x1=np.empty(tot, np.float32), y1=np.empty(tot, np.float32),
+               x2=np.empty(tot, np.float32), y2=np.empty(tot, np.float32),
+               inlier=np.empty(tot, bool), offsets=off, pair_ids=pair_ids.astype(np.uint64),
+               R=np.empty((len(pair_ids), 3, 3)), t=np.empty((len(pair_ids), 3)))
+    for i, (p, k) in enumerate(zip(pair_ids, ns)):
+        d = make_pair(p, int(k), inlier_ratio, noise_px, max_angle_deg, seed_base)
+        a, b = int(off[i]), int(off[i + 1])
+        for key in ("x1", "y1", "x2", "y2", "inlier"):
+            out[key][a:b] = d[key]
+        out["R"][i], out["t"][i] = d["R"], d["t"]
+    return out
+
+
+def ragged_sizes(pair_ids, lo=50, hi=4000, seed_base=SEED_BASE):
+    """N ~ U{lo..hi} per pair, keyed by pair id (config 2's ragged variant)."""
+    return np.array([np.random.Generator(np.random.Philox(key=seed_base ^ 0xA5A5 ^ (int(p) << 20)))
+                     .integers(lo, hi + 1) for p in pair_ids], np.int64)
+
+
+def rot_err_deg(R_est, R_gt):
+    c = (np.trace(R_est @ R_gt.T) - 1.0) / 2.0
+    return np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
+def auc_at(errors_deg, limit=5.0):
+    """AUC@limit of the exact empirical recall curve (failures = inf)."""
+    e = np.sort(np.asarray(errors_deg, float))
+    e = e[e < limit]
+    n = len(errors_deg)
+    if n == 0:
+        return 0.0
+    # recall(theta) steps by 1/n at each error; integral = sum (limit - e_i) / n
+    return float(np.sum(limit - e) / (n * limit))
