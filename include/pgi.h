@@ -1,0 +1,170 @@
+/*
+ * pgi.h -- C ABI of the MI355X-native pairwise relative-pose engine.
+ *
+ * Drop-in boundary for the hot path of danini/pose-graph-initialization
+ * (paths relative to /root/reference/src/pyposegraphbuilder/include/):
+ *   PoseGraphBuilder::estimatePose      pose_graph_builder.h:940-1078 (decl :153-164)
+ *   EssentialMatrixEvaluator::getInliers graph_traversal.h:136-168
+ *   InTraversalPoseTester::test          graph_traversal.h:194-233
+ *   pose::getPoseFromEssentialMatrix     pose_utils.h:172-252
+ * plus the rotation averaging that BASELINE.json:north_star adds downstream.
+ *
+ * Plain pointers and sizes only; all buffers are caller-owned; no exceptions
+ * cross the boundary; every entry point returns PGI_SUCCESS (0) or a negative
+ * pgi_error and records a message readable through pgi_last_error().  The
+ * library needs a HIP device: pgi_create fails (returns NULL) without one --
+ * there is no CPU fallback.
+ *
+ * Pointers named d_* are DEVICE pointers (HBM); h_* are host pointers.
+ */
+#ifndef PGI_H
+#define PGI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGI_VERSION 1
+
+typedef enum {
+    PGI_SUCCESS = 0,
+    PGI_ERR_INVALID = -1,  /* bad argument                                   */
+    PGI_ERR_DEVICE = -2,   /* HIP runtime error (message in pgi_last_error)  */
+    PGI_ERR_NOMEM = -3,
+    PGI_ERR_TOO_LARGE = -4 /* a pair exceeds the supported correspondence count */
+} pgi_error;
+
+/* per-edge status (pgi_edge.status) -- estimatePose's bool, refined */
+#define PGI_EDGE_OK 1              /* true  (pose_graph_builder.h:1077)                  */
+#define PGI_EDGE_FEW_INLIERS 0     /* false (pose_graph_builder.h:1053-1054)             */
+#define PGI_EDGE_NAN (-1)          /* false (pose_graph_builder.h:1069-1070)             */
+#define PGI_EDGE_FEW_POINTS (-2)   /* fewer than 5 rows                                  */
+
+typedef struct pgi_ctx pgi_ctx;
+
+/* Estimator parameters.  Defaults (pgi_default_params) mirror the reference's
+ * call sites: confidence 0.99 (pose_graph_builder.h:1018,1042), max 1000
+ * iterations (OpenCV's default for that overload), kMinimumInlierNumber 20
+ * (examples/cpp_example.cpp), MSAC multiplier 3/2 (pose_graph_builder.h:963). */
+typedef struct {
+    double confidence;
+    uint32_t max_iters;
+    uint32_t round_size;    /* hypotheses per round (LO / termination granularity) */
+    uint32_t lo_iters;      /* n-point refits per improvement                      */
+    uint32_t min_inliers;
+    uint32_t fixed_budget;  /* 0 = adaptive; else exactly this many hypotheses     */
+    uint32_t guess_quirk;   /* 1 = reproduce graph_traversal.h:164 (s^2 < 1.5*thr) */
+    uint32_t vote_all_rows; /* 1 = cheirality vote over all rows (pose_utils.h:203) */
+    uint32_t reserved;
+} pgi_params;
+
+/* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.
+ * 200 bytes, identical on host and device. */
+typedef struct {
+    double E[9];       /* essential matrix, row-major, unit Frobenius norm          */
+    double R[9];       /* R_dst_src row-major   (Sophus::SE3d rotation, :1073-1075)  */
+    double t[3];       /* unit t_dst_src                                            */
+    int32_t status;    /* PGI_EDGE_*                                                */
+    uint32_t n_inl;    /* inlierNumber_ (pose_graph_builder.h:1022,1047)            */
+    uint32_t score;    /* multi-level inlier score of the final model               */
+    uint32_t iters;    /* hypotheses drawn                                          */
+    uint32_t votes;    /* cheirality votes of the chosen candidate (pose_utils.h:251) */
+    uint32_t cand;     /* candidate index 0..3 (pose_utils.h:182,201)               */
+    uint32_t used_guess;
+    uint32_t lo_runs;
+} pgi_edge;
+
+/* Flattened (pair, corr) SoA batch resident in HBM.  Pair p owns rows
+ * [offsets[p], offsets[p+1]).  Coordinates are normalised image coordinates as
+ * produced by createCorrespondenceMatrix (pose_graph_builder.h:917-931). */
+typedef struct {
+    const float* d_x1;
+    const float* d_y1;
+    const float* d_x2;
+    const float* d_y2;
+    const uint64_t* d_offsets;  /* n_pairs + 1                                       */
+    const double* d_thr;        /* n_pairs, normalised threshold (:934-937)          */
+    const double* d_guess_Rt;   /* n_pairs*12 (R row-major, t) or NULL               */
+    const uint8_t* d_has_guess; /* n_pairs or NULL                                   */
+    uint32_t n_pairs;
+    uint32_t max_corr;          /* max rows of any pair (sizes the LDS staging)      */
+    uint64_t pair_id_base;      /* global id of pair 0 (sharding keeps seeds stable) */
+    uint64_t seed;
+} pgi_batch;
+
+const char* pgi_last_error(void);
+int pgi_device_count(void);
+void pgi_default_params(pgi_params* p);
+
+/* device < 0: current device.  stream: a hipStream_t (e.g. torch's current
+ * stream) or NULL for the default stream; all work is enqueued there. */
+pgi_ctx* pgi_create(int device, const pgi_params* params);
+void pgi_destroy(pgi_ctx* ctx);
+int pgi_set_stream(pgi_ctx* ctx, void* hip_stream);
+int pgi_set_params(pgi_ctx* ctx, const pgi_params* params);
+int pgi_synchronize(pgi_ctx* ctx);
+
+/* ---- estimatePose, batched (asynchronous on the ctx stream) ------------- */
+/* d_edges: n_pairs records; d_masks: one byte per row of the batch. */
+int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_edges,
+                            uint8_t* d_masks);
+
+/* ---- estimatePose, literal drop-in (host pointers, synchronous, re-entrant)
+ * corr_aos: n x 4 doubles [x1 y1 x2 y2] == cv::Mat N x 4 CV_64F (:946);
+ * guesses_Rt: g x 12 doubles (the reference passes 0 or 1 guess, SURVEY §8a-12;
+ * the LAST guess wins as in :974-1029); mask: n bytes (std::vector<uchar>).
+ * Returns 1 (true), 0 (false) or a negative pgi_error. */
+int pgi_estimate_pose(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, double thr,
+                      const double* h_guesses_Rt, uint32_t g, uint64_t seed, uint64_t pair_id,
+                      pgi_edge* h_edge, uint8_t* h_mask);
+
+/* ---- getInliers / InTraversalPoseTester, batched ------------------------ */
+/* One model per pair.  d_E: n_pairs x 9 doubles.  d_tau2: per-pair bound on the
+ * SQUARED Sampson distance (pass 1.5*thr for the graph_traversal.h:164 quirk,
+ * (1.5*thr)^2 for :184).  d_masks may be NULL.  f32 arithmetic on the SoA batch. */
+int pgi_score_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, const double* d_E,
+                         const double* d_tau2, uint32_t* d_counts, uint8_t* d_masks);
+/* Reference-layout variant: f64 AoS rows (n x 4) and the reference's exact
+ * operation order (graph_traversal.h:107-115); bit-identical to it. */
+int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr_aos, const uint64_t* d_offsets,
+                       uint32_t n_pairs, const double* d_E, const double* d_tau2,
+                       uint32_t* d_counts, uint8_t* d_masks);
+
+/* ---- getPoseFromEssentialMatrix, batched -------------------------------- */
+/* d_E: n_pairs x 9; d_masks: rows voting (NULL = all rows).  Writes R, t,
+ * votes, cand of d_edges (other fields untouched). */
+int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* batch, const double* d_E,
+                        const uint8_t* d_masks, pgi_edge* d_edges);
+
+/* ---- minimal solver, batched (5-point; debugging / parity) -------------- */
+/* d_pts: n_samples x 5 x 4 floats.  d_models: n_samples x 10 x 9 floats,
+ * d_counts: n_samples.  d_dbg (optional): n_samples x PGI_DBG_DOUBLES doubles:
+ * basis[36] cons[200] red[100] poly[11] roots[10] nroots[1]. */
+#define PGI_DBG_DOUBLES 358
+int pgi_five_point_batch(pgi_ctx* ctx, const float* d_pts, uint32_t n_samples, float* d_models,
+                         uint32_t* d_counts, double* d_dbg);
+
+/* ---- rotation averaging (north_star: L1 + IRLS; not in the reference) ---- */
+typedef struct {
+    uint32_t src, dst;  /* R_rel ~ R_dst * R_src^T  (T_dst_src, pose.h:14)          */
+    double R[9];
+    double weight;      /* edge score = inlier ratio (pose_graph_builder.h:645-654) */
+} pgi_rot_edge;
+typedef struct {
+    uint32_t l1_iters;     /* 5    */
+    uint32_t irls_iters;   /* 100  */
+    uint32_t cg_iters;     /* 200  */
+    double sigma_deg;      /* 5.0  */
+    double tol;            /* 1e-8 mean step, radians */
+} pgi_rotavg_params;
+void pgi_default_rotavg_params(pgi_rotavg_params* p);
+/* h_* host pointers; R_out: n_views x 9 (world->camera), view 0 of each
+ * connected component fixed to its spanning-tree value.  Synchronous. */
+int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_edges,
+                         uint32_t n_views, const pgi_rotavg_params* prm, double* h_R_out,
+                         uint32_t* h_iters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

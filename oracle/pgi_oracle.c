@@ -226,15 +226,23 @@ static inline void epi_row(const float p[4], double a[9]) {
     a[6] = x1;      a[7] = y1;      a[8] = 1.0;
 }
 
+/* dot product as a fixed pairwise tree (maps onto a 16-lane butterfly):
+ * ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)), then + p8 */
+static inline double dot9_tree(const double* a, const double* b) {
+    double p[9];
+    for (int i = 0; i < 9; ++i) p[i] = a[i] * b[i];
+    const double q0 = (p[0] + p[1]) + (p[2] + p[3]);
+    const double q1 = (p[4] + p[5]) + (p[6] + p[7]);
+    return (q0 + q1) + p[8];
+}
+
 static void orthonormalise4(double v[4][9]) {
     for (int f = 0; f < 4; ++f) {
         for (int g = 0; g < f; ++g) {
-            double d = 0;
-            for (int i = 0; i < 9; ++i) d = fma(v[g][i], v[f][i], d);
+            const double d = dot9_tree(v[g], v[f]);
             for (int i = 0; i < 9; ++i) v[f][i] = fma(-d, v[g][i], v[f][i]);
         }
-        double nn = 0;
-        for (int i = 0; i < 9; ++i) nn = fma(v[f][i], v[f][i], nn);
+        const double nn = dot9_tree(v[f], v[f]);
         const double inv = 1.0 / sqrt(nn);
         for (int i = 0; i < 9; ++i) v[f][i] = v[f][i] * inv;
     }

@@ -1,0 +1,655 @@
+// pgi_device.hpp -- gfx950 device building blocks of the pairwise relative-pose engine.
+//
+// Execution model: a wavefront (64 lanes) is split into four DPP rows of 16
+// lanes; one row ("group") solves one 5-point hypothesis cooperatively (matrix
+// rows live one-per-lane in registers, pivots are found with DPP row reductions,
+// pivot rows travel by ds_bpermute), then the whole wavefront scores the
+// resulting models over the LDS-resident correspondences with __ballot/popcount.
+//
+// Numerics: every floating-point statement is ONE IEEE-754 operation in a fixed
+// order (compile with -ffp-contract=off); reductions are either integer
+// popcounts or exact sums, so results do not depend on the lane layout.  The
+// algorithm is specified in DESIGN.md §3; reference citations are relative to
+// /root/reference/src/pyposegraphbuilder/include/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PGI_DEV __device__ __forceinline__
+
+namespace pgi {
+
+constexpr int kGrid = 256;       // root-bracketing intervals
+constexpr int kNewton = 10;      // safeguarded Newton iterations
+constexpr int kJacobiSweeps = 8; // 9x9 tournament Jacobi sweeps
+constexpr int kSvdSweeps = 6;    // 3x3 one-sided Jacobi sweeps
+constexpr int kMaxModels = 10;
+
+// ---- wavefront-scope LDS ordering ------------------------------------------
+// DS operations of one wavefront execute in order; this only stops the
+// compiler from moving LDS accesses across the exchange point.
+PGI_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- DPP row (16-lane) primitives -------------------------------------------
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140, row_shr:n = 0x110 + n.
+template <int CTRL>
+PGI_DEV int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+PGI_DEV double dpp_d(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(dpp_i<CTRL>(hi), dpp_i<CTRL>(lo));
+}
+PGI_DEV int row_max_i(int k) {
+    k = max(k, dpp_i<0xB1>(k));
+    k = max(k, dpp_i<0x4E>(k));
+    k = max(k, dpp_i<0x141>(k));
+    k = max(k, dpp_i<0x140>(k));
+    return k;
+}
+// pairwise tree ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) + (same over lanes 8..15)
+PGI_DEV double row_sum_d(double x) {
+    x = x + dpp_d<0xB1>(x);
+    x = x + dpp_d<0x4E>(x);
+    x = x + dpp_d<0x141>(x);
+    x = x + dpp_d<0x140>(x);
+    return x;
+}
+PGI_DEV int row_scan_incl_i(int x) {
+    x += dpp_i<0x111>(x);
+    x += dpp_i<0x112>(x);
+    x += dpp_i<0x114>(x);
+    x += dpp_i<0x118>(x);
+    return x;
+}
+// exact sums (pre-rounded summands): any order is bit-identical
+PGI_DEV double wave_sum_exact(double x) {
+    x = row_sum_d(x);
+    x = x + __shfl_xor(x, 16);
+    x = x + __shfl_xor(x, 32);
+    return x;
+}
+
+// ---- counter-based RNG --------------------------------------------------------
+PGI_DEV uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+PGI_DEV void sample5(uint64_t base, uint32_t hyp, uint32_t n, uint32_t idx[5]) {
+    uint32_t k = 0, got = 0;
+    idx[0] = idx[1] = idx[2] = idx[3] = idx[4] = 0xFFFFFFFFu;
+    while (got < 5) {
+        const uint64_t u = mix64(base ^ (((uint64_t)hyp << 16) | k));
+        ++k;
+        const uint32_t j = (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dup |= (q < (int)got) && (idx[q] == j);
+        if (!dup || k >= 64) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (q == (int)got) idx[q] = j;
+            ++got;
+        }
+    }
+}
+
+// ---- Sampson terms (f32; the scoring primitive) ---------------------------------
+// r = p2^T E p1 and the gradient norm of graph_traversal.h:107-115, evaluated with
+// one fused multiply-add per term.
+PGI_DEV void sampson_terms(const float e[9], float x1, float y1, float x2, float y2, float& r2,
+                           float& den) {
+    const float rxc = fmaf(e[0], x2, fmaf(e[3], y2, e[6]));
+    const float ryc = fmaf(e[1], x2, fmaf(e[4], y2, e[7]));
+    const float rwc = fmaf(e[2], x2, fmaf(e[5], y2, e[8]));
+    const float r = fmaf(x1, rxc, fmaf(y1, ryc, rwc));
+    const float rx = fmaf(e[0], x1, fmaf(e[1], y1, e[2]));
+    const float ry = fmaf(e[3], x1, fmaf(e[4], y1, e[5]));
+    den = fmaf(rxc, rxc, fmaf(ryc, ryc, fmaf(rx, rx, ry * ry)));
+    r2 = r * r;
+}
+
+// ---- small f64 helpers -----------------------------------------------------------
+PGI_DEV int pivot_key(double a, int row) {
+    const uint32_t hi = (uint32_t)__double2hiint(a) & 0x7FFFFFFFu;
+    return (int)((hi & 0xFFFFFFF0u) | (uint32_t)(15 - row));
+}
+PGI_DEV void cross3(const double a[3], const double b[3], double c[3]) {
+    c[0] = fma(a[1], b[2], -(a[2] * b[1]));
+    c[1] = fma(a[2], b[0], -(a[0] * b[2]));
+    c[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+// element-wise select (keeps the choice in registers: v_cndmask, never an indexed reload)
+PGI_DEV void sel3(bool c, const double a[3], double r[3]) {
+    r[0] = c ? a[0] : r[0];
+    r[1] = c ? a[1] : r[1];
+    r[2] = c ? a[2] : r[2];
+}
+PGI_DEV double grid_point(int j) {
+    const double u = (double)(2 * j - kGrid) / (double)(kGrid + 1);
+    return u / (1.0 - u * u);
+}
+PGI_DEV double horner10(const double p[11], double x) {
+    double v = p[10];
+#pragma unroll
+    for (int c = 9; c >= 0; --c) v = fma(v, x, p[c]);
+    return v;
+}
+PGI_DEV double refine_root(const double p[11], double lo, double hi, bool slo) {
+    double x = 0.5 * (lo + hi), xbest = x, vbest = __builtin_inf();
+    for (int it = 0; it < kNewton; ++it) {
+        double v = p[10], d = 0.0;
+#pragma unroll
+        for (int c = 9; c >= 0; --c) {
+            d = fma(d, x, v);
+            v = fma(v, x, p[c]);
+        }
+        const double av = fabs(v);
+        if (av < vbest) {
+            vbest = av;
+            xbest = x;
+        }
+        if ((v < 0.0) == slo) lo = x; else hi = x;
+        double xn = x - v / d;
+        if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+        x = xn;
+    }
+    return xbest;
+}
+PGI_DEV double pow_uint(double q, uint32_t k) {
+    double r = 1.0, b = q;
+    while (k) {
+        if (k & 1u) r = r * b;
+        b = b * b;
+        k >>= 1;
+    }
+    return r;
+}
+
+// monomial index tables (lin [x,y,z,1] x lin -> quad; quad x lin -> cubic in
+// Nister's column order x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1)
+__device__ constexpr int kQI[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+__device__ constexpr int kCI[10][4] = {{0, 2, 4, 5},     {2, 3, 8, 9},     {4, 8, 10, 11},
+                                       {5, 9, 11, 12},   {3, 1, 6, 7},     {8, 6, 13, 14},
+                                       {9, 7, 14, 15},   {10, 13, 16, 17}, {11, 14, 17, 18},
+                                       {12, 15, 18, 19}};
+// phase-1 quads: Q0..Q5 = (E E^T)_{00,01,02,11,12,22}; Q6..Q8 = the 2x2 minors of rows 1,2.
+// packed per term: entryA | entryB<<4 | sign<<8 (sign 1:+, 2:-, 0:unused)
+__constant__ uint16_t kQT[9][3] = {
+    {0x100 | 0 | (0 << 4), 0x100 | 1 | (1 << 4), 0x100 | 2 | (2 << 4)},
+    {0x100 | 0 | (3 << 4), 0x100 | 1 | (4 << 4), 0x100 | 2 | (5 << 4)},
+    {0x100 | 0 | (6 << 4), 0x100 | 1 | (7 << 4), 0x100 | 2 | (8 << 4)},
+    {0x100 | 3 | (3 << 4), 0x100 | 4 | (4 << 4), 0x100 | 5 | (5 << 4)},
+    {0x100 | 3 | (6 << 4), 0x100 | 4 | (7 << 4), 0x100 | 5 | (8 << 4)},
+    {0x100 | 6 | (6 << 4), 0x100 | 7 | (7 << 4), 0x100 | 8 | (8 << 4)},
+    {0x100 | 4 | (8 << 4), 0x200 | 5 | (7 << 4), 0},
+    {0x100 | 3 | (8 << 4), 0x200 | 5 | (6 << 4), 0},
+    {0x100 | 3 | (7 << 4), 0x200 | 4 | (6 << 4), 0},
+};
+__constant__ uint8_t kLAM[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+__constant__ uint8_t kMN[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+
+// ---- per-group LDS scratch (doubles) ------------------------------------------------
+constexpr int G_BASIS = 0;   // [4][9]  X,Y,Z,W
+constexpr int G_REGA = 36;   // 100: quads[9][10] -> red[6][10] -> T[3][11] | poly[11] | rpoly[11] | brk
+constexpr int G_BROW = 136;  // [3][13]: bx[4] by[4] bc[5]
+constexpr int G_DOUBLES = 176;
+constexpr int A_T = 0, A_POLY = 33, A_RPOLY = 44, A_BRK = 56;  // offsets inside G_REGA
+
+// Five epipolar rows -> orthonormal 4-vector null-space basis in gs[G_BASIS].
+// Row r of the 5x9 system lives in sub-lane r.
+PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, double* gs) {
+    double a[9];
+    {
+        const double x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
+        a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
+        a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
+        a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+    }
+    bool used = false;
+    int mycol = -1;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int key = (s < 5 && !used) ? pivot_key(a[k], s) : -1;
+        const int kmax = row_max_i(key);
+        const bool is_p = (key == kmax) && (key >= 0);
+        const int pl = gbase + (15 - (kmax & 15));
+        if (is_p) {
+            used = true;
+            mycol = k;
+        }
+        const double inv = 1.0 / a[k];
+        const double f = a[k];
+#pragma unroll
+        for (int j = k + 1; j < 9; ++j) {
+            const double v = is_p ? a[j] * inv : a[j];
+            const double pj = __shfl(v, pl);
+            a[j] = is_p ? v : fma(-f, pj, v);
+        }
+    }
+    // v_f[k] = -a[prow[k]][5+f]; v_f[5+g] = delta_fg
+    if (mycol >= 0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) gs[G_BASIS + 9 * f + mycol] = -a[5 + f];
+    }
+    if (s < 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gs[G_BASIS + 9 * s + 5 + g] = (g == s) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    // modified Gram-Schmidt, element i in sub-lane i, tree dot products
+    double v[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) v[f] = (s < 9) ? gs[G_BASIS + 9 * f + s] : 0.0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int g = 0; g < f; ++g) {
+            const double d = row_sum_d(v[g] * v[f]);
+            v[f] = fma(-d, v[g], v[f]);
+        }
+        const double nn = row_sum_d(v[f] * v[f]);
+        const double inv = 1.0 / sqrt(nn);
+        v[f] = v[f] * inv;
+    }
+    wave_sync();
+    if (s < 9) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) gs[G_BASIS + 9 * f + s] = v[f];
+    }
+    wave_sync();
+}
+
+// Debug taps of the back-end (five_point_batch only)
+struct BackendDbg {
+    double* cons;  // [10][20]
+    double* red;   // [10][10] by pivot column
+    double* poly;  // [11]
+    double* roots; // [10]
+    double* nroots;
+};
+
+// Nister back-end on the basis in gs[G_BASIS]: 10 cubic constraints -> Gauss-Jordan
+// -> 3x3 polynomial matrix B(z) -> degree-10 determinant -> bracketed real roots ->
+// E per root.  Returns true in sub-lanes that hold a valid model E32 (sub-lane =
+// root index).  smp: the five sample points (orientation test) or nullptr.
+template <bool DBG>
+PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, const float4* smp,
+                           float E32[9], const BackendDbg* dbg) {
+    // ---- phase 1: nine quadratic forms, one per sub-lane ------------------------------
+    if (s < 9) {
+        double q[10];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) q[c] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t w = kQT[s][t];
+            const int eA = w & 15, eB = (w >> 4) & 15, sg = w >> 8;
+            if (sg) {
+                double A[4], B[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double av = gs[G_BASIS + 9 * b + eA];
+                    A[b] = (sg == 1) ? av : -av;
+                    B[b] = gs[G_BASIS + 9 * b + eB];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) q[kQI[a][b]] = fma(A[a], B[b], q[kQI[a][b]]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 10; ++c) gs[G_REGA + 10 * s + c] = q[c];
+    }
+    wave_sync();
+    // Lambda_ii = (E E^T)_ii - tr/2, coefficient c in sub-lane c
+    if (s < 10) {
+        const double q0 = gs[G_REGA + 0 + s], q3 = gs[G_REGA + 30 + s], q5 = gs[G_REGA + 50 + s];
+        const double tr = (q0 + q3) + q5;
+        gs[G_REGA + 0 + s] = q0 - 0.5 * tr;
+        gs[G_REGA + 30 + s] = q3 - 0.5 * tr;
+        gs[G_REGA + 50 + s] = q5 - 0.5 * tr;
+    }
+    wave_sync();
+    // ---- phase 2: ten cubic constraint rows, one per sub-lane ----------------------------
+    double row[20];
+#pragma unroll
+    for (int m = 0; m < 20; ++m) row[m] = 0.0;
+    if (s < 10) {
+        const int i = (s > 0) ? (s - 1) / 3 : 0, j = (s > 0) ? (s - 1) % 3 : 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int qi = (s == 0) ? 6 + k : kLAM[i][k];
+            const int ei = (s == 0) ? k : 3 * k + j;
+            const bool neg = (s == 0) && (k == 1);
+            double L[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const double lv = gs[G_BASIS + 9 * l + ei];
+                L[l] = neg ? -lv : lv;
+            }
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const double qv = gs[G_REGA + 10 * qi + q];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) row[kCI[q][l]] = fma(qv, L[l], row[kCI[q][l]]);
+            }
+        }
+    }
+    if constexpr (DBG) {
+        if (s < 10)
+            for (int m = 0; m < 20; ++m) dbg->cons[20 * s + m] = row[m];
+    }
+    // ---- Gauss-Jordan, partial pivoting; row r in sub-lane r ---------------------------------
+    bool used = false;
+    int mycol = -1;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const int key = (s < 10 && !used) ? pivot_key(row[k], s) : -1;
+        const int kmax = row_max_i(key);
+        const bool is_p = (key == kmax) && (key >= 0);
+        const int pl = gbase + (15 - (kmax & 15));
+        if (is_p) {
+            used = true;
+            mycol = k;
+        }
+        const double inv = 1.0 / row[k];
+        const double f = row[k];
+#pragma unroll
+        for (int j = k + 1; j < 20; ++j) {
+            const double v = is_p ? row[j] * inv : row[j];
+            const double pj = __shfl(v, pl);
+            row[j] = is_p ? v : fma(-f, pj, v);
+        }
+    }
+    wave_sync();  // quads are dead: region A is reused for the reduced rows
+    if (mycol >= 4) {
+#pragma unroll
+        for (int m = 0; m < 10; ++m) gs[G_REGA + 10 * (mycol - 4) + m] = row[10 + m];
+    }
+    if constexpr (DBG) {
+        if (mycol >= 0)
+            for (int m = 0; m < 10; ++m) dbg->red[10 * mycol + m] = row[10 + m];
+    }
+    wave_sync();
+    // ---- B(z): rows (e,f) = (x2z,x2), (y2z,y2), (xyz,xy) -> e - z f ----------------------------
+    if (s < 3) {
+        const double* e = gs + G_REGA + 20 * s;
+        const double* f = e + 10;
+        double* b = gs + G_BROW + 13 * s;
+        b[0] = e[2]; b[1] = e[1] - f[2]; b[2] = e[0] - f[1]; b[3] = -f[0];
+        b[4] = e[5]; b[5] = e[4] - f[5]; b[6] = e[3] - f[4]; b[7] = -f[3];
+        b[8] = e[9]; b[9] = e[8] - f[9]; b[10] = e[7] - f[8]; b[11] = e[6] - f[7]; b[12] = -f[6];
+    }
+    wave_sync();
+    // ---- det B(z) = sum_i (+,-,+) bc_i * (bx_r by_q - by_r bx_q) ------------------------------
+    if (s < 3) {
+        const double* br = gs + G_BROW + 13 * kMN[s][0];
+        const double* bq = gs + G_BROW + 13 * kMN[s][1];
+        const double* bc = gs + G_BROW + 13 * s + 8;
+        double bxr[4], byr[4], bxq[4], byq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bxr[a] = br[a]; byr[a] = br[4 + a]; bxq[a] = bq[a]; byq[a] = bq[4 + a];
+        }
+        double m[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) m[c] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a + b] = fma(bxr[a], byq[b], m[a + b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a + b] = fma(-byr[a], bxq[b], m[a + b]);
+        double T[11];
+#pragma unroll
+        for (int c = 0; c < 11; ++c) T[c] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const double bca = bc[a];
+#pragma unroll
+            for (int b = 0; b < 7; ++b) T[a + b] = fma(bca, m[b], T[a + b]);
+        }
+#pragma unroll
+        for (int c = 0; c < 11; ++c) gs[G_REGA + A_T + 11 * s + c] = T[c];  // red is dead (consumed above)
+    }
+    wave_sync();
+    if (s < 11) {
+        const double p = (gs[G_REGA + A_T + s] - gs[G_REGA + A_T + 11 + s]) + gs[G_REGA + A_T + 22 + s];
+        gs[G_REGA + A_POLY + s] = p;
+        gs[G_REGA + A_RPOLY + (10 - s)] = p;
+        if constexpr (DBG) dbg->poly[s] = p;
+    }
+    wave_sync();
+    // ---- bracket sign changes on the grid: sub-lane s owns intervals [16s, 16s+16) ---------------
+    double p[11];
+#pragma unroll
+    for (int c = 0; c < 11; ++c) p[c] = gs[G_REGA + A_POLY + c];
+    uint32_t chg = 0, sgn = 0;
+    {
+        bool sp = horner10(p, grid[16 * s]) < 0.0;
+        sgn = sp ? 1u : 0u;
+        for (int b = 0; b < 16; ++b) {
+            const bool sc = horner10(p, grid[16 * s + b + 1]) < 0.0;
+            chg |= (sc != sp) ? (1u << b) : 0u;
+            sgn |= sc ? (2u << b) : 0u;
+            sp = sc;
+        }
+    }
+    const int cnt = __popc(chg);
+    const int incl = row_scan_incl_i(cnt);
+    const int total = __shfl(incl, gbase + 15);
+    int slot = incl - cnt;
+    int* brk = reinterpret_cast<int*>(gs + G_REGA + A_BRK);
+    while (chg) {
+        const int b = __ffs(chg) - 1;
+        chg &= chg - 1;
+        if (slot < kMaxModels) brk[slot] = (16 * s + b) | (int)(((sgn >> b) & 1u) << 16);
+        ++slot;
+    }
+    wave_sync();
+    const int nb = min(total, kMaxModels);
+    if constexpr (DBG) {
+        if (s == 0) dbg->nroots[0] = (double)nb;
+    }
+    // ---- refine one root per sub-lane, back-substitute, build E -------------------------------------
+    bool valid = false;
+    if (s < nb) {
+        const int w = brk[s];
+        const int j = w & 0xFFFF;
+        const bool sprev = (w >> 16) & 1;
+        const double gprev = grid[j], g = grid[j + 1];
+        double z;
+        if (gprev >= 1.0 || g <= -1.0) {  // |z| > 1: solve for 1/z on the reversed polynomial
+            double rp[11];
+#pragma unroll
+            for (int c = 0; c < 11; ++c) rp[c] = gs[G_REGA + A_RPOLY + c];
+            const double wv = refine_root(rp, 1.0 / g, 1.0 / gprev, !sprev);
+            z = 1.0 / wv;
+        } else {
+            z = refine_root(p, gprev, g, sprev);
+        }
+        if constexpr (DBG) dbg->roots[s] = z;
+        double rw[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double* b = gs + G_BROW + 13 * i;
+            rw[i][0] = fma(fma(fma(b[3], z, b[2]), z, b[1]), z, b[0]);
+            rw[i][1] = fma(fma(fma(b[7], z, b[6]), z, b[5]), z, b[4]);
+            rw[i][2] = fma(fma(fma(fma(b[12], z, b[11]), z, b[10]), z, b[9]), z, b[8]);
+        }
+        double c01[3], c02[3], c12[3], cb[3];
+        cross3(rw[0], rw[1], c01);
+        cross3(rw[0], rw[2], c02);
+        cross3(rw[1], rw[2], c12);
+        double wb = fabs(c01[2]);
+        cb[0] = c01[0]; cb[1] = c01[1]; cb[2] = c01[2];
+        const bool t02 = fabs(c02[2]) > wb;
+        wb = t02 ? fabs(c02[2]) : wb;
+        sel3(t02, c02, cb);
+        const bool t12 = fabs(c12[2]) > wb;
+        sel3(t12, c12, cb);
+        const double x = cb[0] / cb[2], y = cb[1] / cb[2];
+        double E[9], n2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            E[m] = fma(x, gs[G_BASIS + m], fma(y, gs[G_BASIS + 9 + m], fma(z, gs[G_BASIS + 18 + m], gs[G_BASIS + 27 + m])));
+            n2 = fma(E[m], E[m], n2);
+        }
+        valid = (n2 > 0.0) && (n2 < 1.0e300);
+        const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+        for (int m = 0; m < 9; ++m) E[m] = E[m] * inv;
+        if (valid && smp) {  // oriented epipolar constraint on the minimal sample
+            const double c0[3] = {E[0], E[3], E[6]}, c1[3] = {E[1], E[4], E[7]}, c2[3] = {E[2], E[5], E[8]};
+            double e01[3], e02[3], e12[3], ep[3];
+            cross3(c0, c1, e01);
+            cross3(c0, c2, e02);
+            cross3(c1, c2, e12);
+            const double n01 = fma(e01[0], e01[0], fma(e01[1], e01[1], e01[2] * e01[2]));
+            const double n02 = fma(e02[0], e02[0], fma(e02[1], e02[1], e02[2] * e02[2]));
+            const double n12 = fma(e12[0], e12[0], fma(e12[1], e12[1], e12[2] * e12[2]));
+            double nbst = n01;
+            ep[0] = e01[0]; ep[1] = e01[1]; ep[2] = e01[2];
+            const bool u02 = n02 > nbst;
+            nbst = u02 ? n02 : nbst;
+            sel3(u02, e02, ep);
+            const bool u12 = n12 > nbst;
+            sel3(u12, e12, ep);
+            int npos = 0, nneg = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double x1 = smp[i].x, y1 = smp[i].y, x2 = smp[i].z, y2 = smp[i].w;
+                const double l0 = fma(E[0], x1, fma(E[1], y1, E[2]));
+                const double l1 = fma(E[3], x1, fma(E[4], y1, E[5]));
+                const double l2 = fma(E[6], x1, fma(E[7], y1, E[8]));
+                const double cx = fma(ep[1], 1.0, -(ep[2] * y2));
+                const double cy = fma(ep[2], x2, -(ep[0] * 1.0));
+                const double cz = fma(ep[0], y2, -(ep[1] * x2));
+                const double sg = fma(cx, l0, fma(cy, l1, cz * l2));
+                npos += sg > 0.0;
+                nneg += sg < 0.0;
+            }
+            valid = (npos == 5) || (nneg == 5);
+        }
+#pragma unroll
+        for (int m = 0; m < 9; ++m) E32[m] = (float)E[m];
+    }
+    return valid;
+}
+
+// ---- 3x3 SVD (one-sided Jacobi) and the four-candidate decomposition ----------------------------------
+// pose_utils.h:144-169: R1 = U D V^T, R2 = U D^T V^T, t = U[:,2]; det fixes as :157-163.
+PGI_DEV void svd3(const double E[9], double U[9], double S[3], double V[9]) {
+    double G[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        G[i] = E[i];
+        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (int sw = 0; sw < kSvdSweeps; ++sw) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+            const double al = fma(G[p], G[p], fma(G[3 + p], G[3 + p], G[6 + p] * G[6 + p]));
+            const double be = fma(G[q], G[q], fma(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
+            const double ga = fma(G[p], G[q], fma(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
+            if (ga == 0.0) continue;
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+            const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const double gp = G[3 * l + p], gq = G[3 * l + q];
+                G[3 * l + p] = fma(c, gp, -(s * gq));
+                G[3 * l + q] = fma(s, gp, c * gq);
+                const double vp = V[3 * l + p], vq = V[3 * l + q];
+                V[3 * l + p] = fma(c, vp, -(s * vq));
+                V[3 * l + q] = fma(s, vp, c * vq);
+            }
+        }
+    }
+    double sg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sg[j] = sqrt(fma(G[j], G[j], fma(G[3 + j], G[3 + j], G[6 + j] * G[6 + j])));
+    // stable selection sort (descending) as three compare-exchanges on (a,b) = (0,1),(0,2),(1,2)
+    int o0 = 0, o1 = 1, o2 = 2;
+    double s0 = sg[0], s1 = sg[1], s2 = sg[2];
+    if (s1 > s0) { double ts = s0; s0 = s1; s1 = ts; int to = o0; o0 = o1; o1 = to; }
+    if (s2 > s0) { double ts = s0; s0 = s2; s2 = ts; int to = o0; o0 = o2; o2 = to; }
+    if (s2 > s1) { double ts = s1; s1 = s2; s2 = ts; int to = o1; o1 = o2; o2 = to; }
+    S[0] = s0; S[1] = s1; S[2] = s2;
+    double Gs[9], Vs[9];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double g0 = G[3 * l + c], v0 = V[3 * l + c];
+            if (o0 == c) { Gs[3 * l + 0] = g0; Vs[3 * l + 0] = v0; }
+            if (o1 == c) { Gs[3 * l + 1] = g0; Vs[3 * l + 1] = v0; }
+            if (o2 == c) { Gs[3 * l + 2] = g0; Vs[3 * l + 2] = v0; }
+        }
+    }
+    const double i0 = 1.0 / S[0], i1 = 1.0 / S[1];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        U[3 * l + 0] = Gs[3 * l + 0] * i0;
+        U[3 * l + 1] = Gs[3 * l + 1] * i1;
+    }
+    const double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+    double u2[3];
+    cross3(u0, u1, u2);
+    U[2] = u2[0]; U[5] = u2[1]; U[8] = u2[2];
+    const double v0[3] = {Vs[0], Vs[3], Vs[6]}, v1[3] = {Vs[1], Vs[4], Vs[7]};
+    double vc[3];
+    cross3(v0, v1, vc);
+    const double dv = fma(vc[0], Vs[2], fma(vc[1], Vs[5], vc[2] * Vs[8]));
+    if (dv < 0.0) { Vs[2] = -Vs[2]; Vs[5] = -Vs[5]; Vs[8] = -Vs[8]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+}
+
+// candidates 0:(R1,+t) 1:(R1,-t) 2:(R2,+t) 3:(R2,-t)  (pose_utils.h:182,201)
+PGI_DEV void decompose_candidates(const double E[9], double R1[9], double R2[9], double t[3]) {
+    double U[9], S[3], V[9];
+    svd3(E, U, S, V);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double a = U[3 * i + 1] * V[3 * j + 0];
+            const double b = U[3 * i + 0] * V[3 * j + 1];
+            const double c = U[3 * i + 2] * V[3 * j + 2];
+            R1[3 * i + j] = (b - a) + c;
+            R2[3 * i + j] = (a - b) + c;
+        }
+    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+    const double tn = 1.0 / sqrt(fma(t[0], t[0], fma(t[1], t[1], t[2] * t[2])));
+    t[0] = t[0] * tn; t[1] = t[1] * tn; t[2] = t[2] * tn;
+}
+
+// depth signs of lambda2*x2 = lambda1*R*x1 + t: bit0 = (R,+t) in front of both, bit1 = (R,-t)
+PGI_DEV uint32_t cheirality_bits(const double R[9], const double t[3], const double X1[3],
+                                 const double X2[3], const double x2t[3]) {
+    double a[3], nn[3], at[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = fma(R[3 * i], X1[0], fma(R[3 * i + 1], X1[1], R[3 * i + 2]));
+    cross3(a, X2, nn);
+    cross3(a, t, at);
+    const double d1 = fma(x2t[0], nn[0], fma(x2t[1], nn[1], x2t[2] * nn[2]));
+    const double d2 = fma(at[0], nn[0], fma(at[1], nn[1], at[2] * nn[2]));
+    return ((d1 > 0.0) && (d2 > 0.0) ? 1u : 0u) | ((d1 < 0.0) && (d2 < 0.0) ? 2u : 0u);
+}
+
+}  // namespace pgi

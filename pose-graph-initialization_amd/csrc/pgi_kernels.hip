@@ -1,0 +1,1125 @@
+// pgi_kernels.hip -- HIP kernels (gfx950) + C ABI of the pairwise relative-pose engine.
+//
+// K1 estimate_pose_kernel : one 256-thread workgroup per image pair.  Correspondences are
+//    staged once from the flattened (pair,corr) SoA in HBM into LDS as float4 rows;
+//    each wavefront solves four 5-point hypotheses at a time (one per 16-lane DPP row),
+//    scores the resulting models over all rows with __ballot/popcount, the workgroup
+//    keeps the round's best, refits it on its inliers (n-point LO) and stops by the
+//    confidence rule; the epilogue writes the inlier mask and decomposes E into (R,t)
+//    with a cheirality vote -- "essential + decompose" in a single launch.
+//    Replaces PoseGraphBuilder::estimatePose (pose_graph_builder.h:940-1078).
+// K2 score_pose_*         : one model per pair -> inlier mask + count (HBM-bound).
+//    Replaces EssentialMatrixEvaluator::getInliers / InTraversalPoseTester::test
+//    (graph_traversal.h:136-168, 194-233).
+// K3 decompose_kernel     : E + rows -> (R,t) (pose_utils.h:144-252).
+// K5 five_point_kernel    : minimal solver on explicit samples (parity / debugging).
+#include "pgi_device.hpp"
+#include "../../include/pgi.h"
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+namespace pgi {
+
+constexpr int NW = 4;          // wavefronts per workgroup
+constexpr int NT = NW * 64;    // threads per workgroup
+constexpr int QCAP = 40;       // models per wavefront pass (4 hypotheses x 10 roots)
+constexpr int GRID_PAD = 264;  // 257 grid points padded
+constexpr double QMAGIC = 393216.0;  // 1.5 * 2^18: summands rounded to multiples of 2^-34
+
+struct WgShared {
+    float bestE[9];
+    int best_score;  // -1: none
+    uint32_t best_ninl;
+    float candE[NW][9];
+    int cand_score[NW];
+    uint32_t cand_ninl[NW];
+    uint32_t cand_hyp[NW];
+    uint32_t wave_cnt[NW];
+    uint32_t votes[4];
+    uint32_t q_count[NW];
+    uint32_t q_hyp[NW][QCAP];
+    uint32_t flag;
+    uint32_t mask_cnt;
+    double Rt[21];  // R1[9] R2[9] t[3]
+};
+
+struct K1Args {
+    const float* x1;
+    const float* y1;
+    const float* x2;
+    const float* y2;
+    const uint64_t* off;
+    const double* thr;
+    const double* guess;
+    const uint8_t* has_guess;
+    pgi_edge* edges;
+    uint8_t* masks;
+    uint32_t n_pairs;
+    uint32_t pts_cap;  // LDS rows reserved (multiple of 64); 0 = rows stay in HBM/L2
+    uint64_t pair_id_base;
+    uint64_t seed;
+    pgi_params prm;
+};
+
+// rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
+template <bool LDS_PTS>
+struct Rows {
+    const float4* lds;
+    const float* x1;
+    const float* y1;
+    const float* x2;
+    const float* y2;
+    uint32_t n;
+    PGI_DEV float4 get(uint32_t i) const {
+        if constexpr (LDS_PTS) {
+            return lds[i];
+        } else {
+            const float nanv = __builtin_nanf("");
+            if (i < n) return make_float4(x1[i], y1[i], x2[i], y2[i]);
+            return make_float4(nanv, nanv, nanv, nanv);
+        }
+    }
+};
+
+PGI_DEV void edge_clear(pgi_edge* e) {
+    double* d = reinterpret_cast<double*>(e);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(pgi_edge) / 8); ++i) d[i] = 0.0;
+}
+
+PGI_DEV float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Score queue models [m_begin, m_end) in blocks of four; keeps the first maximum.
+// The counters are wave-uniform popcounts of ballots (SGPR arithmetic).
+template <bool LDS_PTS>
+PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t npad, const float* queue,
+                         const uint32_t* qhyp, int m_begin, int m_end, float thr2, int lane,
+                         int& b_score, uint32_t& b_ninl, uint32_t& b_hyp, int& b_idx) {
+    for (int m0 = m_begin; m0 < m_end; m0 += 4) {
+        float e[4][9];
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const int m = min(m0 + mm, m_end - 1);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) e[mm][c] = rfl(queue[9 * m + c]);
+        }
+        uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
+        for (uint32_t base = 0; base < npad; base += 64) {
+            const float4 p = rows.get(base + lane);
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                float r2, den;
+                sampson_terms(e[mm], p.x, p.y, p.z, p.w, r2, den);
+                const float t = thr2 * den;
+                const uint32_t c0 = __popcll(__ballot(r2 < 0.25f * t));
+                const uint32_t c1 = __popcll(__ballot(r2 < 0.5625f * t));
+                const uint32_t c2 = __popcll(__ballot(r2 < t));
+                const uint32_t c3 = __popcll(__ballot(r2 < 2.25f * t));
+                sc[mm] += (c0 + c1) + (c2 + c3);
+                ni[mm] += c2;
+            }
+        }
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            if (m0 + mm < m_end && (int)sc[mm] > b_score) {
+                b_score = (int)sc[mm];
+                b_ninl = ni[mm];
+                b_hyp = qhyp ? qhyp[m0 + mm] : 0u;
+                b_idx = m0 + mm;
+            }
+        }
+    }
+}
+
+// Append the valid models of a wavefront (one per lane) to its queue in lane order.
+PGI_DEV int enqueue_models(bool valid, const float E32[9], uint32_t hyp, float* queue, uint32_t* qhyp,
+                           int lane) {
+    const uint64_t bal = __ballot(valid);
+    const int slot = __popcll(bal & ((1ull << lane) - 1ull));
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) queue[9 * slot + c] = E32[c];
+        qhyp[slot] = hyp;
+    }
+    return __popcll(bal);
+}
+
+// Inlier set of model E at bound tau2 -> exact 9x9 normal matrix in loA (LDS) and the
+// inlier count.  Summands are pre-rounded to 2^-34 so every summation order agrees.
+template <bool LDS_PTS>
+PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
+                                  double* loA, double* partial, WgShared* sh, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    double S[45];
+#pragma unroll
+    for (int i = 0; i < 45; ++i) S[i] = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < npad; base += NT) {
+        const uint32_t i = base + tid;
+        const float nanv = __builtin_nanf("");
+        const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
+        float r2, den;
+        sampson_terms(E, p.x, p.y, p.z, p.w, r2, den);
+        const bool in = r2 < tau2 * den;
+        cnt += __popcll(__ballot(in));
+        if (in) {
+            const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
+            double a[9];
+            a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
+            a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
+            a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+#pragma unroll
+            for (int ii = 0; ii < 9; ++ii)
+#pragma unroll
+                for (int jj = ii; jj < 9; ++jj) {
+                    constexpr int kTri[9] = {0, 9, 17, 24, 30, 35, 39, 42, 44};
+                    const int k = kTri[ii] + (jj - ii);
+                    double t = a[ii] * a[jj];
+                    t = (t + QMAGIC) - QMAGIC;
+                    S[k] = S[k] + t;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 45; ++i) {
+        const double v = wave_sum_exact(S[i]);
+        if (lane == 0) partial[45 * w + i] = v;
+    }
+    if (lane == 0) sh->wave_cnt[w] = cnt;
+    __syncthreads();
+    if (tid < 45) {
+        double v = partial[tid];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v = v + partial[45 * ww + tid];
+        // unrank tid -> (i,j), i <= j
+        int i = 0, rem = tid;
+        while (rem >= 9 - i) {
+            rem -= 9 - i;
+            ++i;
+        }
+        const int j = i + rem;
+        loA[9 * i + j] = v;
+        loA[9 * j + i] = v;
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) total += sh->wave_cnt[ww];
+    __syncthreads();
+    return total;
+}
+
+// Tournament-ordered cyclic Jacobi on the 9x9 matrix in LDS (one wavefront, 36 lanes:
+// pair m = lane / 9, index l = lane % 9), then the 4 smallest eigenvectors -> basis of
+// every group of this wavefront (W = smallest, then Z, Y, X).
+PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
+    for (int i = lane; i < 81; i += 64) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
+    wave_sync();
+    const int m = lane / 9, l = lane - 9 * m;
+    const bool act = lane < 36;
+    for (int sw = 0; sw < kJacobiSweeps; ++sw)
+        for (int r = 0; r < 9; ++r) {
+            int p = (r + m + 1) % 9, q = (r + 9 - (m + 1)) % 9;
+            if (p > q) {
+                const int tq = p;
+                p = q;
+                q = tq;
+            }
+            double c = 1.0, s = 0.0;
+            if (act) {
+                const double apq = A[9 * p + q];
+                if (apq != 0.0) {
+                    const double tau = (A[10 * q] - A[10 * p]) / (2.0 * apq);
+                    const double den = fabs(tau) + sqrt(fma(tau, tau, 1.0));
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / den;
+                    c = 1.0 / sqrt(fma(t, t, 1.0));
+                    s = t * c;
+                }
+            }
+            wave_sync();
+            if (act) {  // column phase: A <- A J, V <- V J
+                const double ap = A[9 * l + p], aq = A[9 * l + q];
+                A[9 * l + p] = fma(c, ap, -(s * aq));
+                A[9 * l + q] = fma(s, ap, c * aq);
+                const double vp = V[9 * l + p], vq = V[9 * l + q];
+                V[9 * l + p] = fma(c, vp, -(s * vq));
+                V[9 * l + q] = fma(s, vp, c * vq);
+            }
+            wave_sync();
+            if (act) {  // row phase: A <- J^T A
+                const double ap = A[9 * p + l], aq = A[9 * q + l];
+                A[9 * p + l] = fma(c, ap, -(s * aq));
+                A[9 * q + l] = fma(s, ap, c * aq);
+            }
+            wave_sync();
+        }
+    // four smallest eigenvalues, first minimum wins ties
+    double d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = A[10 * i];
+    uint32_t taken = 0;
+    const int g = lane >> 4, s16 = lane & 15;
+#pragma unroll
+    for (int rank = 0; rank < 4; ++rank) {
+        int bi = -1;
+        double bv = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const bool free_i = !((taken >> i) & 1u);
+            if (free_i && (bi < 0 || d[i] < bv)) {
+                bi = i;
+                bv = d[i];
+            }
+        }
+        taken |= 1u << bi;
+        if (s16 < 9) gscr[g * G_DOUBLES + G_BASIS + 9 * (3 - rank) + s16] = V[9 * s16 + bi];
+    }
+    wave_sync();
+}
+
+// n-point refit of model E's inlier set (bound tau2) -> models in wave 0's queue, scored
+// by all wavefronts.  Returns the inlier count; outputs the best refit model.
+template <bool LDS_PTS>
+PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
+                                 float thr2, double* loA, double* loV, double* partial, double* wscr,
+                                 const double* grid, float* queue0, WgShared* sh, int tid,
+                                 int& r_score, uint32_t& r_ninl, float rE[9]) {
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t ni = normal_matrix_wg<LDS_PTS>(rows, npad, E, tau2, loA, partial, sh, tid);
+    r_score = -1;
+    r_ninl = 0;
+    if (ni < 5) return ni;  // uniform
+    if (w == 0) {
+        jacobi9_wave(loA, loV, wscr, lane);
+        float E32[9];
+        const int g = lane >> 4, s = lane & 15;
+        const bool valid = backend_group<false>(wscr + g * G_DOUBLES, grid, s, g * 16, nullptr, E32, nullptr);
+        const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
+        if (lane == 0) sh->q_count[0] = (uint32_t)cnt;
+    }
+    __syncthreads();
+    const int count = (int)sh->q_count[0];
+    int b_score = -1, b_idx = -1;
+    uint32_t b_ninl = 0, b_hyp = 0;
+    const int mb = 4 * w, me = min(count, 4 * w + 4);
+    if (mb < me) score_queue<LDS_PTS>(rows, npad, queue0, nullptr, mb, me, thr2, lane, b_score, b_ninl, b_hyp, b_idx);
+    if (lane == 0) {
+        sh->cand_score[w] = b_score;
+        sh->cand_ninl[w] = b_ninl;
+        sh->cand_hyp[w] = (uint32_t)b_idx;
+    }
+    __syncthreads();
+    int bw = -1;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww)
+        if (sh->cand_score[ww] > r_score) {
+            r_score = sh->cand_score[ww];
+            bw = ww;
+        }
+    if (bw >= 0) {
+        r_ninl = sh->cand_ninl[bw];
+        const int idx = (int)sh->cand_hyp[bw];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) rE[c] = queue0[9 * idx + c];
+    }
+    __syncthreads();
+    return ni;
+}
+
+template <bool LDS_PTS>
+__global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t pair = blockIdx.x;
+    const uint64_t o = a.off[pair];
+    const uint32_t n = (uint32_t)(a.off[pair + 1] - o);
+    const uint32_t npad = (n + 63u) & ~63u;
+
+    float4* pts = reinterpret_cast<float4*>(smem);
+    double* grid = reinterpret_cast<double*>(smem + (size_t)a.pts_cap * 16);
+    double* wscr_all = grid + GRID_PAD;                   // NW * 4 * G_DOUBLES
+    double* loA = wscr_all + NW * 4 * G_DOUBLES;          // 81
+    double* loV = loA + 81;                               // 81
+    double* partial = loV + 81;                           // NW * 45
+    float* queue_all = reinterpret_cast<float*>(partial + NW * 45 + 1);  // NW * QCAP * 9
+    WgShared* sh = reinterpret_cast<WgShared*>(queue_all + NW * QCAP * 9);
+    double* wscr = wscr_all + w * 4 * G_DOUBLES;
+    float* queue = queue_all + w * QCAP * 9;
+
+    Rows<LDS_PTS> rows;
+    rows.lds = pts;
+    rows.x1 = a.x1 + o; rows.y1 = a.y1 + o; rows.x2 = a.x2 + o; rows.y2 = a.y2 + o;
+    rows.n = n;
+
+    pgi_edge* edge = a.edges + pair;
+    uint8_t* mask = a.masks + o;
+
+    // ---- stage the pair: coalesced SoA reads from HBM -> float4 rows in LDS ----
+    if constexpr (LDS_PTS) {
+        const float nanv = __builtin_nanf("");
+        for (uint32_t i = tid; i < npad; i += NT)
+            pts[i] = (i < n) ? make_float4(rows.x1[i], rows.y1[i], rows.x2[i], rows.y2[i])
+                             : make_float4(nanv, nanv, nanv, nanv);
+    }
+    for (int j = tid; j <= kGrid; j += NT) grid[j] = grid_point(j);
+    if (tid == 0) {
+        sh->best_score = -1;
+        sh->best_ninl = 0;
+        sh->votes[0] = sh->votes[1] = sh->votes[2] = sh->votes[3] = 0;
+        sh->mask_cnt = 0;
+    }
+    __syncthreads();
+
+    const double thr = a.thr[pair];
+    const float thr2 = (float)(thr * thr);
+    const pgi_params prm = a.prm;
+
+    if (n < 5) {
+        for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
+        if (tid == 0) {
+            edge_clear(edge);
+            edge->status = PGI_EDGE_FEW_POINTS;
+        }
+        return;
+    }
+
+    uint32_t out_iters = 0, out_lo = 0, out_used_guess = 0, out_score = 0;
+    float finalE[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) finalE[c] = 0.f;
+    float mask_tau2 = thr2;
+    bool success = false, have_model = false;
+    uint32_t guess_ninl = 0;
+
+    // ---- pose guess (pose_graph_builder.h:974-1029) ----
+    if (a.guess && a.has_guess && a.has_guess[pair]) {
+        const double* G = a.guess + 12 * (size_t)pair;
+        const double R[9] = {G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7], G[8]};
+        const double t[3] = {G[9], G[10], G[11]};
+        // E = [t]x R (pose_utils.h:74-86), plain mul/add like the reference
+        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        double Eg[9], n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += tx[3 * i + k] * R[3 * k + j];
+                Eg[3 * i + j] = s;
+            }
+#pragma unroll
+        for (int m = 0; m < 9; ++m) n2 = fma(Eg[m], Eg[m], n2);
+        const double inv = 1.0 / sqrt(n2);
+        float Ef[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) Ef[m] = (float)(Eg[m] * inv);
+        const double trunc = 1.5 * thr;
+        const float tau2 = prm.guess_quirk ? (float)trunc : (float)(trunc * trunc);
+        int r_score;
+        uint32_t r_ninl;
+        float rE[9];
+        const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, loA, loV, partial, wscr_all, grid,
+                                                     queue_all, sh, tid, r_score, r_ninl, rE);
+        if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
+            success = true;
+            have_model = true;
+            out_used_guess = 1;
+            out_lo = 1;
+            out_score = (uint32_t)r_score;
+            guess_ninl = ni;
+            mask_tau2 = tau2;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) finalE[c] = rE[c];
+            // the mask of the guess path is the guess's inlier set (:1000-1009)
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sh->bestE[c] = Ef[c];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- robust fit (pose_graph_builder.h:1031-1055) ----
+    if (!success) {
+        const uint64_t rng_base = mix64(a.seed ^ mix64(a.pair_id_base + pair));
+        const uint32_t rs = prm.round_size ? prm.round_size : 32u;
+        const uint32_t budget = prm.fixed_budget ? prm.fixed_budget : prm.max_iters;
+        uint32_t hyps = 0;
+        const int g = lane >> 4, s = lane & 15;
+        while (hyps < budget) {
+            int wb_score = -1;
+            uint32_t wb_ninl = 0, wb_hyp = 0;
+            float wbE[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) wbE[c] = 0.f;
+            for (uint32_t pass = 0; pass * (NW * 4) < rs; ++pass) {
+                const uint32_t local = pass * (NW * 4) + w * 4 + g;
+                const bool active = local < rs;
+                const uint32_t hyp = hyps + (active ? local : 0u);
+                uint32_t idx[5];
+                sample5(rng_base, hyp, n, idx);
+                float4 smp[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) smp[k] = rows.get(idx[k]);
+                float4 mine = smp[0];
+#pragma unroll
+                for (int k = 1; k < 5; ++k)
+                    if (s == k) mine = smp[k];
+                nullspace5_group(mine, s, g * 16, wscr + g * G_DOUBLES);
+                float E32[9];
+                const bool valid =
+                    backend_group<false>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr);
+                const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
+                wave_sync();
+                int bidx = -1;
+                score_queue<LDS_PTS>(rows, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, wb_score, wb_ninl, wb_hyp, bidx);
+                if (bidx >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) wbE[c] = queue[9 * bidx + c];
+                }
+                wave_sync();
+            }
+            if (lane == 0) {
+                sh->cand_score[w] = wb_score;
+                sh->cand_ninl[w] = wb_ninl;
+                sh->cand_hyp[w] = wb_hyp;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sh->candE[w][c] = wbE[c];
+            }
+            __syncthreads();
+            hyps += rs;
+            // round best: score desc, hypothesis index asc
+            int rb = -1, rbw = -1;
+            uint32_t rbh = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const int cs = sh->cand_score[ww];
+                const uint32_t ch = sh->cand_hyp[ww];
+                if (cs > rb || (cs == rb && cs >= 0 && ch < rbh)) {
+                    rb = cs;
+                    rbw = ww;
+                    rbh = ch;
+                }
+            }
+            const bool improve = (rb >= 0) && (rb > sh->best_score);
+            __syncthreads();
+            if (improve) {
+                if (tid == 0) {
+                    sh->best_score = rb;
+                    sh->best_ninl = sh->cand_ninl[rbw];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) sh->bestE[c] = sh->candE[rbw][c];
+                }
+                __syncthreads();
+                // local optimisation: n-point refits while they improve
+                for (uint32_t it = 0; it < prm.lo_iters; ++it) {
+                    float bE[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
+                    int r_score;
+                    uint32_t r_ninl;
+                    float rE[9];
+                    const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, bE, thr2, thr2, loA, loV, partial,
+                                                                 wscr_all, grid, queue_all, sh, tid, r_score,
+                                                                 r_ninl, rE);
+                    if (ni < 5) break;
+                    ++out_lo;
+                    const bool better = r_score > sh->best_score;
+                    __syncthreads();
+                    if (!better) break;
+                    if (tid == 0) {
+                        sh->best_score = r_score;
+                        sh->best_ninl = r_ninl;
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
+                    }
+                    __syncthreads();
+                }
+            }
+            if (!prm.fixed_budget && sh->best_score >= 0 && sh->best_ninl >= 5) {
+                const double rho = (double)sh->best_ninl / (double)n;
+                const double r5 = ((rho * rho) * (rho * rho)) * rho;
+                const double q = 1.0 - r5;
+                if (pow_uint(q, hyps) <= 1.0 - prm.confidence) break;
+            }
+        }
+        out_iters = hyps;
+        have_model = sh->best_score >= 0;
+        if (have_model) {
+            out_score = (uint32_t)sh->best_score;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) finalE[c] = sh->bestE[c];
+        }
+    }
+
+    // ---- epilogue: mask, count, decomposition (pose_graph_builder.h:1057-1075) ----
+    if (!have_model) {
+        for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
+        if (tid == 0) {
+            edge_clear(edge);
+            edge->status = PGI_EDGE_FEW_INLIERS;
+            edge->iters = out_iters;
+            edge->lo_runs = out_lo;
+        }
+        return;
+    }
+    float maskE[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) maskE[c] = success ? sh->bestE[c] : finalE[c];
+    double Ed[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ed[c] = (double)finalE[c];
+    if (tid == 0) {
+        double R1[9], R2[9], t[3];
+        decompose_candidates(Ed, R1, R2, t);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            sh->Rt[c] = R1[c];
+            sh->Rt[9 + c] = R2[c];
+        }
+        sh->Rt[18] = t[0]; sh->Rt[19] = t[1]; sh->Rt[20] = t[2];
+    }
+    __syncthreads();
+    double R1[9], R2[9], tt[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        R1[c] = sh->Rt[c];
+        R2[c] = sh->Rt[9 + c];
+    }
+    tt[0] = sh->Rt[18]; tt[1] = sh->Rt[19]; tt[2] = sh->Rt[20];
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, mc = 0;
+    for (uint32_t base = 0; base < npad; base += NT) {
+        const uint32_t i = base + tid;
+        const float nanv = __builtin_nanf("");
+        const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
+        float r2, den;
+        sampson_terms(maskE, p.x, p.y, p.z, p.w, r2, den);
+        const bool in = r2 < mask_tau2 * den;
+        if (i < n) mask[i] = in ? 1 : 0;
+        mc += __popcll(__ballot(in));
+        const bool voter = (i < n) && (prm.vote_all_rows || in);
+        uint32_t b1 = 0, b2 = 0;
+        if (voter) {
+            const double X1[3] = {p.x, p.y, 1.0}, X2[3] = {p.z, p.w, 1.0};
+            double x2t[3];
+            cross3(X2, tt, x2t);
+            b1 = cheirality_bits(R1, tt, X1, X2, x2t);
+            b2 = cheirality_bits(R2, tt, X1, X2, x2t);
+        }
+        v0 += __popcll(__ballot(b1 & 1u));
+        v1 += __popcll(__ballot(b1 & 2u));
+        v2 += __popcll(__ballot(b2 & 1u));
+        v3 += __popcll(__ballot(b2 & 2u));
+    }
+    if (lane == 0) {
+        atomicAdd(&sh->votes[0], v0);
+        atomicAdd(&sh->votes[1], v1);
+        atomicAdd(&sh->votes[2], v2);
+        atomicAdd(&sh->votes[3], v3);
+        atomicAdd(&sh->mask_cnt, mc);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        edge_clear(edge);
+        const uint32_t n_inl = success ? guess_ninl : sh->mask_cnt;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) edge->E[c] = Ed[c];
+        edge->n_inl = n_inl;
+        edge->score = out_score;
+        edge->iters = out_iters;
+        edge->lo_runs = out_lo;
+        edge->used_guess = out_used_guess;
+        if (n_inl < prm.min_inliers) {
+            edge->status = PGI_EDGE_FEW_INLIERS;  // :1053-1054 (no decomposition)
+        } else {
+            const uint32_t vt0 = sh->votes[0], vt1 = sh->votes[1], vt2 = sh->votes[2], vt3 = sh->votes[3];
+            uint32_t best = 0, bv = vt0;
+            if (vt1 > bv) { bv = vt1; best = 1; }
+            if (vt2 > bv) { bv = vt2; best = 2; }
+            if (vt3 > bv) { bv = vt3; best = 3; }
+            const bool second = (best >> 1) != 0;
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double rv = second ? R2[c] : R1[c];
+                edge->R[c] = rv;
+                bad |= !(rv == rv);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                edge->t[c] = (best & 1u) ? -tt[c] : tt[c];
+                bad |= !(tt[c] == tt[c]);
+            }
+            edge->votes = bv;
+            edge->cand = best;
+            edge->status = bad ? PGI_EDGE_NAN : PGI_EDGE_OK;  // :1069-1070
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: one model per pair; one wavefront per pair streams the SoA rows with float4 loads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_pose_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                         const float* __restrict__ x2, const float* __restrict__ y2,
+                                                         const uint64_t* __restrict__ off, const double* __restrict__ Ein,
+                                                         const double* __restrict__ tau2in, uint32_t n_pairs,
+                                                         uint32_t* __restrict__ counts, uint8_t* __restrict__ masks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
+    const uint64_t o = off[pair];
+    const uint32_t n = (uint32_t)(off[pair + 1] - o);
+    float e[9];
+    {
+        double n2 = 0.0, Ed[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            Ed[c] = Ein[9 * (size_t)pair + c];
+            n2 = fma(Ed[c], Ed[c], n2);
+        }
+        const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) e[c] = (float)(Ed[c] * inv);
+    }
+    const float tau2 = (float)tau2in[pair];
+    const float* px1 = x1 + o;
+    const float* py1 = y1 + o;
+    const float* px2 = x2 + o;
+    const float* py2 = y2 + o;
+    uint8_t* pm = masks ? masks + o : nullptr;
+    uint32_t cnt = 0;
+    // head rows until the float4 stream is 16-byte aligned (o is arbitrary)
+    const uint32_t head = min(n, (uint32_t)((4 - (o & 3)) & 3));
+    if ((uint32_t)lane < head) {
+        float r2, den;
+        sampson_terms(e, px1[lane], py1[lane], px2[lane], py2[lane], r2, den);
+        const bool in = r2 < tau2 * den;
+        if (pm) pm[lane] = in;
+        cnt += in;
+    }
+    const uint32_t nv = (n - head) / 4;
+    const float4* vx1 = reinterpret_cast<const float4*>(px1 + head);
+    const float4* vy1 = reinterpret_cast<const float4*>(py1 + head);
+    const float4* vx2 = reinterpret_cast<const float4*>(px2 + head);
+    const float4* vy2 = reinterpret_cast<const float4*>(py2 + head);
+    for (uint32_t i = lane; i < nv; i += 64) {
+        const float4 a = vx1[i], b = vy1[i], c = vx2[i], d = vy2[i];
+        float r2, den;
+        uint32_t m = 0;
+        sampson_terms(e, a.x, b.x, c.x, d.x, r2, den); m |= (r2 < tau2 * den) ? 1u : 0u;
+        sampson_terms(e, a.y, b.y, c.y, d.y, r2, den); m |= (r2 < tau2 * den) ? 0x100u : 0u;
+        sampson_terms(e, a.z, b.z, c.z, d.z, r2, den); m |= (r2 < tau2 * den) ? 0x10000u : 0u;
+        sampson_terms(e, a.w, b.w, c.w, d.w, r2, den); m |= (r2 < tau2 * den) ? 0x1000000u : 0u;
+        if (pm) *reinterpret_cast<uint32_t*>(pm + head + 4 * (size_t)i) = m;
+        cnt += __popc(m);
+    }
+    const uint32_t done = head + 4 * nv;
+    if (done + lane < n) {
+        const uint32_t i = done + lane;
+        float r2, den;
+        sampson_terms(e, px1[i], py1[i], px2[i], py2[i], r2, den);
+        const bool in = r2 < tau2 * den;
+        if (pm) pm[i] = in;
+        cnt += in;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+    if (lane == 0) counts[pair] = cnt;
+}
+
+// f64 AoS rows, the reference's own operation order (graph_traversal.h:107-115)
+__global__ __launch_bounds__(256) void score_pose_f64_kernel(const double* __restrict__ corr, const uint64_t* __restrict__ off,
+                                                             const double* __restrict__ Ein, const double* __restrict__ tau2in,
+                                                             uint32_t n_pairs, uint32_t* __restrict__ counts,
+                                                             uint8_t* __restrict__ masks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
+    const uint64_t o = off[pair];
+    const uint32_t n = (uint32_t)(off[pair + 1] - o);
+    const double* E = Ein + 9 * (size_t)pair;
+    const double e11 = E[0], e12 = E[1], e13 = E[2], e21 = E[3], e22 = E[4], e23 = E[5], e31 = E[6], e32 = E[7],
+                 e33 = E[8];
+    const double tau2 = tau2in[pair];
+    const double4* rowsv = reinterpret_cast<const double4*>(corr + 4 * o);
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const double4 s = rowsv[i];
+        const double x1 = s.x, y1 = s.y, x2 = s.z, y2 = s.w;
+        const double rxc = e11 * x2 + e21 * y2 + e31;
+        const double ryc = e12 * x2 + e22 * y2 + e32;
+        const double rwc = e13 * x2 + e23 * y2 + e33;
+        const double r = (x1 * rxc + y1 * ryc + rwc);
+        const double rx = e11 * x1 + e12 * y1 + e13;
+        const double ry = e21 * x1 + e22 * y1 + e23;
+        const double sq = r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+        const bool in = sq < tau2;
+        if (masks) masks[o + i] = in;
+        cnt += in;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+    if (lane == 0) counts[pair] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: decomposition of a given E per pair (one workgroup per pair).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decompose_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                        const float* __restrict__ x2, const float* __restrict__ y2,
+                                                        const uint64_t* __restrict__ off, const double* __restrict__ Ein,
+                                                        const uint8_t* __restrict__ masks, pgi_edge* __restrict__ edges) {
+    __shared__ double Rt[21];
+    __shared__ uint32_t votes[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t pair = blockIdx.x;
+    const uint64_t o = off[pair];
+    const uint32_t n = (uint32_t)(off[pair + 1] - o);
+    if (tid == 0) {
+        double Ed[9], R1[9], R2[9], t[3];
+        for (int c = 0; c < 9; ++c) Ed[c] = Ein[9 * (size_t)pair + c];
+        decompose_candidates(Ed, R1, R2, t);
+        for (int c = 0; c < 9; ++c) {
+            Rt[c] = R1[c];
+            Rt[9 + c] = R2[c];
+        }
+        Rt[18] = t[0]; Rt[19] = t[1]; Rt[20] = t[2];
+        votes[0] = votes[1] = votes[2] = votes[3] = 0;
+    }
+    __syncthreads();
+    double R1[9], R2[9], tt[3];
+    for (int c = 0; c < 9; ++c) {
+        R1[c] = Rt[c];
+        R2[c] = Rt[9 + c];
+    }
+    tt[0] = Rt[18]; tt[1] = Rt[19]; tt[2] = Rt[20];
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + tid;
+        const bool voter = (i < n) && (!masks || masks[o + i]);
+        uint32_t b1 = 0, b2 = 0;
+        if (voter) {
+            const double X1[3] = {x1[o + i], y1[o + i], 1.0}, X2[3] = {x2[o + i], y2[o + i], 1.0};
+            double x2t[3];
+            cross3(X2, tt, x2t);
+            b1 = cheirality_bits(R1, tt, X1, X2, x2t);
+            b2 = cheirality_bits(R2, tt, X1, X2, x2t);
+        }
+        v0 += __popcll(__ballot(b1 & 1u));
+        v1 += __popcll(__ballot(b1 & 2u));
+        v2 += __popcll(__ballot(b2 & 1u));
+        v3 += __popcll(__ballot(b2 & 2u));
+    }
+    if (lane == 0) {
+        atomicAdd(&votes[0], v0);
+        atomicAdd(&votes[1], v1);
+        atomicAdd(&votes[2], v2);
+        atomicAdd(&votes[3], v3);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t best = 0;
+        for (uint32_t c = 1; c < 4; ++c)
+            if (votes[c] > votes[best]) best = c;
+        pgi_edge* e = edges + pair;
+        const double* Rb = (best >> 1) ? R2 : R1;
+        for (int c = 0; c < 9; ++c) e->R[c] = Rb[c];
+        for (int c = 0; c < 3; ++c) e->t[c] = (best & 1u) ? -tt[c] : tt[c];
+        e->votes = votes[best];
+        e->cand = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: minimal solver on explicit samples; one 16-lane group per sample, 4 samples per wavefront.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void five_point_kernel(const float* __restrict__ pts, uint32_t n_samples,
+                                                        float* __restrict__ models, uint32_t* __restrict__ counts,
+                                                        double* __restrict__ dbgout) {
+    __shared__ double grid[GRID_PAD];
+    __shared__ double scr[4 * G_DOUBLES];
+    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15;
+    for (int j = lane; j <= kGrid; j += 64) grid[j] = grid_point(j);
+    __syncthreads();
+    const uint32_t smp_i = min(blockIdx.x * 4 + g, n_samples - 1);
+    const bool active = blockIdx.x * 4 + g < n_samples;
+    float4 smp[5];
+    for (int k = 0; k < 5; ++k) {
+        const float* p = pts + 20 * (size_t)smp_i + 4 * k;
+        smp[k] = make_float4(p[0], p[1], p[2], p[3]);
+    }
+    float4 mine = smp[0];
+    for (int k = 1; k < 5; ++k)
+        if (s == k) mine = smp[k];
+    double* gs = scr + g * G_DOUBLES;
+    nullspace5_group(mine, s, g * 16, gs);
+    float E32[9];
+    bool valid;
+    if (dbgout) {
+        double* d = dbgout + (size_t)smp_i * PGI_DBG_DOUBLES;
+        if (active && s < 9)
+            for (int f = 0; f < 4; ++f) d[9 * f + s] = gs[G_BASIS + 9 * f + s];
+        BackendDbg dbg{d + 36, d + 236, d + 336, d + 347, d + 357};
+        if (active && s < 10) d[347 + s] = 0.0;
+        valid = backend_group<true>(gs, grid, s, g * 16, smp, E32, &dbg);
+    } else {
+        valid = backend_group<false>(gs, grid, s, g * 16, smp, E32, nullptr);
+    }
+    // compact the valid roots of each group in root order
+    const uint64_t bal = __ballot(valid);
+    const uint32_t gb = (uint32_t)((bal >> (16 * g)) & 0xFFFFu);
+    const int slot = __popc(gb & ((1u << s) - 1u));
+    if (active && valid)
+        for (int c = 0; c < 9; ++c) models[(size_t)smp_i * 90 + 9 * slot + c] = E32[c];
+    if (active && s == 0) counts[smp_i] = __popc(gb);
+}
+
+}  // namespace pgi
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace pgi;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (x);                                                                         \
+        if (_e != hipSuccess)                                                                        \
+            return fail(PGI_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+struct pgi_ctx {
+    int device;
+    hipStream_t stream;
+    pgi_params prm;
+    std::mutex mu;
+    // scratch for the single-pair drop-in
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int max_lds = 0;
+};
+
+static size_t k1_fixed_lds() {
+    return (size_t)GRID_PAD * 8 + (size_t)NW * 4 * G_DOUBLES * 8 + (81 + 81 + NW * 45 + 1) * 8 +
+           (size_t)NW * QCAP * 9 * 4 + sizeof(WgShared) + 64;
+}
+
+extern "C" {
+
+const char* pgi_last_error(void) { return g_err.c_str(); }
+
+int pgi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void pgi_default_params(pgi_params* p) {
+    p->confidence = 0.99;
+    p->max_iters = 1000;
+    p->round_size = 32;
+    p->lo_iters = 2;
+    p->min_inliers = 20;
+    p->fixed_budget = 0;
+    p->guess_quirk = 1;
+    p->vote_all_rows = 0;
+    p->reserved = 0;
+}
+
+pgi_ctx* pgi_create(int device, const pgi_params* params) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        g_err = "pgi_create: no HIP device (this library has no CPU fallback)";
+        return nullptr;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) {
+        g_err = "pgi_create: device index out of range";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_err = "pgi_create: hipSetDevice failed";
+        return nullptr;
+    }
+    pgi_ctx* c = new (std::nothrow) pgi_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    c->stream = nullptr;
+    if (params) c->prm = *params; else pgi_default_params(&c->prm);
+    int lds = 0;
+    (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+    c->max_lds = lds > 0 ? lds : 65536;
+    return c;
+}
+
+void pgi_destroy(pgi_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    delete ctx;
+}
+
+int pgi_set_stream(pgi_ctx* ctx, void* s) {
+    if (!ctx) return fail(PGI_ERR_INVALID, "null ctx");
+    ctx->stream = (hipStream_t)s;
+    return PGI_SUCCESS;
+}
+
+int pgi_set_params(pgi_ctx* ctx, const pgi_params* p) {
+    if (!ctx || !p) return fail(PGI_ERR_INVALID, "null argument");
+    if (!(p->confidence > 0.0 && p->confidence < 1.0)) return fail(PGI_ERR_INVALID, "confidence must be in (0,1)");
+    ctx->prm = *p;
+    return PGI_SUCCESS;
+}
+
+int pgi_synchronize(pgi_ctx* ctx) {
+    if (!ctx) return fail(PGI_ERR_INVALID, "null ctx");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PGI_SUCCESS;
+}
+
+int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
+    if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
+    if (b->n_pairs == 0) return PGI_SUCCESS;
+    if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
+        return fail(PGI_ERR_INVALID, "batch pointers missing");
+    K1Args a;
+    a.x1 = b->d_x1; a.y1 = b->d_y1; a.x2 = b->d_x2; a.y2 = b->d_y2;
+    a.off = b->d_offsets; a.thr = b->d_thr; a.guess = b->d_guess_Rt; a.has_guess = b->d_has_guess;
+    a.edges = d_edges; a.masks = d_masks; a.n_pairs = b->n_pairs;
+    a.pair_id_base = b->pair_id_base; a.seed = b->seed; a.prm = ctx->prm;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t cap = (b->max_corr + 63u) & ~63u;
+    const size_t lds_rows = (size_t)cap * 16 + k1_fixed_lds();
+    if (lds_rows <= (size_t)ctx->max_lds) {
+        a.pts_cap = cap;
+        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        hipLaunchKernelGGL(estimate_pose_kernel<true>, dim3(b->n_pairs), dim3(NT), lds_rows, ctx->stream, a);
+    } else {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
+        a.pts_cap = 0;
+        const size_t lds = k1_fixed_lds();
+        hipLaunchKernelGGL(estimate_pose_kernel<false>, dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, const double* guesses, uint32_t g,
+                      uint64_t seed, uint64_t pair_id, pgi_edge* h_edge, uint8_t* h_mask) {
+    if (!ctx || !corr || !h_edge || !h_mask) return fail(PGI_ERR_INVALID, "null argument");
+    if (g && !guesses) return fail(PGI_ERR_INVALID, "guess count without guesses");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    // layout of the scratch: x1 y1 x2 y2 (n floats each) | off[2] | thr | guess[12] | has | edge | mask
+    const size_t nf = ((size_t)n + 3) & ~(size_t)3;
+    const size_t bytes = 4 * nf * 4 + 16 + 8 + 96 + 8 + sizeof(pgi_edge) + nf + 64;
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_scratch, bytes));
+        ctx->scratch_bytes = bytes;
+    }
+    std::vector<char> h(bytes, 0);
+    float* hx1 = (float*)h.data();
+    float* hy1 = hx1 + nf;
+    float* hx2 = hy1 + nf;
+    float* hy2 = hx2 + nf;
+    for (uint32_t i = 0; i < n; ++i) {  // cv::Mat N x 4 CV_64F rows -> f32 SoA
+        hx1[i] = (float)corr[4 * (size_t)i + 0];
+        hy1[i] = (float)corr[4 * (size_t)i + 1];
+        hx2[i] = (float)corr[4 * (size_t)i + 2];
+        hy2[i] = (float)corr[4 * (size_t)i + 3];
+    }
+    char* p = (char*)(hy2 + nf);
+    uint64_t* hoff = (uint64_t*)p; hoff[0] = 0; hoff[1] = n; p += 16;
+    *(double*)p = thr; const size_t o_thr = p - h.data(); p += 8;
+    const size_t o_guess = p - h.data();
+    if (g) memcpy(p, guesses + 12 * (size_t)(g - 1), 96);  // the last guess wins (:974-1029)
+    p += 96;
+    const size_t o_has = p - h.data(); *p = g ? 1 : 0; p += 8;
+    const size_t o_edge = p - h.data(); p += sizeof(pgi_edge);
+    const size_t o_mask = p - h.data();
+    char* d = (char*)ctx->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, h.data(), o_edge, hipMemcpyHostToDevice, ctx->stream));
+    pgi_batch b;
+    b.d_x1 = (float*)d; b.d_y1 = b.d_x1 + nf; b.d_x2 = b.d_y1 + nf; b.d_y2 = b.d_x2 + nf;
+    b.d_offsets = (uint64_t*)(d + 4 * nf * 4);
+    b.d_thr = (double*)(d + o_thr);
+    b.d_guess_Rt = g ? (double*)(d + o_guess) : nullptr;
+    b.d_has_guess = g ? (uint8_t*)(d + o_has) : nullptr;
+    b.n_pairs = 1; b.max_corr = n; b.pair_id_base = pair_id; b.seed = seed;
+    int rc = pgi_estimate_pose_batch(ctx, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask));
+    if (rc != PGI_SUCCESS) return rc;
+    HIP_TRY(hipMemcpyAsync(h_edge, d + o_edge, sizeof(pgi_edge), hipMemcpyDeviceToHost, ctx->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(h_mask, d + o_mask, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return h_edge->status == PGI_EDGE_OK ? 1 : 0;
+}
+
+int pgi_score_pose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, const double* d_tau2,
+                         uint32_t* d_counts, uint8_t* d_masks) {
+    if (!ctx || !b || !d_E || !d_tau2 || !d_counts) return fail(PGI_ERR_INVALID, "null argument");
+    if (b->n_pairs == 0) return PGI_SUCCESS;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(score_pose_kernel, dim3((b->n_pairs + 3) / 4), dim3(256), 0, ctx->stream, b->d_x1, b->d_y1,
+                       b->d_x2, b->d_y2, b->d_offsets, d_E, d_tau2, b->n_pairs, d_counts, d_masks);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr, const uint64_t* d_off, uint32_t n_pairs, const double* d_E,
+                       const double* d_tau2, uint32_t* d_counts, uint8_t* d_masks) {
+    if (!ctx || !d_corr || !d_off || !d_E || !d_tau2 || !d_counts) return fail(PGI_ERR_INVALID, "null argument");
+    if (n_pairs == 0) return PGI_SUCCESS;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(score_pose_f64_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, ctx->stream, d_corr, d_off, d_E,
+                       d_tau2, n_pairs, d_counts, d_masks);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, const uint8_t* d_masks,
+                        pgi_edge* d_edges) {
+    if (!ctx || !b || !d_E || !d_edges) return fail(PGI_ERR_INVALID, "null argument");
+    if (b->n_pairs == 0) return PGI_SUCCESS;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(decompose_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->d_x1, b->d_y1, b->d_x2,
+                       b->d_y2, b->d_offsets, d_E, d_masks, d_edges);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_five_point_batch(pgi_ctx* ctx, const float* d_pts, uint32_t n_samples, float* d_models, uint32_t* d_counts,
+                         double* d_dbg) {
+    if (!ctx || !d_pts || !d_models || !d_counts) return fail(PGI_ERR_INVALID, "null argument");
+    if (n_samples == 0) return PGI_SUCCESS;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(five_point_kernel, dim3((n_samples + 3) / 4), dim3(64), 0, ctx->stream, d_pts, n_samples,
+                       d_models, d_counts, d_dbg);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+void pgi_default_rotavg_params(pgi_rotavg_params* p) {
+    p->l1_iters = 5;
+    p->irls_iters = 100;
+    p->cg_iters = 200;
+    p->sigma_deg = 5.0;
+    p->tol = 1e-8;
+}
+
+}  // extern "C"

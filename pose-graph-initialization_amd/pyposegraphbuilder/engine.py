@@ -1,0 +1,156 @@
+"""Engine: the batched entry points of include/pgi.h over torch device tensors.
+
+torch is used for HBM allocation and the stream only; all compute is in libpgi.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    def __init__(self, device=None, **params):
+        lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.PgiError("no HIP device visible: the pose engine has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.params = L.default_params(**params)
+        self._ctx = lib.pgi_create(self.device.index, C.byref(self.params))
+        if not self._ctx:
+            raise L.PgiError("pgi_create failed: " + L.last_error())
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pgi_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        L.check(self._lib.pgi_set_params(self._ctx, C.byref(self.params)))
+
+    def _bind_stream(self):
+        L.check(self._lib.pgi_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self):
+        L.check(self._lib.pgi_synchronize(self._ctx))
+
+    # ---- batches -------------------------------------------------------------------------
+    def upload(self, x1, y1, x2, y2, offsets, thr, guesses=None, has_guess=None, seed=0, pair_id_base=0):
+        """Host (numpy) flattened SoA -> a device-resident batch dict."""
+        dev = self.device
+        off = np.ascontiguousarray(offsets, np.uint64)
+        P = len(off) - 1
+        b = dict(
+            x1=torch.from_numpy(np.ascontiguousarray(x1, np.float32)).to(dev),
+            y1=torch.from_numpy(np.ascontiguousarray(y1, np.float32)).to(dev),
+            x2=torch.from_numpy(np.ascontiguousarray(x2, np.float32)).to(dev),
+            y2=torch.from_numpy(np.ascontiguousarray(y2, np.float32)).to(dev),
+            offsets=torch.from_numpy(off.view(np.int64)).to(dev),
+            thr=torch.from_numpy(np.ascontiguousarray(np.broadcast_to(thr, (P,)), np.float64)).to(dev),
+            guesses=None, has_guess=None, n_pairs=P,
+            max_corr=int(np.diff(off.astype(np.int64)).max()) if P else 0,
+            seed=int(seed), pair_id_base=int(pair_id_base))
+        if guesses is not None:
+            b["guesses"] = torch.from_numpy(np.ascontiguousarray(guesses, np.float64).reshape(P, 12)).to(dev)
+            hg = np.ones(P, np.uint8) if has_guess is None else np.ascontiguousarray(has_guess, np.uint8)
+            b["has_guess"] = torch.from_numpy(hg).to(dev)
+        return b
+
+    def _batch_struct(self, b):
+        s = L.Batch()
+        s.d_x1, s.d_y1, s.d_x2, s.d_y2 = (b[k].data_ptr() for k in ("x1", "y1", "x2", "y2"))
+        s.d_offsets = b["offsets"].data_ptr()
+        s.d_thr = b["thr"].data_ptr()
+        s.d_guess_Rt = b["guesses"].data_ptr() if b.get("guesses") is not None else None
+        s.d_has_guess = b["has_guess"].data_ptr() if b.get("has_guess") is not None else None
+        s.n_pairs, s.max_corr = b["n_pairs"], b["max_corr"]
+        s.pair_id_base, s.seed = b["pair_id_base"], b["seed"]
+        return s
+
+    def estimate_pose_batch(self, b, edges=None, masks=None):
+        """Enqueues estimatePose for every pair; returns (edges uint8[P,200], masks uint8[rows]) on device."""
+        P, rows = b["n_pairs"], b["x1"].numel()
+        if edges is None:
+            edges = torch.empty((P, L.EDGE_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        if masks is None:
+            masks = torch.empty(max(rows, 1), dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        s = self._batch_struct(b)
+        L.check(self._lib.pgi_estimate_pose_batch(self._ctx, C.byref(s), _ptr(edges), _ptr(masks)))
+        return edges, masks[:rows]
+
+    @staticmethod
+    def edges_to_numpy(edges):
+        return edges.cpu().numpy().view(L.EDGE_DTYPE).reshape(-1)
+
+    def score_pose_batch(self, b, E, tau2, want_masks=True):
+        P, rows = b["n_pairs"], b["x1"].numel()
+        E = torch.as_tensor(np.ascontiguousarray(E, np.float64).reshape(P, 9)).to(self.device)
+        tau2 = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(tau2, (P,)), np.float64)).to(self.device)
+        counts = torch.empty(P, dtype=torch.int32, device=self.device)
+        masks = torch.empty(max(rows, 1), dtype=torch.uint8, device=self.device) if want_masks else None
+        self._bind_stream()
+        s = self._batch_struct(b)
+        L.check(self._lib.pgi_score_pose_batch(self._ctx, C.byref(s), _ptr(E), _ptr(tau2), _ptr(counts), _ptr(masks)))
+        return counts, (masks[:rows] if want_masks else None)
+
+    def score_pose_f64(self, corr_aos, offsets, E, tau2):
+        """Reference-layout rows (n x 4 f64, cv::Mat N x 4 CV_64F) and arithmetic."""
+        off = np.ascontiguousarray(offsets, np.uint64)
+        P = len(off) - 1
+        dev = self.device
+        c = torch.from_numpy(np.ascontiguousarray(corr_aos, np.float64)).to(dev)
+        o = torch.from_numpy(off.view(np.int64)).to(dev)
+        E = torch.from_numpy(np.ascontiguousarray(E, np.float64).reshape(P, 9)).to(dev)
+        t2 = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(tau2, (P,)), np.float64)).to(dev)
+        counts = torch.empty(P, dtype=torch.int32, device=dev)
+        masks = torch.empty(max(len(corr_aos), 1), dtype=torch.uint8, device=dev)
+        self._bind_stream()
+        L.check(self._lib.pgi_score_pose_f64(self._ctx, _ptr(c), _ptr(o), P, _ptr(E), _ptr(t2), _ptr(counts),
+                                             _ptr(masks)))
+        return counts.cpu().numpy().astype(np.uint32), masks[:len(corr_aos)].cpu().numpy()
+
+    def decompose_batch(self, b, E, masks=None):
+        P = b["n_pairs"]
+        E = torch.as_tensor(np.ascontiguousarray(E, np.float64).reshape(P, 9)).to(self.device)
+        edges = torch.zeros((P, L.EDGE_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        s = self._batch_struct(b)
+        L.check(self._lib.pgi_decompose_batch(self._ctx, C.byref(s), _ptr(E), _ptr(masks), _ptr(edges)))
+        return edges
+
+    def five_point_batch(self, pts, debug=False):
+        """pts: [S,5,4] float32 -> (models [S,10,9] f32, counts [S], dbg [S,358] f64 or None)."""
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 5, 4)
+        S = len(pts)
+        d_pts = torch.from_numpy(pts).to(self.device)
+        models = torch.zeros((S, 10, 9), dtype=torch.float32, device=self.device)
+        counts = torch.zeros(S, dtype=torch.int32, device=self.device)
+        dbg = torch.zeros((S, L.DBG_DOUBLES), dtype=torch.float64, device=self.device) if debug else None
+        self._bind_stream()
+        L.check(self._lib.pgi_five_point_batch(self._ctx, _ptr(d_pts), S, _ptr(models), _ptr(counts), _ptr(dbg)))
+        return models.cpu().numpy(), counts.cpu().numpy(), (dbg.cpu().numpy() if debug else None)
+
+    # ---- single-pair drop-in (host pointers) --------------------------------------------------
+    def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
+        """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""
+        c = np.ascontiguousarray(corr_aos, np.float64).reshape(-1, 4)
+        g = None if guesses is None else np.ascontiguousarray(guesses, np.float64).reshape(-1, 12)
+        e = L.Edge()
+        mask = np.zeros(max(len(c), 1), np.uint8)
+        self._bind_stream()
+        rc = L.check(self._lib.pgi_estimate_pose(
+            self._ctx, c.ctypes.data_as(C.c_void_p), len(c), float(thr),
+            None if g is None else g.ctypes.data_as(C.c_void_p), 0 if g is None else len(g),
+            int(seed), int(pair_id), C.byref(e), mask.ctypes.data_as(C.c_void_p)))
+        return bool(rc), e, mask[:len(c)]
