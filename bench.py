@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- pose-graph edges/sec (essential + decompose) on MI355X.
+
+Step   = one pass of the hot path (PoseGraphBuilder::estimatePose, pose_graph_builder.h:940-1078)
+         over one batch of synthetic image pairs already resident in HBM: robust essential
+         matrix (5-point hypotheses, multi-level Sampson scoring, n-point LO), inlier mask and
+         decomposition to (R, t), one kernel launch -- followed, when N > 1, by the RCCL
+         all-gather of the per-edge records (the only exchange step of the path).
+Workload = BASELINE.json configs[1]: 10 000 pairs x 2 000 correspondences per GPU
+         (weak scaling: each rank owns its own 10 000 pairs, ids rank*P ...).
+Launch  : python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
+         python -m torch.distributed.run --nproc-per-node N ... (one rank per GPU).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_F32_PEAK_TF = 157.3    # vector fp32 peak
+EDGE_RECORD_BYTES = 200     # sizeof(pgi_edge)
+
+
+def algorithmic_bytes_per_edge(n):
+    """rows read once (4 x f32), mask written once (u8), one edge record."""
+    return 17 * n + EDGE_RECORD_BYTES
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU (config 2: 10000)")
+    ap.add_argument("--corrs", type=int, default=2000, help="correspondences per pair (config 2: 2000)")
+    ap.add_argument("--inlier-ratio", type=float, default=0.5)
+    ap.add_argument("--thr-px", type=float, default=0.75)
+    ap.add_argument("--fixed-budget", type=int, default=0, help="0 = adaptive (confidence 0.99, cap 1000)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-256 / score_pose lines")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    from pyposegraphbuilder import Engine, synthetic as S
+    from pyposegraphbuilder import _lib as L
+
+    P, N = args.pairs, args.corrs
+    thr = args.thr_px / S.FOCAL_PX
+    seed = 0xB0BA
+    pair_base = rank * P
+    t0 = time.time()
+    b = S.make_batch(np.arange(pair_base, pair_base + P), N, inlier_ratio=args.inlier_ratio)
+    gen_s = time.time() - t0
+
+    eng = Engine(fixed_budget=args.fixed_budget)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
+    edges = torch.empty((P, EDGE_RECORD_BYTES), dtype=torch.uint8, device=eng.device)
+    masks = torch.empty(P * N, dtype=torch.uint8, device=eng.device)
+    gathered = torch.empty((world * P, EDGE_RECORD_BYTES), dtype=torch.uint8, device=eng.device) if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        eng.estimate_pose_batch(db, edges, masks)
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:  # the path's one exchange: per-edge records to every rank (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, edges)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))  # HIP events on the launch stream
+
+    got = eng.edges_to_numpy(edges)
+    masks_host = masks.cpu().numpy()  # the secondary runs below reuse the device buffers
+    ok = got["status"] == 1
+    errs = np.array([S.rot_err_deg(got["R"][i].reshape(3, 3), b["R"][i]) if ok[i] else np.inf for i in range(P)])
+    auc5 = S.auc_at(errs, 5.0)
+
+    value = world * P * args.steps / dt
+    bytes_per_launch = P * algorithmic_bytes_per_edge(N)
+    achieved_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("pairs") == P and tj.get("corrs") == N:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "pose-graph edges/sec (essential+decompose)",
+        "value": round(value, 1), "unit": "edges/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 scoring / f64 solver", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d pairs x %d corrs batched essential RANSAC + decompose per GPU" % (P, N),
+                   "pairs_per_gpu": P, "corrs_per_pair": N, "inlier_ratio": args.inlier_ratio,
+                   "noise_px": 0.25, "thr_px": args.thr_px,
+                   "mode": "fixed budget %d" % args.fixed_budget if args.fixed_budget else
+                           "adaptive (confidence 0.99, cap 1000, rounds of 32)",
+                   "parallelism": "pairs sharded over %d GPU(s)%s" % (world, ", all-gather of edge records" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "kernel": "estimate_pose_kernel", "kernel_ms": round(kern_ms, 3),
+                     "bytes_per_edge": algorithmic_bytes_per_edge(N),
+                     "note": "K1 stages rows once into LDS; it is VALU/LDS-bound by design (SURVEY 8d), see 'valu'"},
+        "quality": {"rot_err_auc_at_5deg": round(auc5, 4), "edges_ok": int(ok.sum()),
+                    "median_rot_err_deg": round(float(np.median(errs)), 4), "mean_hypotheses": float(got["iters"].mean()),
+                    "mean_lo_refits": float(got["lo_runs"].mean())},
+        "setup": {"gen_s": round(gen_s, 1)},
+    }
+    # compute-side figure: residual evaluations dominate; ~2.6 models survive per hypothesis after the
+    # oriented-constraint prune, 34 flop per residual+levels, ~1.2e4 flop (f64) per 5-point solve
+    hyp = float(got["iters"].mean())
+    flop_edge = hyp * (1.2e4 + 2.6 * N * 34.0) + float(got["lo_runs"].mean()) * (N * 250.0 + 10 * N * 34.0)
+    out["valu"] = {"flop_per_edge_est": round(flop_edge), "achieved_tflops_est": round(P * flop_edge / (kern_ms * 1e-3) / 1e12, 3),
+                   "peak_tflops_f32": VALU_F32_PEAK_TF,
+                   "frac_est": round(P * flop_edge / (kern_ms * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4)}
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # secondary lines (not `value`): fixed budget of 256 hypotheses; the HBM-bound K2 score kernel
+        eng.set_params(fixed_budget=256)
+        eng.estimate_pose_batch(db, edges, masks)
+        torch.cuda.synchronize()
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.estimate_pose_batch(db, edges, masks)
+        z.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(z)
+        out["fixed_budget_256"] = {"edges_per_s": round(P / (ms * 1e-3), 1), "kernel_ms": round(ms, 3)}
+        eng.set_params(fixed_budget=args.fixed_budget)
+        Egt = np.stack([np.cross(np.eye(3), b["t"][i]) @ b["R"][i] for i in range(P)]).reshape(P, 9)
+        dE = torch.from_numpy(Egt).to(eng.device)
+        dt2 = torch.full((P,), thr * thr, dtype=torch.float64, device=eng.device)
+        cnt = torch.empty(P, dtype=torch.int32, device=eng.device)
+        import ctypes as C
+        st = eng._batch_struct(db)
+        def k2():
+            L.check(eng._lib.pgi_score_pose_batch(eng._ctx, C.byref(st), C.c_void_p(dE.data_ptr()), C.c_void_p(dt2.data_ptr()),
+                                                  C.c_void_p(cnt.data_ptr()), C.c_void_p(masks.data_ptr())))
+        eng._bind_stream()
+        for _ in range(3):
+            k2()
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(10):
+            k2()
+        z.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(z) / 10
+        k2_bytes = P * (17 * N + 76 + 8)
+        out["score_pose_k2"] = {"kernel_ms": round(ms, 4), "achieved_GBs": round(k2_bytes / (ms * 1e-3) / 1e9, 1),
+                                "frac_hbm": round(k2_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "pair_scores_per_s": round(P / (ms * 1e-3), 1)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),
+        # same inputs / seeds / mode, all host cores, bounded sample; also re-checks parity on that sample
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        prm = O.default_params(fixed_budget=args.fixed_budget)
+        cores = O.lib().pgo_num_threads()
+
+        def run(m):
+            o = b["offsets"][:m + 1]
+            r = int(o[-1])
+            t0 = time.perf_counter()
+            e, mk = O.estimate_pose_batch(b["x1"][:r], b["y1"][:r], b["x2"][:r], b["y2"][:r], o, thr, prm, seed,
+                                          pair_id_base=pair_base, threads=cores)
+            return time.perf_counter() - t0, e, mk
+        m0 = min(P, 4 * cores)
+        t_probe, _, _ = run(m0)
+        m = int(min(P, max(m0, args.cpu_seconds / max(t_probe / m0, 1e-6))))
+        t_cpu, e_cpu, mk_cpu = run(m)
+        rows = int(b["offsets"][m])
+        parity = bool(np.array_equal(masks_host[:rows], mk_cpu) and
+                      np.array_equal(got["E"][:m], e_cpu["E"]) and np.array_equal(got["n_inl"][:m], e_cpu["n_inl"]))
+        out["cpu_baseline"] = {"value": round(m / t_cpu, 1), "unit": "edges/s", "cores": int(cores), "kind": "port",
+                               "sample": "first %d pairs of the same batch (%.1f s); build CPU restatement, not OpenCV" % (m, t_cpu),
+                               "gpu_matches_on_sample": parity}
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -548,11 +548,15 @@ void pgo_jacobi9(double A[81], double V[81]) {
                 const double apq = A[9 * p + q];
                 double c = 1.0, s = 0.0;
                 if (apq != 0.0) {
-                    const double tau = (A[10 * q] - A[10 * p]) / (2.0 * apq);
-                    const double den = fabs(tau) + sqrt(fma(tau, tau, 1.0));
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / den;
-                    c = 1.0 / sqrt(fma(t, t, 1.0));
-                    s = t * c;
+                    /* t = sgn(al) be / (|al| + hypot(al,be)), c = d/r, s = sgn(al) be / r:
+                     * the classic rotation with one division and two square roots */
+                    const double al = A[10 * q] - A[10 * p], be = 2.0 * apq;
+                    const double h = sqrt(fma(al, al, be * be));
+                    const double d = fabs(al) + h;
+                    const double r = sqrt(fma(d, d, be * be));
+                    const double inv = 1.0 / r;
+                    c = d * inv;
+                    s = (al >= 0.0 ? be : -be) * inv;
                 }
                 C[m - 1] = c;
                 S[m - 1] = s;

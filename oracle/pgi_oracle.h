@@ -39,7 +39,7 @@ extern "C" {
 #define PGO_NEWTON_ITERS 10    /* safeguarded Newton iterations per bracket       */
 #endif
 #ifndef PGO_JACOBI9_SWEEPS
-#define PGO_JACOBI9_SWEEPS 8   /* cyclic (tournament-ordered) Jacobi sweeps, 9x9  */
+#define PGO_JACOBI9_SWEEPS 6   /* cyclic (tournament-ordered) Jacobi sweeps, 9x9  */
 #endif
 #ifndef PGO_SVD3_SWEEPS
 #define PGO_SVD3_SWEEPS 6      /* one-sided Jacobi sweeps, 3x3                    */

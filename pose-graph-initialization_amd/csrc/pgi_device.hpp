@@ -21,9 +21,38 @@ namespace pgi {
 
 constexpr int kGrid = 256;       // root-bracketing intervals
 constexpr int kNewton = 10;      // safeguarded Newton iterations
-constexpr int kJacobiSweeps = 8; // 9x9 tournament Jacobi sweeps
+constexpr int kJacobiSweeps = 6; // 9x9 tournament Jacobi sweeps
 constexpr int kSvdSweeps = 6;    // 3x3 one-sided Jacobi sweeps
 constexpr int kMaxModels = 10;
+
+// ---- optional per-phase cycle accounting (-DPGI_PROFILE; scripts/profile_phases.py) ----
+constexpr int kProfSlots = 32;
+#ifdef PGI_PROFILE
+struct Prof {
+    unsigned long long t, acc[kProfSlots];
+    PGI_DEV void start() {
+        for (int i = 0; i < kProfSlots; ++i) acc[i] = 0;
+        t = __builtin_amdgcn_s_memtime();
+    }
+    template <int I>
+    PGI_DEV void mark() {
+        const unsigned long long n = __builtin_amdgcn_s_memtime();
+        acc[I] += n - t;
+        t = n;
+    }
+    PGI_DEV void flush(unsigned long long* out, int lane) {
+        if (out && lane == 0)
+            for (int i = 0; i < kProfSlots; ++i) atomicAdd(out + i, acc[i]);
+    }
+};
+#else
+struct Prof {
+    PGI_DEV void start() {}
+    template <int I>
+    PGI_DEV void mark() {}
+    PGI_DEV void flush(unsigned long long*, int) {}
+};
+#endif
 
 // ---- wavefront-scope LDS ordering ------------------------------------------
 // DS operations of one wavefront execute in order; this only stops the
@@ -83,13 +112,34 @@ PGI_DEV uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+PGI_DEV uint32_t draw_index(uint64_t base, uint32_t hyp, uint32_t k, uint32_t n) {
+    const uint64_t u = mix64(base ^ (((uint64_t)hyp << 16) | k));
+    return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
+}
+// Five distinct row indices: draws k = 0,1,2,... are accepted in order unless they repeat an
+// earlier accepted index.  The first eight draws are hashed up front (independent chains).
 PGI_DEV void sample5(uint64_t base, uint32_t hyp, uint32_t n, uint32_t idx[5]) {
-    uint32_t k = 0, got = 0;
+    uint32_t cand[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cand[k] = draw_index(base, hyp, (uint32_t)k, n);
+    uint32_t got = 0;
     idx[0] = idx[1] = idx[2] = idx[3] = idx[4] = 0xFFFFFFFFu;
-    while (got < 5) {
-        const uint64_t u = mix64(base ^ (((uint64_t)hyp << 16) | k));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t j = cand[k];
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dup |= (q < (int)got) && (idx[q] == j);
+        const bool take = (got < 5) && !dup;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (take && q == (int)got) idx[q] = j;
+        got += take ? 1u : 0u;
+    }
+    uint32_t k = 8;
+    while (got < 5) {  // rare: three or more repeats among the first eight draws
+        const uint32_t j = draw_index(base, hyp, k, n);
         ++k;
-        const uint32_t j = (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
         bool dup = false;
 #pragma unroll
         for (int q = 0; q < 5; ++q) dup |= (q < (int)got) && (idx[q] == j);
@@ -281,9 +331,9 @@ struct BackendDbg {
 // -> 3x3 polynomial matrix B(z) -> degree-10 determinant -> bracketed real roots ->
 // E per root.  Returns true in sub-lanes that hold a valid model E32 (sub-lane =
 // root index).  smp: the five sample points (orientation test) or nullptr.
-template <bool DBG>
+template <bool DBG, int PB = 3>
 PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, const float4* smp,
-                           float E32[9], const BackendDbg* dbg) {
+                           float E32[9], const BackendDbg* dbg, Prof& prof) {
     // ---- phase 1: nine quadratic forms, one per sub-lane ------------------------------
     if (s < 9) {
         double q[10];
@@ -349,6 +399,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
         if (s < 10)
             for (int m = 0; m < 20; ++m) dbg->cons[20 * s + m] = row[m];
     }
+    prof.mark<PB + 0>();
     // ---- Gauss-Jordan, partial pivoting; row r in sub-lane r ---------------------------------
     bool used = false;
     int mycol = -1;
@@ -371,6 +422,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
             row[j] = is_p ? v : fma(-f, pj, v);
         }
     }
+    prof.mark<PB + 1>();
     wave_sync();  // quads are dead: region A is reused for the reduced rows
     if (mycol >= 4) {
 #pragma unroll
@@ -432,6 +484,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
         if constexpr (DBG) dbg->poly[s] = p;
     }
     wave_sync();
+    prof.mark<PB + 2>();
     // ---- bracket sign changes on the grid: sub-lane s owns intervals [16s, 16s+16) ---------------
     double p[11];
 #pragma unroll
@@ -463,6 +516,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     if constexpr (DBG) {
         if (s == 0) dbg->nroots[0] = (double)nb;
     }
+    prof.mark<PB + 3>();
     // ---- refine one root per sub-lane, back-substitute, build E -------------------------------------
     bool valid = false;
     if (s < nb) {
@@ -481,6 +535,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
             z = refine_root(p, gprev, g, sprev);
         }
         if constexpr (DBG) dbg->roots[s] = z;
+        prof.mark<PB + 4>();
         double rw[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -546,6 +601,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
 #pragma unroll
         for (int m = 0; m < 9; ++m) E32[m] = (float)E[m];
     }
+    prof.mark<PB + 5>();
     return valid;
 }
 

@@ -43,7 +43,7 @@ struct WgShared {
     uint32_t votes[4];
     uint32_t q_count[NW];
     uint32_t q_hyp[NW][QCAP];
-    uint32_t flag;
+    uint32_t pass_ctr;
     uint32_t mask_cnt;
     double Rt[21];  // R1[9] R2[9] t[3]
 };
@@ -64,6 +64,7 @@ struct K1Args {
     uint64_t pair_id_base;
     uint64_t seed;
     pgi_params prm;
+    unsigned long long* prof;  // kProfSlots counters (profiling builds) or nullptr
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -94,21 +95,26 @@ PGI_DEV void edge_clear(pgi_edge* e) {
 
 PGI_DEV float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-// Score queue models [m_begin, m_end) in blocks of four; keeps the first maximum.
-// The counters are wave-uniform popcounts of ballots (SGPR arithmetic).
+// Score queue models [m_begin, m_end) in blocks of four; keeps the first maximum that beats
+// `floor_score` (the best of earlier rounds: only a strictly better model can matter).
+// The counters are wave-uniform popcounts of ballots (SGPR arithmetic).  A block is
+// abandoned as soon as none of its models can still exceed the bar -- exact, because the
+// levels only add: final score <= partial + 4 * rows left.
 template <bool LDS_PTS>
-PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t npad, const float* queue,
+PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float* queue,
                          const uint32_t* qhyp, int m_begin, int m_end, float thr2, int lane,
-                         int& b_score, uint32_t& b_ninl, uint32_t& b_hyp, int& b_idx) {
+                         int floor_score, int& b_score, uint32_t& b_ninl, uint32_t& b_hyp, int& b_idx) {
     for (int m0 = m_begin; m0 < m_end; m0 += 4) {
         float e[4][9];
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             const int m = min(m0 + mm, m_end - 1);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) e[mm][c] = rfl(queue[9 * m + c]);
+            for (int c = 0; c < 9; ++c) e[mm][c] = queue[9 * m + c];  // VGPRs: no constant-bus moves
         }
+        const int bar = __builtin_amdgcn_readfirstlane(max(floor_score, b_score));  // wave-uniform
         uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
+        bool dead = false;
         for (uint32_t base = 0; base < npad; base += 64) {
             const float4 p = rows.get(base + lane);
 #pragma unroll
@@ -123,10 +129,17 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t npad, const float* 
                 sc[mm] += (c0 + c1) + (c2 + c3);
                 ni[mm] += c2;
             }
+            const uint32_t seen = min(n, base + 64u);
+            const uint32_t smax = max(max(sc[0], sc[1]), max(sc[2], sc[3]));
+            if ((int)(smax + 4u * (n - seen)) <= bar) {
+                dead = true;
+                break;
+            }
         }
+        if (dead) continue;
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
-            if (m0 + mm < m_end && (int)sc[mm] > b_score) {
+            if (m0 + mm < m_end && (int)sc[mm] > max(floor_score, b_score)) {
                 b_score = (int)sc[mm];
                 b_ninl = ni[mm];
                 b_hyp = qhyp ? qhyp[m0 + mm] : 0u;
@@ -232,12 +245,14 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
             double c = 1.0, s = 0.0;
             if (act) {
                 const double apq = A[9 * p + q];
-                if (apq != 0.0) {
-                    const double tau = (A[10 * q] - A[10 * p]) / (2.0 * apq);
-                    const double den = fabs(tau) + sqrt(fma(tau, tau, 1.0));
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / den;
-                    c = 1.0 / sqrt(fma(t, t, 1.0));
-                    s = t * c;
+                if (apq != 0.0) {  // one division, two square roots per rotation
+                    const double al = A[10 * q] - A[10 * p], be = 2.0 * apq;
+                    const double h = sqrt(fma(al, al, be * be));
+                    const double d = fabs(al) + h;
+                    const double r = sqrt(fma(d, d, be * be));
+                    const double inv = 1.0 / r;
+                    c = d * inv;
+                    s = (al >= 0.0 ? be : -be) * inv;
                 }
             }
             wave_sync();
@@ -286,27 +301,33 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
 template <bool LDS_PTS>
 PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                  float thr2, double* loA, double* loV, double* partial, double* wscr,
-                                 const double* grid, float* queue0, WgShared* sh, int tid,
-                                 int& r_score, uint32_t& r_ninl, float rE[9]) {
+                                 const double* grid, float* queue0, WgShared* sh, int tid, int floor_score,
+                                 int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof) {
     const int lane = tid & 63, w = tid >> 6;
+    prof.mark<11>();
     const uint32_t ni = normal_matrix_wg<LDS_PTS>(rows, npad, E, tau2, loA, partial, sh, tid);
+    prof.mark<12>();
     r_score = -1;
     r_ninl = 0;
     if (ni < 5) return ni;  // uniform
     if (w == 0) {
         jacobi9_wave(loA, loV, wscr, lane);
+        prof.mark<13>();
         float E32[9];
         const int g = lane >> 4, s = lane & 15;
-        const bool valid = backend_group<false>(wscr + g * G_DOUBLES, grid, s, g * 16, nullptr, E32, nullptr);
+        const bool valid = backend_group<false, 14>(wscr + g * G_DOUBLES, grid, s, g * 16, nullptr, E32, nullptr, prof);
         const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
         if (lane == 0) sh->q_count[0] = (uint32_t)cnt;
     }
     __syncthreads();
+    prof.mark<20>();
     const int count = (int)sh->q_count[0];
     int b_score = -1, b_idx = -1;
     uint32_t b_ninl = 0, b_hyp = 0;
     const int mb = 4 * w, me = min(count, 4 * w + 4);
-    if (mb < me) score_queue<LDS_PTS>(rows, npad, queue0, nullptr, mb, me, thr2, lane, b_score, b_ninl, b_hyp, b_idx);
+    if (mb < me)
+        score_queue<LDS_PTS>(rows, rows.n, npad, queue0, nullptr, mb, me, thr2, lane, floor_score, b_score, b_ninl, b_hyp,
+                             b_idx);
     if (lane == 0) {
         sh->cand_score[w] = b_score;
         sh->cand_ninl[w] = b_ninl;
@@ -327,6 +348,7 @@ PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const
         for (int c = 0; c < 9; ++c) rE[c] = queue0[9 * idx + c];
     }
     __syncthreads();
+    prof.mark<21>();
     return ni;
 }
 
@@ -357,6 +379,8 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
 
     pgi_edge* edge = a.edges + pair;
     uint8_t* mask = a.masks + o;
+    Prof prof;
+    prof.start();
 
     // ---- stage the pair: coalesced SoA reads from HBM -> float4 rows in LDS ----
     if constexpr (LDS_PTS) {
@@ -371,8 +395,10 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         sh->best_ninl = 0;
         sh->votes[0] = sh->votes[1] = sh->votes[2] = sh->votes[3] = 0;
         sh->mask_cnt = 0;
+        sh->pass_ctr = 0;
     }
     __syncthreads();
+    prof.mark<0>();
 
     const double thr = a.thr[pair];
     const float thr2 = (float)(thr * thr);
@@ -424,7 +450,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         uint32_t r_ninl;
         float rE[9];
         const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, loA, loV, partial, wscr_all, grid,
-                                                     queue_all, sh, tid, r_score, r_ninl, rE);
+                                                     queue_all, sh, tid, -1, r_score, r_ninl, rE, prof);
         if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
             success = true;
             have_model = true;
@@ -457,8 +483,14 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
             float wbE[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) wbE[c] = 0.f;
-            for (uint32_t pass = 0; pass * (NW * 4) < rs; ++pass) {
-                const uint32_t local = pass * (NW * 4) + w * 4 + g;
+            const int floor_score = sh->best_score;
+            const uint32_t n_pass = (rs + 3u) / 4u;
+            for (;;) {  // wavefronts pull passes (four hypotheses each) from a shared counter
+                uint32_t pass = 0;
+                if (lane == 0) pass = atomicAdd(&sh->pass_ctr, 1u);
+                pass = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);
+                if (pass >= n_pass) break;
+                const uint32_t local = pass * 4 + g;
                 const bool active = local < rs;
                 const uint32_t hyp = hyps + (active ? local : 0u);
                 uint32_t idx[5];
@@ -470,19 +502,24 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
 #pragma unroll
                 for (int k = 1; k < 5; ++k)
                     if (s == k) mine = smp[k];
+                prof.mark<1>();
                 nullspace5_group(mine, s, g * 16, wscr + g * G_DOUBLES);
+                prof.mark<2>();
                 float E32[9];
                 const bool valid =
-                    backend_group<false>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr);
+                    backend_group<false, 3>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr, prof);
                 const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
                 wave_sync();
+                prof.mark<9>();
                 int bidx = -1;
-                score_queue<LDS_PTS>(rows, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, wb_score, wb_ninl, wb_hyp, bidx);
+                score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, wb_score, wb_ninl,
+                                     wb_hyp, bidx);
                 if (bidx >= 0) {
 #pragma unroll
                     for (int c = 0; c < 9; ++c) wbE[c] = queue[9 * bidx + c];
                 }
                 wave_sync();
+                prof.mark<10>();
             }
             if (lane == 0) {
                 sh->cand_score[w] = wb_score;
@@ -492,6 +529,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                 for (int c = 0; c < 9; ++c) sh->candE[w][c] = wbE[c];
             }
             __syncthreads();
+            prof.mark<22>();
             hyps += rs;
             // round best: score desc, hypothesis index asc
             int rb = -1, rbw = -1;
@@ -507,6 +545,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                 }
             }
             const bool improve = (rb >= 0) && (rb > sh->best_score);
+            if (tid == 0) sh->pass_ctr = 0;
             __syncthreads();
             if (improve) {
                 if (tid == 0) {
@@ -525,8 +564,8 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                     uint32_t r_ninl;
                     float rE[9];
                     const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, bE, thr2, thr2, loA, loV, partial,
-                                                                 wscr_all, grid, queue_all, sh, tid, r_score,
-                                                                 r_ninl, rE);
+                                                                 wscr_all, grid, queue_all, sh, tid,
+                                                                 sh->best_score, r_score, r_ninl, rE, prof);
                     if (ni < 5) break;
                     ++out_lo;
                     const bool better = r_score > sh->best_score;
@@ -557,6 +596,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         }
     }
 
+    prof.mark<23>();
     // ---- epilogue: mask, count, decomposition (pose_graph_builder.h:1057-1075) ----
     if (!have_model) {
         for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
@@ -660,6 +700,8 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
             edge->status = bad ? PGI_EDGE_NAN : PGI_EDGE_OK;  // :1069-1070
         }
     }
+    prof.mark<24>();
+    prof.flush(a.prof, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -867,9 +909,11 @@ __global__ __launch_bounds__(64) void five_point_kernel(const float* __restrict_
             for (int f = 0; f < 4; ++f) d[9 * f + s] = gs[G_BASIS + 9 * f + s];
         BackendDbg dbg{d + 36, d + 236, d + 336, d + 347, d + 357};
         if (active && s < 10) d[347 + s] = 0.0;
-        valid = backend_group<true>(gs, grid, s, g * 16, smp, E32, &dbg);
+        Prof prof;
+        valid = backend_group<true>(gs, grid, s, g * 16, smp, E32, &dbg, prof);
     } else {
-        valid = backend_group<false>(gs, grid, s, g * 16, smp, E32, nullptr);
+        Prof prof;
+        valid = backend_group<false>(gs, grid, s, g * 16, smp, E32, nullptr, prof);
     }
     // compact the valid roots of each group in root order
     const uint64_t bal = __ballot(valid);
@@ -908,6 +952,7 @@ struct pgi_ctx {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     int max_lds = 0;
+    unsigned long long* d_prof = nullptr;
 };
 
 static size_t k1_fixed_lds() {
@@ -990,6 +1035,13 @@ int pgi_synchronize(pgi_ctx* ctx) {
     return PGI_SUCCESS;
 }
 
+// profiling builds only (-DPGI_PROFILE): device buffer of kProfSlots 64-bit cycle counters
+int pgi_internal_set_profile_buffer(pgi_ctx* ctx, unsigned long long* d_buf) {
+    if (!ctx) return PGI_ERR_INVALID;
+    ctx->d_prof = d_buf;
+    return PGI_SUCCESS;
+}
+
 int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
@@ -1000,6 +1052,7 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     a.off = b->d_offsets; a.thr = b->d_thr; a.guess = b->d_guess_Rt; a.has_guess = b->d_has_guess;
     a.edges = d_edges; a.masks = d_masks; a.n_pairs = b->n_pairs;
     a.pair_id_base = b->pair_id_base; a.seed = b->seed; a.prm = ctx->prm;
+    a.prof = ctx->d_prof;
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     const size_t lds_rows = (size_t)cap * 16 + k1_fixed_lds();

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-phase cycle accounting of estimate_pose_kernel (instrumented libpgi_prof.so, s_memtime).
+Reports wave-ticks per phase summed over all wavefronts, as a share of the total."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+from pyposegraphbuilder import _lib as L
+L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi_prof.so")
+import torch
+from pyposegraphbuilder import Engine, synthetic as S
+
+NAMES = {0: "stage rows -> LDS", 1: "sample + gather", 2: "nullspace 5x9 + MGS", 3: "quads + cubic rows",
+         4: "Gauss-Jordan 10x20", 5: "B(z), det poly", 6: "bracket grid", 7: "Newton refine",
+         8: "E from root + orientation", 9: "enqueue", 10: "score models", 11: "LO entry", 12: "LO normal matrix",
+         13: "LO jacobi 9x9", 14: "LO quads+rows", 15: "LO Gauss-Jordan", 16: "LO B/det", 17: "LO brackets",
+         18: "LO refine", 19: "LO E from root", 20: "LO wait for wave 0", 21: "LO score+combine",
+         22: "round barrier wait", 23: "merge/termination", 24: "epilogue (mask+decompose)"}
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+fb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+eng = Engine(fixed_budget=fb)
+b = S.make_batch(np.arange(P), N)
+db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=1)
+buf = torch.zeros(32, dtype=torch.int64, device=eng.device)
+eng.estimate_pose_batch(db); torch.cuda.synchronize()
+eng._lib.pgi_internal_set_profile_buffer.argtypes = [C.c_void_p, C.c_void_p]
+eng._lib.pgi_internal_set_profile_buffer(eng._ctx, C.c_void_p(buf.data_ptr()))
+a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record(); e, m = eng.estimate_pose_batch(db); z.record(); torch.cuda.synchronize()
+acc = buf.cpu().numpy().astype(np.float64)
+tot = acc.sum()
+got = eng.edges_to_numpy(e)
+print("P=%d N=%d budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over %d waves)" % (
+    P, N, fb, a.elapsed_time(z), got["iters"].mean(), got["lo_runs"].mean(), 4 * P))
+for i in range(25):
+    print("%2d %-28s %14.0f  %6.2f%%  %10.0f ticks/wave" % (i, NAMES.get(i, ""), acc[i], 100 * acc[i] / tot, acc[i] / (4 * P)))
