@@ -1,0 +1,32 @@
+// pgi_internal.hpp -- shared by the translation units of libpgi.so (not part of the C ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include "../../include/pgi.h"
+
+namespace pgi {
+std::string& last_error_ref();
+inline int fail(int code, const std::string& msg) {
+    last_error_ref() = msg;
+    return code;
+}
+}  // namespace pgi
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (x);                                                                         \
+        if (_e != hipSuccess)                                                                        \
+            return pgi::fail(PGI_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+struct pgi_ctx {
+    int device;
+    hipStream_t stream;
+    pgi_params prm;
+    std::mutex mu;
+    // scratch for the single-pair drop-in
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int max_lds = 0;
+    unsigned long long* d_prof = nullptr;
+};

@@ -14,7 +14,7 @@
 // K3 decompose_kernel     : E + rows -> (R,t) (pose_utils.h:144-252).
 // K5 five_point_kernel    : minimal solver on explicit samples (parity / debugging).
 #include "pgi_device.hpp"
-#include "../../include/pgi.h"
+#include "pgi_internal.hpp"
 
 #include <mutex>
 #include <new>
@@ -298,11 +298,13 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
 
 // n-point refit of model E's inlier set (bound tau2) -> models in wave 0's queue, scored
 // by all wavefronts.  Returns the inlier count; outputs the best refit model.
-template <bool LDS_PTS>
+// While wave 0 runs the serial section (9x9 Jacobi + back-end) the other wavefronts call
+// `spare()` -- the caller uses it to start on the next round's hypotheses.
+template <bool LDS_PTS, class SPARE>
 PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                  float thr2, double* loA, double* loV, double* partial, double* wscr,
                                  const double* grid, float* queue0, WgShared* sh, int tid, int floor_score,
-                                 int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof) {
+                                 int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, SPARE spare) {
     const int lane = tid & 63, w = tid >> 6;
     prof.mark<11>();
     const uint32_t ni = normal_matrix_wg<LDS_PTS>(rows, npad, E, tau2, loA, partial, sh, tid);
@@ -318,6 +320,8 @@ PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const
         const bool valid = backend_group<false, 14>(wscr + g * G_DOUBLES, grid, s, g * 16, nullptr, E32, nullptr, prof);
         const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
         if (lane == 0) sh->q_count[0] = (uint32_t)cnt;
+    } else {
+        spare();
     }
     __syncthreads();
     prof.mark<20>();
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         uint32_t r_ninl;
         float rE[9];
         const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, loA, loV, partial, wscr_all, grid,
-                                                     queue_all, sh, tid, -1, r_score, r_ninl, rE, prof);
+                                                     queue_all, sh, tid, -1, r_score, r_ninl, rE, prof, [] {});
         if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
             success = true;
             have_model = true;
@@ -477,49 +481,59 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         const uint32_t budget = prm.fixed_budget ? prm.fixed_budget : prm.max_iters;
         uint32_t hyps = 0;
         const int g = lane >> 4, s = lane & 15;
+        const uint32_t n_pass = (rs + 3u) / 4u;
+        // best of the round this wavefront is working on (first maximum in hypothesis order)
+        int wb_score = -1;
+        uint32_t wb_ninl = 0, wb_hyp = 0;
+        float wbE[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) wbE[c] = 0.f;
+        // one pass = four hypotheses (one per 16-lane group): sample, solve, score
+        auto do_pass = [&](uint32_t pass, uint32_t base_hyp, int floor_score) {
+            const uint32_t local = pass * 4 + g;
+            const bool active = local < rs;
+            const uint32_t hyp = base_hyp + (active ? local : 0u);
+            uint32_t idx[5];
+            sample5(rng_base, hyp, n, idx);
+            float4 smp[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) smp[k] = rows.get(idx[k]);
+            float4 mine = smp[0];
+#pragma unroll
+            for (int k = 1; k < 5; ++k)
+                if (s == k) mine = smp[k];
+            prof.mark<1>();
+            nullspace5_group(mine, s, g * 16, wscr + g * G_DOUBLES);
+            prof.mark<2>();
+            float E32[9];
+            const bool valid = backend_group<false, 3>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr, prof);
+            const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
+            wave_sync();
+            prof.mark<9>();
+            int bidx = -1;
+            score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, wb_score, wb_ninl,
+                                 wb_hyp, bidx);
+            if (bidx >= 0) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) wbE[c] = queue[9 * bidx + c];
+            }
+            wave_sync();
+            prof.mark<10>();
+        };
+        // wavefronts pull passes of the current round from a shared counter
+        auto pull_pass = [&]() -> uint32_t {
+            uint32_t pass = 0;
+            if (lane == 0) pass = atomicAdd(&sh->pass_ctr, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);
+        };
         while (hyps < budget) {
-            int wb_score = -1;
-            uint32_t wb_ninl = 0, wb_hyp = 0;
-            float wbE[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) wbE[c] = 0.f;
-            const int floor_score = sh->best_score;
-            const uint32_t n_pass = (rs + 3u) / 4u;
-            for (;;) {  // wavefronts pull passes (four hypotheses each) from a shared counter
-                uint32_t pass = 0;
-                if (lane == 0) pass = atomicAdd(&sh->pass_ctr, 1u);
-                pass = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);
-                if (pass >= n_pass) break;
-                const uint32_t local = pass * 4 + g;
-                const bool active = local < rs;
-                const uint32_t hyp = hyps + (active ? local : 0u);
-                uint32_t idx[5];
-                sample5(rng_base, hyp, n, idx);
-                float4 smp[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) smp[k] = rows.get(idx[k]);
-                float4 mine = smp[0];
-#pragma unroll
-                for (int k = 1; k < 5; ++k)
-                    if (s == k) mine = smp[k];
-                prof.mark<1>();
-                nullspace5_group(mine, s, g * 16, wscr + g * G_DOUBLES);
-                prof.mark<2>();
-                float E32[9];
-                const bool valid =
-                    backend_group<false, 3>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr, prof);
-                const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
-                wave_sync();
-                prof.mark<9>();
-                int bidx = -1;
-                score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, wb_score, wb_ninl,
-                                     wb_hyp, bidx);
-                if (bidx >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) wbE[c] = queue[9 * bidx + c];
+            {
+                const int floor_score = sh->best_score;
+                for (;;) {
+                    const uint32_t pass = pull_pass();
+                    if (pass >= n_pass) break;
+                    do_pass(pass, hyps, floor_score);
                 }
-                wave_sync();
-                prof.mark<10>();
             }
             if (lane == 0) {
                 sh->cand_score[w] = wb_score;
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c) sh->candE[w][c] = wbE[c];
             }
+            wb_score = -1;  // from here on the wavefront state belongs to the NEXT round
             __syncthreads();
             prof.mark<22>();
             hyps += rs;
@@ -555,17 +570,25 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                     for (int c = 0; c < 9; ++c) sh->bestE[c] = sh->candE[rbw][c];
                 }
                 __syncthreads();
-                // local optimisation: n-point refits while they improve
+                // local optimisation: n-point refits while they improve.  Hypotheses never depend on
+                // the current best, so the wavefronts idle during the serial Jacobi already work on
+                // the next round (discarded if this refit ends the search): same results, less waiting.
+                const bool more = hyps < budget;
                 for (uint32_t it = 0; it < prm.lo_iters; ++it) {
                     float bE[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
+                    const int cur_best = sh->best_score;
                     int r_score;
                     uint32_t r_ninl;
                     float rE[9];
-                    const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, bE, thr2, thr2, loA, loV, partial,
-                                                                 wscr_all, grid, queue_all, sh, tid,
-                                                                 sh->best_score, r_score, r_ninl, rE, prof);
+                    const uint32_t ni = refit_and_score<LDS_PTS>(
+                        rows, npad, bE, thr2, thr2, loA, loV, partial, wscr_all, grid, queue_all, sh, tid, cur_best,
+                        r_score, r_ninl, rE, prof, [&] {
+                            if (!more) return;
+                            const uint32_t pass = pull_pass();
+                            if (pass < n_pass) do_pass(pass, hyps, cur_best);
+                        });
                     if (ni < 5) break;
                     ++out_lo;
                     const bool better = r_score > sh->best_score;
@@ -931,29 +954,12 @@ __global__ __launch_bounds__(64) void five_point_kernel(const float* __restrict_
 // =================================================================================================
 using namespace pgi;
 
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
+namespace pgi {
+std::string& last_error_ref() {
+    static thread_local std::string e;
+    return e;
 }
-#define HIP_TRY(x)                                                                                   \
-    do {                                                                                             \
-        hipError_t _e = (x);                                                                         \
-        if (_e != hipSuccess)                                                                        \
-            return fail(PGI_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e));             \
-    } while (0)
-
-struct pgi_ctx {
-    int device;
-    hipStream_t stream;
-    pgi_params prm;
-    std::mutex mu;
-    // scratch for the single-pair drop-in
-    void* d_scratch = nullptr;
-    size_t scratch_bytes = 0;
-    int max_lds = 0;
-    unsigned long long* d_prof = nullptr;
-};
+}  // namespace pgi
 
 static size_t k1_fixed_lds() {
     return (size_t)GRID_PAD * 8 + (size_t)NW * 4 * G_DOUBLES * 8 + (81 + 81 + NW * 45 + 1) * 8 +
@@ -962,7 +968,7 @@ static size_t k1_fixed_lds() {
 
 extern "C" {
 
-const char* pgi_last_error(void) { return g_err.c_str(); }
+const char* pgi_last_error(void) { return pgi::last_error_ref().c_str(); }
 
 int pgi_device_count(void) {
     int n = 0;
@@ -985,18 +991,18 @@ void pgi_default_params(pgi_params* p) {
 pgi_ctx* pgi_create(int device, const pgi_params* params) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
-        g_err = "pgi_create: no HIP device (this library has no CPU fallback)";
+        pgi::last_error_ref() = "pgi_create: no HIP device (this library has no CPU fallback)";
         return nullptr;
     }
     if (device < 0) {
         if (hipGetDevice(&device) != hipSuccess) device = 0;
     }
     if (device >= n) {
-        g_err = "pgi_create: device index out of range";
+        pgi::last_error_ref() = "pgi_create: device index out of range";
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) {
-        g_err = "pgi_create: hipSetDevice failed";
+        pgi::last_error_ref() = "pgi_create: hipSetDevice failed";
         return nullptr;
     }
     pgi_ctx* c = new (std::nothrow) pgi_ctx();
@@ -1165,14 +1171,6 @@ int pgi_five_point_batch(pgi_ctx* ctx, const float* d_pts, uint32_t n_samples, f
                        d_models, d_counts, d_dbg);
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
-}
-
-void pgi_default_rotavg_params(pgi_rotavg_params* p) {
-    p->l1_iters = 5;
-    p->irls_iters = 100;
-    p->cg_iters = 200;
-    p->sigma_deg = 5.0;
-    p->tol = 1e-8;
 }
 
 }  // extern "C"

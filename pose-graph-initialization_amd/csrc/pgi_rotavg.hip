@@ -1,0 +1,416 @@
+// pgi_rotavg.hip -- rotation averaging (L1 + IRLS) on the pose graph.
+//
+// NOT in the reference: BASELINE.json:north_star adds it downstream of the
+// per-edge estimator.  Algorithm: Chatterjee & Govindu (ICCV'13 / TPAMI'18), specified in
+// oracle/rotavg_oracle.py and DESIGN.md §3.7.  Edge convention of the reference
+// (pose.h:14, graph_traversal.h:340-344): R_rel ~ R_dst R_src^T, world->camera R_k.
+//
+// Data path: the problem is MB-scale (V <= ~1e4 views) and latency-bound, so it is solved by
+//   rot_residual_kernel  one thread per edge   : omega = log(R_dst^T R_rel R_src), robust weight
+//   rot_solve_kernel     ONE 1024-thread workgroup : weighted-Laplacian normal equations assembled
+//                        per vertex from a CSR adjacency (fixed order), Jacobi-preconditioned CG
+//                        on the three axes at once; block reductions in a fixed tree => deterministic
+//   rot_update_kernel    one thread per view   : R_k <- R_k exp(d_k)
+// Multi-GPU: "replicas only" -- after the all-gather of the edge records every rank (or rank 0)
+// runs this identical solve; an edge-partitioned CG would pay an all-reduce per iteration for a
+// 3V-vector and is pure latency.
+#include "pgi_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace pgi {
+
+#define RDEV __device__ __forceinline__
+
+RDEV void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+RDEV void mat3_tmul(const double* A, const double* B, double* C) {  // A^T B
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+// log map through the unit quaternion (Shepperd's branch selection): robust up to pi
+RDEV void so3_log(const double* R, double* w) {
+    const double tr = R[0] + R[4] + R[8];
+    double q0, q1, q2, q3;  // w, x, y, z
+    if (tr > 0.0) {
+        const double s = sqrt(tr + 1.0) * 2.0;
+        q0 = 0.25 * s; q1 = (R[7] - R[5]) / s; q2 = (R[2] - R[6]) / s; q3 = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2.0;
+        q0 = (R[7] - R[5]) / s; q1 = 0.25 * s; q2 = (R[1] + R[3]) / s; q3 = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2.0;
+        q0 = (R[2] - R[6]) / s; q1 = (R[1] + R[3]) / s; q2 = 0.25 * s; q3 = (R[5] + R[7]) / s;
+    } else {
+        const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2.0;
+        q0 = (R[3] - R[1]) / s; q1 = (R[2] + R[6]) / s; q2 = (R[5] + R[7]) / s; q3 = 0.25 * s;
+    }
+    if (q0 < 0.0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+    const double nv = sqrt(q1 * q1 + q2 * q2 + q3 * q3);
+    const double k = (nv < 1e-12) ? 2.0 : 2.0 * atan2(nv, q0) / nv;
+    w[0] = k * q1; w[1] = k * q2; w[2] = k * q3;
+}
+
+RDEV void so3_exp(const double* w, double* R) {
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double t = sqrt(t2);
+    double a, b;  // sin t / t, (1 - cos t) / t^2
+    if (t < 1e-6) {
+        a = 1.0 - t2 / 6.0;
+        b = 0.5 - t2 / 24.0;
+    } else {
+        a = sin(t) / t;
+        b = (1.0 - cos(t)) / t2;
+    }
+    const double x = w[0], y = w[1], z = w[2];
+    R[0] = 1.0 - b * (y * y + z * z); R[1] = -a * z + b * x * y;        R[2] = a * y + b * x * z;
+    R[3] = a * z + b * x * y;         R[4] = 1.0 - b * (x * x + z * z); R[5] = -a * x + b * y * z;
+    R[6] = -a * y + b * x * z;        R[7] = a * x + b * y * z;         R[8] = 1.0 - b * (x * x + y * y);
+}
+
+struct RotEdgeDev {
+    uint32_t src, dst;
+    double R[9];
+    double weight;
+};
+
+__global__ __launch_bounds__(256) void rot_residual_kernel(const RotEdgeDev* __restrict__ edges, uint32_t n_edges,
+                                                           const double* __restrict__ R, int l1_phase, double sigma,
+                                                           double* __restrict__ omega, double* __restrict__ w) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const RotEdgeDev ed = edges[e];
+    double Ri[9], Rj[9], T[9], D[9], om[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        Ri[c] = R[9 * (size_t)ed.src + c];
+        Rj[c] = R[9 * (size_t)ed.dst + c];
+    }
+    mat3_mul(ed.R, Ri, T);   // R_rel R_src
+    mat3_tmul(Rj, T, D);     // R_dst^T R_rel R_src
+    so3_log(D, om);
+    const double n2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    double wt;
+    if (l1_phase) {
+        wt = ed.weight / fmax(sqrt(n2), 1e-4);
+    } else {
+        const double s2 = sigma * sigma, d = n2 + s2;
+        wt = ed.weight * s2 / (d * d) * s2;
+    }
+    omega[3 * (size_t)e + 0] = om[0];
+    omega[3 * (size_t)e + 1] = om[1];
+    omega[3 * (size_t)e + 2] = om[2];
+    w[e] = wt;
+}
+
+// block-wide sum of three doubles, fixed tree order (deterministic)
+__device__ void block_sum3(double v[3], double* red /* 3*1024 */, int tid) {
+    red[tid] = v[0];
+    red[1024 + tid] = v[1];
+    red[2048 + tid] = v[2];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[tid] += red[tid + s];
+            red[1024 + tid] += red[1024 + tid + s];
+            red[2048 + tid] += red[2048 + tid + s];
+        }
+        __syncthreads();
+    }
+    v[0] = red[0];
+    v[1] = red[1024];
+    v[2] = red[2048];
+    __syncthreads();
+}
+
+// adj_ptr[V+1]; adj_edge / adj_other / adj_sign per incidence (sign +1: the vertex is dst, -1: src)
+__global__ __launch_bounds__(1024) void rot_solve_kernel(uint32_t n_views, const uint32_t* __restrict__ adj_ptr,
+                                                         const uint32_t* __restrict__ adj_edge,
+                                                         const uint32_t* __restrict__ adj_other,
+                                                         const int8_t* __restrict__ adj_sign,
+                                                         const uint8_t* __restrict__ is_root,
+                                                         const double* __restrict__ omega, const double* __restrict__ w,
+                                                         uint32_t cg_iters, double cg_tol, double* __restrict__ diag,
+                                                         double* __restrict__ x, double* __restrict__ r,
+                                                         double* __restrict__ p, double* __restrict__ Ap,
+                                                         double* __restrict__ stats /* mean|d|, cg iterations */) {
+    __shared__ double red[3 * 1024];
+    const int tid = threadIdx.x;
+    // assemble: diag_k = sum w_e ; b_k = sum sign * w_e * omega_e ; x = 0, r = b, z = r / diag, p = z
+    double rz[3] = {0, 0, 0};
+    for (uint32_t k = tid; k < n_views; k += 1024) {
+        double d = 0, b[3] = {0, 0, 0};
+        if (!is_root[k]) {
+            for (uint32_t a = adj_ptr[k]; a < adj_ptr[k + 1]; ++a) {
+                const uint32_t e = adj_edge[a];
+                const double we = w[e], sg = (double)adj_sign[a];
+                d += we;
+                b[0] += sg * we * omega[3 * (size_t)e + 0];
+                b[1] += sg * we * omega[3 * (size_t)e + 1];
+                b[2] += sg * we * omega[3 * (size_t)e + 2];
+            }
+        }
+        diag[k] = d;
+        const double inv = d > 0.0 ? 1.0 / d : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            x[3 * (size_t)k + c] = 0.0;
+            r[3 * (size_t)k + c] = b[c];
+            const double z = b[c] * inv;
+            p[3 * (size_t)k + c] = z;
+            rz[c] += b[c] * z;
+        }
+    }
+    block_sum3(rz, red, tid);
+    const double rz0[3] = {rz[0], rz[1], rz[2]};
+    uint32_t it = 0;
+    for (; it < cg_iters; ++it) {
+        bool done = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) done &= !(rz[c] > cg_tol * cg_tol * rz0[c]);
+        if (done) break;  // uniform: rz is identical in every thread
+        double pAp[3] = {0, 0, 0};
+        for (uint32_t k = tid; k < n_views; k += 1024) {
+            double y[3] = {0, 0, 0};
+            if (!is_root[k]) {
+                const double d = diag[k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[c] = d * p[3 * (size_t)k + c];
+                for (uint32_t a = adj_ptr[k]; a < adj_ptr[k + 1]; ++a) {
+                    const uint32_t o = adj_other[a];
+                    if (is_root[o]) continue;
+                    const double we = w[adj_edge[a]];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) y[c] -= we * p[3 * (size_t)o + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Ap[3 * (size_t)k + c] = y[c];
+                pAp[c] += p[3 * (size_t)k + c] * y[c];
+            }
+        }
+        block_sum3(pAp, red, tid);
+        double alpha[3], rzn[3] = {0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) alpha[c] = pAp[c] > 0.0 ? rz[c] / pAp[c] : 0.0;
+        for (uint32_t k = tid; k < n_views; k += 1024) {
+            const double d = diag[k], inv = d > 0.0 ? 1.0 / d : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = 3 * (size_t)k + c;
+                x[i] += alpha[c] * p[i];
+                const double rn = r[i] - alpha[c] * Ap[i];
+                r[i] = rn;
+                rzn[c] += rn * (rn * inv);
+            }
+        }
+        block_sum3(rzn, red, tid);
+        for (uint32_t k = tid; k < n_views; k += 1024) {
+            const double d = diag[k], inv = d > 0.0 ? 1.0 / d : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = 3 * (size_t)k + c;
+                const double beta = rz[c] > 0.0 ? rzn[c] / rz[c] : 0.0;
+                p[i] = r[i] * inv + beta * p[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rz[c] = rzn[c];
+    }
+    double nd[3] = {0, 0, 0};
+    for (uint32_t k = tid; k < n_views; k += 1024)
+        nd[0] += sqrt(x[3 * (size_t)k] * x[3 * (size_t)k] + x[3 * (size_t)k + 1] * x[3 * (size_t)k + 1] +
+                      x[3 * (size_t)k + 2] * x[3 * (size_t)k + 2]);
+    block_sum3(nd, red, tid);
+    if (tid == 0) {
+        stats[0] = nd[0] / (double)n_views;
+        stats[1] = (double)it;
+    }
+}
+
+__global__ __launch_bounds__(256) void rot_update_kernel(uint32_t n_views, const double* __restrict__ x,
+                                                         double* __restrict__ R) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_views) return;
+    double Rk[9], Ex[9], Rn[9];
+    const double wv[3] = {x[3 * (size_t)k], x[3 * (size_t)k + 1], x[3 * (size_t)k + 2]};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Rk[c] = R[9 * (size_t)k + c];
+    so3_exp(wv, Ex);
+    mat3_mul(Rk, Ex, Rn);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[9 * (size_t)k + c] = Rn[c];
+}
+
+// ---- host: maximum-weight spanning forest + BFS initialisation ----------------------------------------
+static void spanning_forest_init(uint32_t V, const pgi_rot_edge* E, uint32_t nE, std::vector<double>& R,
+                                 std::vector<uint8_t>& is_root) {
+    std::vector<uint32_t> order(nE);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return E[a].weight > E[b].weight; });
+    std::vector<uint32_t> parent(V);
+    std::iota(parent.begin(), parent.end(), 0u);
+    auto find = [&](uint32_t a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    };
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> adj(V);  // (edge, other|inv<<31)
+    for (uint32_t e : order) {
+        const uint32_t a = find(E[e].src), b = find(E[e].dst);
+        if (a == b) continue;
+        parent[std::max(a, b)] = std::min(a, b);
+        adj[E[e].src].push_back({e, E[e].dst});
+        adj[E[e].dst].push_back({e, E[e].src | 0x80000000u});
+    }
+    R.assign((size_t)V * 9, 0.0);
+    is_root.assign(V, 0);
+    std::vector<uint8_t> seen(V, 0);
+    std::vector<uint32_t> queue;
+    for (uint32_t root = 0; root < V; ++root) {
+        if (seen[root]) continue;
+        seen[root] = 1;
+        is_root[root] = 1;
+        R[9 * (size_t)root] = R[9 * (size_t)root + 4] = R[9 * (size_t)root + 8] = 1.0;
+        queue.assign(1, root);
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const uint32_t u = queue[h];
+            for (auto& pr : adj[u]) {
+                const uint32_t e = pr.first, v = pr.second & 0x7FFFFFFFu;
+                const bool inv = pr.second >> 31;
+                if (seen[v]) continue;
+                seen[v] = 1;
+                const double* Rr = E[e].R;
+                const double* Ru = &R[9 * (size_t)u];
+                double* Rv = &R[9 * (size_t)v];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) {
+                        double s = 0;
+                        for (int k = 0; k < 3; ++k) s += (inv ? Rr[3 * k + i] : Rr[3 * i + k]) * Ru[3 * k + j];
+                        Rv[3 * i + j] = s;
+                    }
+                queue.push_back(v);
+            }
+        }
+    }
+}
+
+}  // namespace pgi
+
+using namespace pgi;
+
+extern "C" {
+
+void pgi_default_rotavg_params(pgi_rotavg_params* p) {
+    p->l1_iters = 5;
+    p->irls_iters = 100;
+    p->cg_iters = 200;
+    p->sigma_deg = 5.0;
+    p->tol = 1e-8;
+}
+
+int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_edges, uint32_t n_views,
+                         const pgi_rotavg_params* prm_in, double* h_R_out, uint32_t* h_iters_out) {
+    if (!ctx || !h_R_out || (n_edges && !h_edges)) return fail(PGI_ERR_INVALID, "null argument");
+    pgi_rotavg_params prm;
+    if (prm_in) prm = *prm_in; else pgi_default_rotavg_params(&prm);
+    for (uint32_t e = 0; e < n_edges; ++e)
+        if (h_edges[e].src >= n_views || h_edges[e].dst >= n_views || h_edges[e].src == h_edges[e].dst)
+            return fail(PGI_ERR_INVALID, "edge endpoints out of range");
+    if (n_views == 0) return PGI_SUCCESS;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<double> R;
+    std::vector<uint8_t> is_root;
+    spanning_forest_init(n_views, h_edges, n_edges, R, is_root);
+    if (h_iters_out) *h_iters_out = 0;
+    if (n_edges == 0) {
+        memcpy(h_R_out, R.data(), R.size() * 8);
+        return PGI_SUCCESS;
+    }
+    // CSR adjacency, incidences in edge order
+    std::vector<uint32_t> ptr(n_views + 1, 0), aedge(2 * (size_t)n_edges), aother(2 * (size_t)n_edges);
+    std::vector<int8_t> asign(2 * (size_t)n_edges);
+    for (uint32_t e = 0; e < n_edges; ++e) {
+        ++ptr[h_edges[e].src + 1];
+        ++ptr[h_edges[e].dst + 1];
+    }
+    for (uint32_t k = 0; k < n_views; ++k) ptr[k + 1] += ptr[k];
+    {
+        std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (uint32_t e = 0; e < n_edges; ++e) {
+            uint32_t a = fill[h_edges[e].src]++;
+            aedge[a] = e; aother[a] = h_edges[e].dst; asign[a] = -1;
+            a = fill[h_edges[e].dst]++;
+            aedge[a] = e; aother[a] = h_edges[e].src; asign[a] = +1;
+        }
+    }
+    static_assert(sizeof(RotEdgeDev) == sizeof(pgi_rot_edge), "edge layout");
+    const size_t V = n_views, E = n_edges;
+    // one allocation, carved
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_edges = carve(E * sizeof(pgi_rot_edge)), o_R = carve(V * 72), o_ptr = carve((V + 1) * 4),
+                 o_aedge = carve(2 * E * 4), o_aother = carve(2 * E * 4), o_asign = carve(2 * E),
+                 o_root = carve(V), o_omega = carve(E * 24), o_w = carve(E * 8), o_diag = carve(V * 8),
+                 o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24),
+                 o_stats = carve(16);
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, off));
+    struct Guard {
+        char* p;
+        ~Guard() { (void)hipFree(p); }
+    } guard{d};
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_edges, h_edges, E * sizeof(pgi_rot_edge), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_R, R.data(), V * 72, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_ptr, ptr.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_aedge, aedge.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_aother, aother.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_asign, asign.data(), 2 * E, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_root, is_root.data(), V, hipMemcpyHostToDevice, st));
+    const double sigma = prm.sigma_deg * 3.14159265358979323846 / 180.0;
+    uint32_t iters = 0;
+    for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
+        hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st,
+                           (const RotEdgeDev*)(d + o_edges), n_edges, (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0,
+                           sigma, (double*)(d + o_omega), (double*)(d + o_w));
+        hipLaunchKernelGGL(rot_solve_kernel, dim3(1), dim3(1024), 0, st, n_views, (const uint32_t*)(d + o_ptr),
+                           (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const int8_t*)(d + o_asign),
+                           (const uint8_t*)(d + o_root), (const double*)(d + o_omega), (const double*)(d + o_w),
+                           prm.cg_iters, 1e-10, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
+                           (double*)(d + o_p), (double*)(d + o_Ap), (double*)(d + o_stats));
+        hipLaunchKernelGGL(rot_update_kernel, dim3((n_views + 255) / 256), dim3(256), 0, st, n_views,
+                           (const double*)(d + o_x), (double*)(d + o_R));
+        double stats[2];
+        HIP_TRY(hipMemcpyAsync(stats, d + o_stats, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        iters = it + 1;
+        if (stats[0] < prm.tol) break;
+    }
+    HIP_TRY(hipMemcpyAsync(h_R_out, d + o_R, V * 72, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_iters_out) *h_iters_out = iters;
+    return PGI_SUCCESS;
+}
+
+}  // extern "C"

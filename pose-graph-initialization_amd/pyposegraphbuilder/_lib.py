@@ -84,9 +84,9 @@ def load():
                                        C.c_void_p, C.c_void_p]
     lib.pgi_decompose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_five_point_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-    if hasattr(lib, "pgi_rotation_average"):
-        lib.pgi_rotation_average.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
-                                             C.POINTER(RotAvgParams), C.c_void_p, C.c_void_p]
+    lib.pgi_rotation_average.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.POINTER(RotAvgParams), C.c_void_p, C.c_void_p]
+    lib.pgi_default_rotavg_params.argtypes = [C.POINTER(RotAvgParams)]
     _lib = lib
     return lib
 

@@ -141,6 +141,27 @@ class Engine:
         L.check(self._lib.pgi_five_point_batch(self._ctx, _ptr(d_pts), S, _ptr(models), _ptr(counts), _ptr(dbg)))
         return models.cpu().numpy(), counts.cpu().numpy(), (dbg.cpu().numpy() if debug else None)
 
+    # ---- rotation averaging -----------------------------------------------------------------------
+    def rotation_average(self, src, dst, R_rel, weight, n_views, **kw):
+        """L1 + IRLS rotation averaging over edges (src, dst, R_dst_src, weight) -> (R[n_views,3,3], iters)."""
+        E = len(src)
+        edges = np.zeros(E, L.ROT_EDGE_DTYPE)
+        edges["src"], edges["dst"] = src, dst
+        edges["R"] = np.asarray(R_rel, np.float64).reshape(E, 9)
+        edges["weight"] = weight
+        prm = L.RotAvgParams()
+        self._lib.pgi_default_rotavg_params(C.byref(prm))
+        for k, v in kw.items():
+            if not hasattr(prm, k):
+                raise TypeError("unknown parameter %r" % k)
+            setattr(prm, k, v)
+        R = np.zeros((n_views, 3, 3))
+        iters = C.c_uint32(0)
+        self._bind_stream()
+        L.check(self._lib.pgi_rotation_average(self._ctx, edges.ctypes.data_as(C.c_void_p), E, n_views, C.byref(prm),
+                                               R.ctypes.data_as(C.c_void_p), C.byref(iters)))
+        return R, iters.value
+
     # ---- single-pair drop-in (host pointers) --------------------------------------------------
     def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
         """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""

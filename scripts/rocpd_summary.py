@@ -10,13 +10,13 @@ def main():
         db = sqlite3.connect(path)
         cur = db.cursor()
         print("==", path)
-        print("%-60s %6s %12s %12s %7s  vgpr agpr sgpr lds" % ("kernel", "calls", "total_ns", "avg_ns", "%"))
-        rows = cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
+        print("%-60s %6s %12s %12s %7s  vgpr agpr sgpr lds" % ("kernel", "calls", "total_us", "avg_us", "%"))
+        rows = cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()  # view is in us
         meta = {r[0]: r[1:] for r in cur.execute(
             "select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name")}
         for name, calls, tot, avg, pct in rows:
             m = meta.get(name, ("", "", "", ""))
-            print("%-60s %6d %12d %12.0f %7.2f  %s %s %s %s" % (name[:60], calls, tot, avg, pct, *m))
+            print("%-60s %6d %12.1f %12.1f %7.2f  %s %s %s %s" % (name[:60], calls, tot, avg, pct, *m))
         try:
             cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')")]
             if "counter_name" in cols:

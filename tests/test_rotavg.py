@@ -1,0 +1,69 @@
+"""Rotation averaging: the numpy/scipy oracle on known graphs (CPU) and the HIP solver against it (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import rotavg_oracle as RO  # noqa: E402
+
+
+def test_oracle_exact_on_noise_free_graph():
+    src, dst, Rrel, w, Rgt, _ = RO.make_graph(40, 5, noise_deg=0.0, outlier_frac=0.0, seed=1)
+    R, iters = RO.rotation_average(40, src, dst, Rrel, w)
+    assert RO.align_error_deg(R, Rgt).max() < 1e-4  # arccos resolution near 1
+    assert iters <= 2
+
+
+def test_oracle_rejects_outlier_edges():
+    src, dst, Rrel, w, Rgt, out = RO.make_graph(50, 6, noise_deg=1.0, outlier_frac=0.15, seed=3)
+    R0, _ = RO.spanning_forest_init(50, src, dst, Rrel, w)
+    R, iters = RO.rotation_average(50, src, dst, Rrel, w)
+    e0, e = RO.align_error_deg(R0, Rgt), RO.align_error_deg(R, Rgt)
+    assert e.mean() < 0.6 and e.max() < 1.5 and e.mean() < 0.5 * e0.mean()
+    # consistent with every inlier edge to ~noise level
+    res = np.einsum("eji,ejk,ekl->eil", R[dst], Rrel, R[src])
+    ang = np.degrees(np.arccos(np.clip((np.trace(res, axis1=1, axis2=2) - 1) / 2, -1, 1)))
+    assert np.median(ang[~out]) < 1.5 and np.median(ang[out]) > 20
+
+
+def test_oracle_disconnected_components_and_gauge():
+    src, dst, Rrel, w, Rgt, _ = RO.make_graph(30, 4, noise_deg=0.0, outlier_frac=0.0, seed=5, components=3)
+    R, _ = RO.rotation_average(30, src, dst, Rrel, w)
+    for c in range(3):  # each component has its own gauge: its smallest view is the identity
+        np.testing.assert_allclose(R[c], np.eye(3), atol=1e-12)
+        idx = np.arange(c, 30, 3)
+        G = Rgt[c].T @ R[c]
+        for k in idx:
+            np.testing.assert_allclose(Rgt[k] @ G, R[k], atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,k,noise,outl,comps", [(40, 5, 0.0, 0.0, 1), (50, 6, 1.0, 0.15, 1), (340, 20, 1.0, 0.2, 1),
+                                                  (30, 4, 0.5, 0.1, 3), (1500, 12, 2.0, 0.25, 1)])
+def test_hip_rotation_averaging_matches_oracle(V, k, noise, outl, comps):
+    from pyposegraphbuilder import Engine
+    eng = Engine()
+    src, dst, Rrel, w, Rgt, _ = RO.make_graph(V, k, noise, outl, seed=7, components=comps)
+    R, iters = eng.rotation_average(src, dst, Rrel, w, V)
+    Ro, iters_o = RO.rotation_average(V, src, dst, Rrel, w)
+    d = np.einsum("kij,kmj->kim", R, Ro)
+    ang = np.arccos(np.clip((np.trace(d, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    assert ang.max() < 1e-5, (ang.max(), iters, iters_o)  # rad; PCG vs sparse direct solve, ocml vs libm
+    assert abs(iters - iters_o) <= 1
+    np.testing.assert_allclose(np.einsum("kij,kmj->kim", R, R), np.tile(np.eye(3), (V, 1, 1)), atol=1e-9)
+    if comps == 1:
+        assert RO.align_error_deg(R, Rgt).mean() < max(0.05, noise)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_rotation_averaging_edge_cases():
+    from pyposegraphbuilder import Engine, PgiError
+    eng = Engine()
+    R, it = eng.rotation_average(np.zeros(0, int), np.zeros(0, int), np.zeros((0, 3, 3)), np.zeros(0), 4)
+    np.testing.assert_array_equal(R, np.tile(np.eye(3), (4, 1, 1)))
+    with pytest.raises(PgiError):
+        eng.rotation_average([0], [7], [np.eye(3)], [1.0], 3)
+    eng.close()
