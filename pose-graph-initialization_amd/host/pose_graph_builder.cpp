@@ -1,0 +1,179 @@
+// pose_graph_builder.cpp -- implementation of the C++ host layer (links against libpgi.so).
+// HIP is used here for device buffers and copies only; every computation is a C-ABI call.
+#include "pose_graph_builder.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace reconstruction {
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) throw PgiError("hipMalloc failed");
+    }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+void h2d(void* d, const void* h, size_t n) {
+    if (n && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) throw PgiError("hipMemcpy H2D failed");
+}
+void d2h(void* h, const void* d, size_t n) {
+    if (n && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) != hipSuccess) throw PgiError("hipMemcpy D2H failed");
+}
+}  // namespace
+
+namespace detail {
+int score_f64(pgi_ctx* ctx, const double* corr, uint32_t n, const double E[9], double tau2, uint32_t* count,
+              uchar* mask) {
+    DevBuf dc((size_t)n * 32), doff(16), dE(72), dt(8), dcnt(4), dm(n);
+    const uint64_t off[2] = {0, n};
+    h2d(dc.p, corr, (size_t)n * 32);
+    h2d(doff.p, off, 16);
+    h2d(dE.p, E, 72);
+    h2d(dt.p, &tau2, 8);
+    int rc = pgi_score_pose_f64(ctx, dc.as<double>(), doff.as<uint64_t>(), 1, dE.as<double>(), dt.as<double>(),
+                                dcnt.as<uint32_t>(), dm.as<uint8_t>());
+    if (rc < 0) return rc;
+    rc = pgi_synchronize(ctx);
+    if (rc < 0) return rc;
+    d2h(count, dcnt.p, 4);
+    if (mask) d2h(mask, dm.p, n);
+    return PGI_SUCCESS;
+}
+}  // namespace detail
+
+namespace {
+// f64 AoS rows of many pairs -> flattened f32 SoA batch on the device
+struct DeviceBatch {
+    std::vector<uint64_t> off;
+    size_t rows = 0;
+    std::unique_ptr<DevBuf> x1, y1, x2, y2, doff, thr, guess, has, edges, masks;
+    pgi_batch b{};
+};
+}  // namespace
+
+size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
+                                       std::vector<pgi_edge>* edges_out) {
+    const size_t P = pairs.size();
+    if (!P) return 0;
+    std::vector<uint64_t> off(P + 1, 0);
+    uint32_t max_corr = 0;
+    for (size_t i = 0; i < P; ++i) {
+        off[i + 1] = off[i] + (uint64_t)pairs[i].correspondences.rows;
+        max_corr = std::max(max_corr, (uint32_t)pairs[i].correspondences.rows);
+    }
+    const size_t rows = off[P];
+    std::vector<float> x1(rows), y1(rows), x2(rows), y2(rows);
+    std::vector<double> thr(P), guess(12 * P, 0.0);
+    std::vector<uint8_t> has(P, 0);
+    bool any_guess = false;
+    for (size_t i = 0; i < P; ++i) {
+        const CorrespondenceMatrix& c = pairs[i].correspondences;
+        for (int r = 0; r < c.rows; ++r) {
+            const double* q = c.ptr(r);
+            const size_t k = off[i] + (size_t)r;
+            x1[k] = (float)q[0]; y1[k] = (float)q[1]; x2[k] = (float)q[2]; y2[k] = (float)q[3];
+        }
+        thr[i] = pairs[i].normalizedThreshold;
+        if (!pairs[i].poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
+            const SE3d& g = pairs[i].poseGuesses.back();
+            for (int c2 = 0; c2 < 9; ++c2) guess[12 * i + c2] = g.R[c2];
+            for (int c2 = 0; c2 < 3; ++c2) guess[12 * i + 9 + c2] = g.t[c2];
+            has[i] = 1;
+            any_guess = true;
+        }
+    }
+    DevBuf dx1(rows * 4), dy1(rows * 4), dx2(rows * 4), dy2(rows * 4), doff((P + 1) * 8), dthr(P * 8),
+        dguess(P * 96), dhas(P), dedges(P * sizeof(pgi_edge)), dmasks(rows);
+    h2d(dx1.p, x1.data(), rows * 4); h2d(dy1.p, y1.data(), rows * 4);
+    h2d(dx2.p, x2.data(), rows * 4); h2d(dy2.p, y2.data(), rows * 4);
+    h2d(doff.p, off.data(), (P + 1) * 8); h2d(dthr.p, thr.data(), P * 8);
+    if (any_guess) {
+        h2d(dguess.p, guess.data(), P * 96);
+        h2d(dhas.p, has.data(), P);
+    }
+    pgi_batch b{};
+    b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
+    b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
+    b.d_guess_Rt = any_guess ? dguess.as<double>() : nullptr;
+    b.d_has_guess = any_guess ? dhas.as<uint8_t>() : nullptr;
+    b.n_pairs = (uint32_t)P; b.max_corr = max_corr; b.pair_id_base = 0; b.seed = seed;
+    Engine::check(pgi_estimate_pose_batch(engine->get(), &b, dedges.as<pgi_edge>(), dmasks.as<uint8_t>()));
+    Engine::check(pgi_synchronize(engine->get()));
+    std::vector<pgi_edge> edges(P);
+    d2h(edges.data(), dedges.p, P * sizeof(pgi_edge));
+    size_t added = 0;
+    for (size_t i = 0; i < P; ++i) {
+        if (edges[i].status != PGI_EDGE_OK) continue;  // caller `continue`s (pose_graph_builder.h:641-642)
+        SE3d T;
+        for (int c = 0; c < 9; ++c) T.R[c] = edges[i].R[c];
+        for (int c = 0; c < 3; ++c) T.t[c] = edges[i].t[c];
+        const double score = (double)edges[i].n_inl / (double)std::max(1, pairs[i].correspondences.rows);
+        poseGraph_.addEdge(pairs[i].src, pairs[i].dst, Pose(T), score);  // :645-654
+        ++added;
+    }
+    if (edges_out) *edges_out = std::move(edges);
+    return added;
+}
+
+void PoseGraphBuilder::run(std::vector<ViewPair>& cand, PoseGraph& poseGraph_, size_t waveSize) {
+    // descending similarity, ties by (src,dst): the order the reference pops its heap
+    std::stable_sort(cand.begin(), cand.end(), [](const ViewPair& a, const ViewPair& b) {
+        if (a.similarity != b.similarity) return a.similarity > b.similarity;
+        return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);
+    });
+    std::vector<ViewPair> wave;
+    uint64_t seed = 0;
+    for (size_t i = 0; i < cand.size(); ++i) {
+        ViewPair& vp = cand[i];
+        if (vp.similarity < kSimilarityThreshold) break;                       // heap holds sim >= threshold only
+        if (poseGraph_.hasEdge(vp.src, vp.dst)) continue;                      // pose_graph_builder.h:426-431
+        if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
+        if (!poseGraph_.hasVertex(vp.src)) poseGraph_.addVertex(vp.src);
+        if (!poseGraph_.hasVertex(vp.dst)) poseGraph_.addVertex(vp.dst);
+        wave.push_back(std::move(vp));
+        if (wave.size() == waveSize) {
+            estimatePoses(wave, poseGraph_, seed++);
+            wave.clear();
+        }
+    }
+    if (!wave.empty()) estimatePoses(wave, poseGraph_, seed++);
+}
+
+namespace pose {
+int getPoseFromEssentialMatrix(Engine& eng, const Matrix3d& E, const CorrespondenceMatrix& c, Matrix3d& rotation_,
+                               Vector3d& translation_) {
+    const size_t n = (size_t)c.rows;
+    std::vector<float> x1(n), y1(n), x2(n), y2(n);
+    for (size_t r = 0; r < n; ++r) {
+        const double* q = c.ptr((int)r);
+        x1[r] = (float)q[0]; y1[r] = (float)q[1]; x2[r] = (float)q[2]; y2[r] = (float)q[3];
+    }
+    DevBuf dx1(n * 4), dy1(n * 4), dx2(n * 4), dy2(n * 4), doff(16), dthr(8), dE(72), dedge(sizeof(pgi_edge));
+    const uint64_t off[2] = {0, n};
+    const double thr = 0;
+    h2d(dx1.p, x1.data(), n * 4); h2d(dy1.p, y1.data(), n * 4); h2d(dx2.p, x2.data(), n * 4); h2d(dy2.p, y2.data(), n * 4);
+    h2d(doff.p, off, 16); h2d(dthr.p, &thr, 8); h2d(dE.p, E.data(), 72);
+    pgi_batch b{};
+    b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
+    b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>(); b.n_pairs = 1; b.max_corr = (uint32_t)n;
+    // all rows vote, as in the reference (pose_utils.h:203)
+    Engine::check(pgi_decompose_batch(eng.get(), &b, dE.as<double>(), nullptr, dedge.as<pgi_edge>()));
+    Engine::check(pgi_synchronize(eng.get()));
+    pgi_edge e;
+    d2h(&e, dedge.p, sizeof e);
+    for (int k = 0; k < 9; ++k) rotation_[k] = e.R[k];
+    for (int k = 0; k < 3; ++k) translation_[k] = e.t[k];
+    return (int)e.votes;
+}
+}  // namespace pose
+
+}  // namespace reconstruction

@@ -1,0 +1,376 @@
+// pose_graph_builder.hpp -- C++17 host layer over the C ABI (include/pgi.h), mirroring the
+// reference's interface for the pose-estimation path so that its call sites read the same:
+//
+//   reconstruction::Pose                     <- include/pose.h:11-104
+//   reconstruction::PoseGraphEdge/PoseGraph  <- include/pose_graph.h:28-226
+//   reconstruction::EssentialMatrixEvaluator <- include/graph_traversal.h:82-170
+//   reconstruction::InTraversalPoseTester    <- include/graph_traversal.h:174-242
+//   reconstruction::pose::getPoseFromEssentialMatrix <- include/pose_utils.h:172-252
+//   reconstruction::PoseGraphBuilder         <- include/pose_graph_builder.h:25-171 (17-argument ctor,
+//                                               estimatePose seam :153-164, batched variant for the scheduler)
+//
+// The reference's signatures use cv::Mat / Eigen / Sophus types, none of which exist on this
+// image; the stand-ins below keep the same member names and meaning:
+//   Sophus::SE3d  -> reconstruction::SE3d  {rotationMatrix(), translation(), inverse(), operator*}
+//   cv::Mat N x 4 CV_64F -> reconstruction::CorrespondenceMatrix (row-major doubles, rows/cols/ptr)
+//   Eigen::Matrix3d -> reconstruction::Matrix3d (row-major double[9])
+// All arithmetic runs on the GPU through libpgi.so; there is no CPU path.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pgi.h"
+
+namespace reconstruction {
+
+typedef size_t ViewId;  // include/types.h:9-14
+typedef std::pair<ViewId, ViewId> EdgeId;
+typedef unsigned char uchar;
+using Matrix3d = std::array<double, 9>;  // row-major
+using Vector3d = std::array<double, 3>;
+
+struct SE3d {  // T_dst_src: x_dst = R x_src + t
+    Matrix3d R{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    Vector3d t{{0, 0, 0}};
+    SE3d() = default;
+    SE3d(const Matrix3d& R_, const Vector3d& t_) : R(R_), t(t_) {}
+    const Matrix3d& rotationMatrix() const { return R; }
+    const Vector3d& translation() const { return t; }
+    SE3d inverse() const {
+        SE3d o;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) o.R[3 * i + j] = R[3 * j + i];
+        for (int i = 0; i < 3; ++i) o.t[i] = -(o.R[3 * i] * t[0] + o.R[3 * i + 1] * t[1] + o.R[3 * i + 2] * t[2]);
+        return o;
+    }
+    SE3d operator*(const SE3d& b) const {  // (this * b)(x) = this(b(x))
+        SE3d o;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j)
+                o.R[3 * i + j] = R[3 * i] * b.R[j] + R[3 * i + 1] * b.R[3 + j] + R[3 * i + 2] * b.R[6 + j];
+            o.t[i] = R[3 * i] * b.t[0] + R[3 * i + 1] * b.t[1] + R[3 * i + 2] * b.t[2] + t[i];
+        }
+        return o;
+    }
+};
+
+struct CorrespondenceMatrix {  // cv::Mat N x 4 CV_64F: [x1 y1 x2 y2], normalised (pose_graph_builder.h:917-931)
+    int rows = 0;
+    static constexpr int cols = 4;
+    std::vector<double> data;
+    CorrespondenceMatrix() = default;
+    explicit CorrespondenceMatrix(int n) : rows(n), data((size_t)n * 4) {}
+    double* ptr(int r = 0) { return data.data() + 4 * (size_t)r; }
+    const double* ptr(int r = 0) const { return data.data() + 4 * (size_t)r; }
+};
+
+namespace pose {
+// pose_utils.h:74-86
+inline Matrix3d getEssentialMatrixFromRelativePose(const SE3d& p) {
+    const Vector3d& t = p.t;
+    const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    Matrix3d E;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += tx[3 * i + k] * p.R[3 * k + j];
+            E[3 * i + j] = s;
+        }
+    return E;
+}
+}  // namespace pose
+
+class Pose {  // include/pose.h
+   public:
+    Pose() = default;
+    Pose(const SE3d& T_dst_src_, double source_scale_ = 0.0, double destination_scale_ = 0.0)
+        : essentialMatrix(pose::getEssentialMatrixFromRelativePose(T_dst_src_)),
+          T_dst_src(T_dst_src_),
+          sourceScale(source_scale_),
+          destinationScale(destination_scale_) {}
+    Pose(const Matrix3d& rotation_, const Vector3d& translation_) : Pose(SE3d(rotation_, translation_)) {}
+    Pose clone() const { return Pose(T_dst_src, sourceScale, destinationScale); }
+    void setPose(const SE3d& T) {
+        T_dst_src = T;
+        essentialMatrix = pose::getEssentialMatrixFromRelativePose(T);
+    }
+    const SE3d& getTransform() const { return T_dst_src; }
+    const Matrix3d& getRotation() const { return T_dst_src.R; }
+    const Vector3d& getTranslation() const { return T_dst_src.t; }
+    const Matrix3d& getEssentialMatrix() const { return essentialMatrix; }
+    Pose getInverse() const { return Pose(T_dst_src.inverse()); }
+    Pose operator*(const Pose& o) const { return Pose(T_dst_src * o.getTransform()); }
+    void getScales(double& s, double& d) const {
+        s = sourceScale;
+        d = destinationScale;
+    }
+
+   protected:
+    Matrix3d essentialMatrix{};
+    SE3d T_dst_src;
+    double sourceScale = 0, destinationScale = 0;
+};
+
+class PoseGraphVertex {
+   public:
+    static constexpr ViewId Undefined = (ViewId)-1;
+    PoseGraphVertex(ViewId id_ = Undefined) : view_id(id_) {}
+    const ViewId& id() const { return view_id; }
+    bool isUndefined() const { return view_id == Undefined; }
+
+   protected:
+    ViewId view_id;
+};
+
+class PoseGraphEdge {  // include/pose_graph.h:28-60; score = inlier ratio (pose_graph_builder.h:645-654)
+   public:
+    PoseGraphEdge(ViewId s = PoseGraphVertex::Undefined, ViewId d = PoseGraphVertex::Undefined, Pose T = Pose(),
+                  double score_ = 1.0)
+        : view_id_src(s), view_id_dst(d), score(score_), T_dst_src(std::move(T)) {}
+    bool isUndefined() const {
+        return view_id_src == PoseGraphVertex::Undefined || view_id_dst == PoseGraphVertex::Undefined;
+    }
+    const ViewId& getSourceId() const { return view_id_src; }
+    const ViewId& getDestinationId() const { return view_id_dst; }
+    const Pose& getValue() const { return T_dst_src; }
+    Pose& getMutableValue() { return T_dst_src; }
+    const double& getScore() const { return score; }
+
+   protected:
+    ViewId view_id_src, view_id_dst;
+    double score;
+    Pose T_dst_src;
+};
+
+class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing ids)
+   public:
+    size_t numVertices() const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        return vertices.size();
+    }
+    size_t numEdges() const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        return edges.size();
+    }
+    void addVertex(ViewId id) {
+        std::unique_lock<std::shared_mutex> l(mu);
+        vertices.emplace(id, PoseGraphVertex(id));
+    }
+    bool hasVertex(ViewId id) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        return vertices.count(id) != 0;
+    }
+    bool hasEdge(ViewId s, ViewId d) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        return edges.count({s, d}) != 0;
+    }
+    void addEdge(ViewId s, ViewId d, const Pose& T, double score = 1.0) {
+        std::unique_lock<std::shared_mutex> l(mu);
+        edges.emplace(EdgeId{s, d}, PoseGraphEdge(s, d, T, score));
+    }
+    PoseGraphEdge getEdgeById(const EdgeId& id) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        auto it = edges.find(id);
+        return it == edges.end() ? PoseGraphEdge() : it->second;
+    }
+    std::vector<EdgeId> getEdgeIds() const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        std::vector<EdgeId> ids;
+        for (auto& kv : edges) ids.push_back(kv.first);
+        return ids;
+    }
+
+   protected:
+    mutable std::shared_mutex mu;
+    std::map<ViewId, PoseGraphVertex> vertices;
+    std::map<EdgeId, PoseGraphEdge> edges;
+};
+
+// ---- the engine handle shared by the classes below ---------------------------------------------------
+class PgiError : public std::runtime_error {
+   public:
+    using std::runtime_error::runtime_error;
+};
+
+class Engine {
+   public:
+    explicit Engine(int device = -1, const pgi_params* prm = nullptr) : ctx(pgi_create(device, prm)) {
+        if (!ctx) throw PgiError(std::string("pgi_create: ") + pgi_last_error());
+    }
+    ~Engine() { pgi_destroy(ctx); }
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+    pgi_ctx* get() const { return ctx; }
+    static void check(int rc) {
+        if (rc < 0) throw PgiError(pgi_last_error());
+    }
+
+   protected:
+    pgi_ctx* ctx;
+};
+
+// device buffer helpers live in the implementation file to keep HIP out of this header
+namespace detail {
+int score_f64(pgi_ctx* ctx, const double* corr, uint32_t n, const double E[9], double tau2, uint32_t* count,
+              uchar* mask);
+}
+
+class EssentialMatrixEvaluator {  // include/graph_traversal.h:82-170
+   public:
+    explicit EssentialMatrixEvaluator(Engine& e) : eng(&e) {}
+    // graph_traversal.h:136-168.  NOTE the reference compares the SQUARED residual with the un-squared
+    // kThreshold_ (line 164); this call reproduces that: pass 1.5*thr exactly as estimatePose does (:985-989).
+    void getInliers(const CorrespondenceMatrix& kCorrespondences_, const Matrix3d& kDescriptor_,
+                    const double& kThreshold_, std::vector<size_t>& inliers_) const {
+        std::vector<uchar> mask((size_t)kCorrespondences_.rows);
+        uint32_t cnt = 0;
+        Engine::check(detail::score_f64(eng->get(), kCorrespondences_.ptr(), (uint32_t)kCorrespondences_.rows,
+                                        kDescriptor_.data(), kThreshold_, &cnt, mask.data()));
+        inliers_.reserve((size_t)kCorrespondences_.rows);
+        for (size_t i = 0; i < mask.size(); ++i)
+            if (mask[i]) inliers_.emplace_back(i);
+    }
+
+   protected:
+    Engine* eng;
+};
+
+template <typename _Evaluator = EssentialMatrixEvaluator>
+class InTraversalPoseTester {  // include/graph_traversal.h:174-242
+   public:
+    InTraversalPoseTester(Engine& e, double kInlierOutlierThreshold_, size_t kMinimumInlierNumber_,
+                          const CorrespondenceMatrix* correspondences_)
+        : eng(&e),
+          kSquaredInlierOutlierThreshold(kInlierOutlierThreshold_ * kInlierOutlierThreshold_),
+          kMinimumInlierNumber(kMinimumInlierNumber_),
+          correspondences(correspondences_) {}
+    // graph_traversal.h:194-233: true as soon as kMinimumInlierNumber inliers exist; inlierNumber_ is then
+    // exactly kMinimumInlierNumber (the reference returns at that inlier), otherwise the full count.
+    bool test(const SE3d& kPose_, size_t& inlierNumber_) const {
+        const Matrix3d E = pose::getEssentialMatrixFromRelativePose(kPose_);
+        uint32_t cnt = 0;
+        Engine::check(detail::score_f64(eng->get(), correspondences->ptr(), (uint32_t)correspondences->rows, E.data(),
+                                        kSquaredInlierOutlierThreshold, &cnt, nullptr));
+        const bool ok = cnt >= kMinimumInlierNumber;
+        inlierNumber_ = ok ? kMinimumInlierNumber : cnt;
+        return ok;
+    }
+
+   protected:
+    Engine* eng;
+    double kSquaredInlierOutlierThreshold;
+    size_t kMinimumInlierNumber;
+    const CorrespondenceMatrix* correspondences;
+};
+
+class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
+   public:
+    PoseGraphBuilder(const size_t kCoreNumber_, const size_t kMaximumTrackletNumber_,
+                     const size_t kMaximumSearchDepth_, const size_t kMaximumPathNumber_,
+                     const size_t kMinimumInlierNumber_, const size_t kMinimumPointNumber_,
+                     const size_t kMaximumPointNumberForEpipolarHashing_, const double kTraversalHeuristicsWeight_,
+                     const double kSimilarityThreshold_, const double kInlierOutlierThreshold_,
+                     const std::string& kImagePath_, const std::string& kWorkspacePath_,
+                     const std::string& kSimilarityGraphPath_, const std::string& kFocalLengthPath_,
+                     const bool kUsePathFinding_, const bool kUseGPU_, const bool kUseEpipolarHashing_)
+        : kCoreNumber(kCoreNumber_),
+          kMinimumInlierNumber(kMinimumInlierNumber_),
+          kMinimumPointNumber(kMinimumPointNumber_),
+          kMaximumPointNumberForEpipolarHashing(kMaximumPointNumberForEpipolarHashing_),
+          kMaximumSearchDepth(kMaximumSearchDepth_),
+          kMaximumPathNumber(kMaximumPathNumber_),
+          kMaximumTrackletNumber(kMaximumTrackletNumber_),
+          kImagePath(kImagePath_),
+          kWorkspacePath(kWorkspacePath_),
+          kSimilarityGraphPath(kSimilarityGraphPath_),
+          kFocalLengthPath(kFocalLengthPath_),
+          kUseGPU(kUseGPU_),
+          kUsePathFinding(kUsePathFinding_),
+          kUseEpipolarHashing(kUseEpipolarHashing_),
+          kTraversalHeuristicsWeight(kTraversalHeuristicsWeight_),
+          kInlierOutlierThreshold(kInlierOutlierThreshold_),
+          kSimilarityThreshold(kSimilarityThreshold_) {
+        pgi_params p;
+        pgi_default_params(&p);
+        p.min_inliers = (uint32_t)kMinimumInlierNumber_;
+        engine.reset(new Engine(-1, &p));
+    }
+
+    // A candidate view pair with its normalised correspondences (what processImages hands to
+    // estimatePose, pose_graph_builder.h:553-565, 616-627).
+    struct ViewPair {
+        ViewId src, dst;
+        double similarity;
+        CorrespondenceMatrix correspondences;
+        double normalizedThreshold;
+        std::vector<SE3d> poseGuesses;  // from the A* traversal (0 or 1 in the reference)
+    };
+
+    // The estimatePose seam (pose_graph_builder.h:153-164, 940-1078).  reconstruction_, the pixel threshold
+    // and the view indices are unused by the reference's body and are therefore not parameters here.
+    bool estimatePose(const size_t kMinimumInlierNumber_, const CorrespondenceMatrix& kCorrespondences_,
+                      const double kThreshold_, const std::vector<SE3d>& poseGuesses_, SE3d& estimatedPose_,
+                      std::vector<uchar>& inlierMask_, size_t& inlierNumber_, uint64_t seed = 0,
+                      uint64_t pairId = 0) {
+        pgi_params p;
+        pgi_default_params(&p);
+        p.min_inliers = (uint32_t)kMinimumInlierNumber_;
+        Engine::check(pgi_set_params(engine->get(), &p));
+        std::vector<double> g(12 * poseGuesses_.size());
+        for (size_t i = 0; i < poseGuesses_.size(); ++i) {
+            for (int c = 0; c < 9; ++c) g[12 * i + c] = poseGuesses_[i].R[c];
+            for (int c = 0; c < 3; ++c) g[12 * i + 9 + c] = poseGuesses_[i].t[c];
+        }
+        inlierMask_.assign((size_t)kCorrespondences_.rows, 0);  // :1000, :1034
+        pgi_edge e;
+        uchar dummy = 0;
+        const int rc = pgi_estimate_pose(engine->get(), kCorrespondences_.ptr(), (uint32_t)kCorrespondences_.rows,
+                                         kThreshold_, g.empty() ? nullptr : g.data(), (uint32_t)poseGuesses_.size(),
+                                         seed, pairId, &e, inlierMask_.empty() ? &dummy : inlierMask_.data());
+        Engine::check(rc);
+        inlierNumber_ = e.n_inl;
+        if (rc != 1) return false;  // :1053-1054, :1069-1070
+        for (int c = 0; c < 9; ++c) estimatedPose_.R[c] = e.R[c];
+        for (int c = 0; c < 3; ++c) estimatedPose_.t[c] = e.t[c];
+        return true;
+    }
+
+    // Batched form used by run(): every pair of a wave in one launch; edges with score =
+    // inliers / matches are added to the pose graph (pose_graph_builder.h:645-654).
+    size_t estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed = 0,
+                         std::vector<pgi_edge>* edges_out = nullptr);
+
+    // Wave-scheduled run over caller-provided candidate pairs (the image / feature / matching stages of
+    // the reference's run() -- pose_graph_builder.h:173-239, 352-715 -- are outside this build's scope,
+    // DESIGN.md §6): pairs above kSimilarityThreshold with at least kMinimumPointNumber matches, in
+    // descending similarity (imagesimilarity_graph.h max-heap order), are estimated in batches.
+    void run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096);
+
+    Engine& getEngine() { return *engine; }
+
+   protected:
+    const size_t kCoreNumber, kMinimumInlierNumber, kMinimumPointNumber, kMaximumPointNumberForEpipolarHashing,
+        kMaximumSearchDepth, kMaximumPathNumber, kMaximumTrackletNumber;
+    const std::string kImagePath, kWorkspacePath, kSimilarityGraphPath, kFocalLengthPath;
+    const bool kUseGPU, kUsePathFinding, kUseEpipolarHashing;
+    const double kTraversalHeuristicsWeight, kInlierOutlierThreshold, kSimilarityThreshold;
+    std::unique_ptr<Engine> engine;
+};
+
+namespace pose {
+// pose_utils.h:172-252: returns the vote count of the chosen candidate
+int getPoseFromEssentialMatrix(Engine& eng, const Matrix3d& essential_matrix_,
+                               const CorrespondenceMatrix& normalized_correspondences_, Matrix3d& rotation_,
+                               Vector3d& translation_);
+}  // namespace pose
+
+}  // namespace reconstruction

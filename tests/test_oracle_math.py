@@ -182,9 +182,9 @@ def test_jacobi9_matches_eigh():
         w = np.linalg.eigvalsh(A)
         np.testing.assert_allclose(np.sort(np.diag(D)), w, atol=1e-11 * w[-1])
         np.testing.assert_allclose(V.T @ V, np.eye(9), atol=1e-12)
-        np.testing.assert_allclose(A @ V, V * np.diag(D), atol=1e-10 * w[-1])
+        np.testing.assert_allclose(A @ V, V * np.diag(D), atol=1e-9 * w[-1])  # 6 fixed sweeps
         off = D - np.diag(np.diag(D))
-        assert np.abs(off).max() < 1e-12 * w[-1]
+        assert np.abs(off).max() < 1e-9 * w[-1]
         B = O.basis_from_eigen(D, V)
         order = np.argsort(np.diag(D), kind="stable")
         np.testing.assert_array_equal(B[3], V[:, order[0]])
