@@ -187,6 +187,25 @@ uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, cons
     return c;
 }
 
+/* Pre-verification (T(d,d)-style, Matas & Chum): once a best model with n_bar inliers exists, a
+ * candidate must show at least floor(16*n_bar/n) rows within 1.5*thr among the FIRST min(64,n)
+ * rows -- a quarter of what a model as good as the best is expected to show -- or it is dropped
+ * unscored.  Keyed only on state fixed at round start, so it is execution-order independent. */
+int pgo_preverify(const float E[9], const float* x1, const float* y1, const float* x2, const float* y2,
+                  uint32_t n, double thr, uint32_t n_bar) {
+    if (n_bar == 0) return 1;
+    const float thr2 = (float)(thr * thr);
+    const uint32_t k_min = (uint32_t)((16ull * n_bar) / n);
+    const uint32_t m = n < 64 ? n : 64;
+    uint32_t c3 = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        float r2, den;
+        sampson_terms(E, x1[i], y1[i], x2[i], y2[i], &r2, &den);
+        c3 += (r2 < 2.25f * (thr2 * den));
+    }
+    return c3 >= k_min;
+}
+
 /* ---- pivot key: high word of |a| with the row packed into the low 4 bits */
 static inline int32_t pivot_key(double a, int row) {
     uint64_t b;
@@ -749,6 +768,7 @@ static void local_optimise(const float* x1, const float* y1, const float* x2, co
         uint32_t bs = best->score, bi = 0, bn = 0;
         for (uint32_t m = 0; m < nm; ++m) {
             uint32_t s, c;
+            if (!pgo_preverify(models[m], x1, y1, x2, y2, n, thr, best->n_inl)) continue;
             pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
             if (s > bs) { bs = s; bi = m; bn = c; improved = 1; }
         }
@@ -770,6 +790,9 @@ void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, con
     const uint32_t rs = prm->round_size ? prm->round_size : 32;
     const uint32_t budget = prm->fixed_budget ? prm->fixed_budget : prm->max_iters;
     uint32_t hyps = 0, lo_runs = 0;
+    /* pre-verification bar of the NEXT round: inliers of the best right after a round's merge and
+     * BEFORE its local optimisation (so hypotheses of round r+1 may start while LO of round r runs) */
+    uint32_t n_bar = 0;
     while (hyps < budget) {
         /* one round: rs hypotheses, best by (score desc, hyp asc, root asc) */
         best_t rb;
@@ -785,6 +808,7 @@ void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, con
             const uint32_t nm = pgo_five_point(pts, models, NULL);
             for (uint32_t m = 0; m < nm; ++m) {
                 uint32_t s, c;
+                if (!pgo_preverify(models[m], x1, y1, x2, y2, n, thr, n_bar)) continue;
                 pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
                 if (!rb.valid || s > rb.score) {
                     memcpy(rb.E, models[m], sizeof rb.E);
@@ -795,7 +819,10 @@ void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, con
         hyps += rs;
         if (rb.valid && (!best.valid || rb.score > best.score)) {
             best = rb;
+            n_bar = best.n_inl;
             local_optimise(x1, y1, x2, y2, n, thr, prm, &best, mask, &lo_runs);
+        } else {
+            n_bar = best.valid ? best.n_inl : 0;
         }
         if (!prm->fixed_budget && best.valid && best.n_inl >= 5) {
             const double rho = (double)best.n_inl / (double)n;

@@ -109,6 +109,9 @@ void pgo_sample5(uint64_t seed, uint64_t pair_id, uint32_t hyp, uint32_t n, uint
 void pgo_score_model(const float E[9], const float* x1, const float* y1, const float* x2,
                      const float* y2, uint32_t n, double thr, uint32_t* score,
                      uint32_t* n_inl);
+/* pre-verification on the first min(64,n) rows against a best with n_bar inliers (1 = keep) */
+int pgo_preverify(const float E[9], const float* x1, const float* y1, const float* x2,
+                  const float* y2, uint32_t n, double thr, uint32_t n_bar);
 /* mask[i] = sampson^2 < tau2 (tau2 arbitrary; f32 arithmetic) */
 uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, const float* x2,
                         const float* y2, uint32_t n, float tau2, uint8_t* mask);

@@ -16,6 +16,9 @@
 #include <stdint.h>
 
 #define PGI_DEV __device__ __forceinline__
+// coarse phases are real calls: register allocation (and spilling) is per phase, and only the
+// caller's few live values are saved around a call instead of inside the hot loops
+#define PGI_PHASE __device__ __noinline__
 
 namespace pgi {
 
@@ -183,10 +186,21 @@ PGI_DEV void sel3(bool c, const double a[3], double r[3]) {
     r[1] = c ? a[1] : r[1];
     r[2] = c ? a[2] : r[2];
 }
-PGI_DEV double grid_point(int j) {
-    const double u = (double)(2 * j - kGrid) / (double)(kGrid + 1);
-    return u / (1.0 - u * u);
+// root-bracketing grid z_j = u/(1-u^2), u uniform in (-1,1): evaluated by the compiler in IEEE
+// double (identical to the run-time expression) and kept in constant memory instead of LDS
+struct GridTab {
+    double v[kGrid + 1];
+};
+constexpr GridTab make_grid() {
+    GridTab g{};
+    for (int j = 0; j <= kGrid; ++j) {
+        const double u = (double)(2 * j - kGrid) / (double)(kGrid + 1);
+        g.v[j] = u / (1.0 - u * u);
+    }
+    return g;
 }
+__device__ constexpr GridTab kGridTab = make_grid();
+// (grid lookups go through kGridTab)
 PGI_DEV double horner10(const double p[11], double x) {
     double v = p[10];
 #pragma unroll
@@ -247,16 +261,28 @@ __constant__ uint16_t kQT[9][3] = {
 __constant__ uint8_t kLAM[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
 __constant__ uint8_t kMN[3][2] = {{1, 2}, {0, 2}, {0, 1}};
 
-// ---- per-group LDS scratch (doubles) ------------------------------------------------
-constexpr int G_BASIS = 0;   // [4][9]  X,Y,Z,W
-constexpr int G_REGA = 36;   // 100: quads[9][10] -> red[6][10] -> T[3][11] | poly[11] | rpoly[11] | brk
-constexpr int G_BROW = 136;  // [3][13]: bx[4] by[4] bc[5]
-constexpr int G_DOUBLES = 176;
-constexpr int A_T = 0, A_POLY = 33, A_RPOLY = 44, A_BRK = 56;  // offsets inside G_REGA
+// ---- per-wavefront LDS scratch (doubles): [basis x4 | B(z) rows x4 | region A x4] ---------------
+// group g of the wavefront uses basis[g], brow[g], rega[g].  Region A is reused in sequence:
+// quads Q0..Q5 -> reduced rows (6x10) -> T[3][11] | poly[11] | rpoly[11] | brackets; the three
+// minors Q6..Q8 sit in the (not yet used) B(z) area.  After the solve the model queue of the
+// wavefront (40 x 9 floats) overlays the four region-A blocks.
+constexpr int G_BASIS_SZ = 36, G_BROW_SZ = 39, G_REGA_SZ = 66;
+constexpr int W_BASIS = 0, W_BROW = 4 * G_BASIS_SZ, W_REGA = W_BROW + 4 * G_BROW_SZ;
+constexpr int W_DOUBLES = W_REGA + 4 * G_REGA_SZ;  // 564 doubles = 4512 B per wavefront
+constexpr int A_T = 0, A_POLY = 33, A_RPOLY = 44, A_BRK = 56;  // offsets inside region A
+struct GroupScratch {
+    double* basis;  // [4][9]  X,Y,Z,W
+    double* brow;   // [3][13]: bx[4] by[4] bc[5]   (minors Q6..Q8 during constraint building)
+    double* rega;   // 66
+};
+PGI_DEV GroupScratch group_scratch(double* wave_base, int g) {
+    return GroupScratch{wave_base + W_BASIS + g * G_BASIS_SZ, wave_base + W_BROW + g * G_BROW_SZ,
+                        wave_base + W_REGA + g * G_REGA_SZ};
+}
 
 // Five epipolar rows -> orthonormal 4-vector null-space basis in gs[G_BASIS].
 // Row r of the 5x9 system lives in sub-lane r.
-PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, double* gs) {
+PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, const GroupScratch gs) {
     double a[9];
     {
         const double x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
@@ -288,17 +314,17 @@ PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, double* gs) {
     // v_f[k] = -a[prow[k]][5+f]; v_f[5+g] = delta_fg
     if (mycol >= 0) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) gs[G_BASIS + 9 * f + mycol] = -a[5 + f];
+        for (int f = 0; f < 4; ++f) gs.basis[9 * f + mycol] = -a[5 + f];
     }
     if (s < 4) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gs[G_BASIS + 9 * s + 5 + g] = (g == s) ? 1.0 : 0.0;
+        for (int g = 0; g < 4; ++g) gs.basis[9 * s + 5 + g] = (g == s) ? 1.0 : 0.0;
     }
     wave_sync();
     // modified Gram-Schmidt, element i in sub-lane i, tree dot products
     double v[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) v[f] = (s < 9) ? gs[G_BASIS + 9 * f + s] : 0.0;
+    for (int f = 0; f < 4; ++f) v[f] = (s < 9) ? gs.basis[9 * f + s] : 0.0;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -313,7 +339,7 @@ PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, double* gs) {
     wave_sync();
     if (s < 9) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) gs[G_BASIS + 9 * f + s] = v[f];
+        for (int f = 0; f < 4; ++f) gs.basis[9 * f + s] = v[f];
     }
     wave_sync();
 }
@@ -331,9 +357,10 @@ struct BackendDbg {
 // -> 3x3 polynomial matrix B(z) -> degree-10 determinant -> bracketed real roots ->
 // E per root.  Returns true in sub-lanes that hold a valid model E32 (sub-lane =
 // root index).  smp: the five sample points (orientation test) or nullptr.
-template <bool DBG, int PB = 3>
-PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, const float4* smp,
-                           float E32[9], const BackendDbg* dbg, Prof& prof) {
+// `sample(i)` returns sample row i (0..4) for the orientation test; CHECK = false skips the test.
+template <bool DBG, int PB, bool CHECK, class SAMPLE>
+PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sample, float E32[9],
+                           const BackendDbg* dbg, Prof& prof) {
     // ---- phase 1: nine quadratic forms, one per sub-lane ------------------------------
     if (s < 9) {
         double q[10];
@@ -347,9 +374,9 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
                 double A[4], B[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const double av = gs[G_BASIS + 9 * b + eA];
+                    const double av = gs.basis[9 * b + eA];
                     A[b] = (sg == 1) ? av : -av;
-                    B[b] = gs[G_BASIS + 9 * b + eB];
+                    B[b] = gs.basis[9 * b + eB];
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
@@ -357,17 +384,18 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
                     for (int b = 0; b < 4; ++b) q[kQI[a][b]] = fma(A[a], B[b], q[kQI[a][b]]);
             }
         }
+        double* qdst = (s < 6) ? gs.rega + 10 * s : gs.brow + 10 * (s - 6);
 #pragma unroll
-        for (int c = 0; c < 10; ++c) gs[G_REGA + 10 * s + c] = q[c];
+        for (int c = 0; c < 10; ++c) qdst[c] = q[c];
     }
     wave_sync();
     // Lambda_ii = (E E^T)_ii - tr/2, coefficient c in sub-lane c
     if (s < 10) {
-        const double q0 = gs[G_REGA + 0 + s], q3 = gs[G_REGA + 30 + s], q5 = gs[G_REGA + 50 + s];
+        const double q0 = gs.rega[0 + s], q3 = gs.rega[30 + s], q5 = gs.rega[50 + s];
         const double tr = (q0 + q3) + q5;
-        gs[G_REGA + 0 + s] = q0 - 0.5 * tr;
-        gs[G_REGA + 30 + s] = q3 - 0.5 * tr;
-        gs[G_REGA + 50 + s] = q5 - 0.5 * tr;
+        gs.rega[0 + s] = q0 - 0.5 * tr;
+        gs.rega[30 + s] = q3 - 0.5 * tr;
+        gs.rega[50 + s] = q5 - 0.5 * tr;
     }
     wave_sync();
     // ---- phase 2: ten cubic constraint rows, one per sub-lane ----------------------------
@@ -378,18 +406,18 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
         const int i = (s > 0) ? (s - 1) / 3 : 0, j = (s > 0) ? (s - 1) % 3 : 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int qi = (s == 0) ? 6 + k : kLAM[i][k];
+            const double* qsrc = (s == 0) ? gs.brow + 10 * k : gs.rega + 10 * kLAM[i][k];
             const int ei = (s == 0) ? k : 3 * k + j;
             const bool neg = (s == 0) && (k == 1);
             double L[4];
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
-                const double lv = gs[G_BASIS + 9 * l + ei];
+                const double lv = gs.basis[9 * l + ei];
                 L[l] = neg ? -lv : lv;
             }
 #pragma unroll
             for (int q = 0; q < 10; ++q) {
-                const double qv = gs[G_REGA + 10 * qi + q];
+                const double qv = qsrc[q];
 #pragma unroll
                 for (int l = 0; l < 4; ++l) row[kCI[q][l]] = fma(qv, L[l], row[kCI[q][l]]);
             }
@@ -426,7 +454,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     wave_sync();  // quads are dead: region A is reused for the reduced rows
     if (mycol >= 4) {
 #pragma unroll
-        for (int m = 0; m < 10; ++m) gs[G_REGA + 10 * (mycol - 4) + m] = row[10 + m];
+        for (int m = 0; m < 10; ++m) gs.rega[10 * (mycol - 4) + m] = row[10 + m];
     }
     if constexpr (DBG) {
         if (mycol >= 0)
@@ -435,9 +463,9 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     wave_sync();
     // ---- B(z): rows (e,f) = (x2z,x2), (y2z,y2), (xyz,xy) -> e - z f ----------------------------
     if (s < 3) {
-        const double* e = gs + G_REGA + 20 * s;
+        const double* e = gs.rega + 20 * s;
         const double* f = e + 10;
-        double* b = gs + G_BROW + 13 * s;
+        double* b = gs.brow + 13 * s;
         b[0] = e[2]; b[1] = e[1] - f[2]; b[2] = e[0] - f[1]; b[3] = -f[0];
         b[4] = e[5]; b[5] = e[4] - f[5]; b[6] = e[3] - f[4]; b[7] = -f[3];
         b[8] = e[9]; b[9] = e[8] - f[9]; b[10] = e[7] - f[8]; b[11] = e[6] - f[7]; b[12] = -f[6];
@@ -445,9 +473,9 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     wave_sync();
     // ---- det B(z) = sum_i (+,-,+) bc_i * (bx_r by_q - by_r bx_q) ------------------------------
     if (s < 3) {
-        const double* br = gs + G_BROW + 13 * kMN[s][0];
-        const double* bq = gs + G_BROW + 13 * kMN[s][1];
-        const double* bc = gs + G_BROW + 13 * s + 8;
+        const double* br = gs.brow + 13 * kMN[s][0];
+        const double* bq = gs.brow + 13 * kMN[s][1];
+        const double* bc = gs.brow + 13 * s + 8;
         double bxr[4], byr[4], bxq[4], byq[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -474,13 +502,13 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
             for (int b = 0; b < 7; ++b) T[a + b] = fma(bca, m[b], T[a + b]);
         }
 #pragma unroll
-        for (int c = 0; c < 11; ++c) gs[G_REGA + A_T + 11 * s + c] = T[c];  // red is dead (consumed above)
+        for (int c = 0; c < 11; ++c) gs.rega[A_T + 11 * s + c] = T[c];  // red is dead (consumed above)
     }
     wave_sync();
     if (s < 11) {
-        const double p = (gs[G_REGA + A_T + s] - gs[G_REGA + A_T + 11 + s]) + gs[G_REGA + A_T + 22 + s];
-        gs[G_REGA + A_POLY + s] = p;
-        gs[G_REGA + A_RPOLY + (10 - s)] = p;
+        const double p = (gs.rega[A_T + s] - gs.rega[A_T + 11 + s]) + gs.rega[A_T + 22 + s];
+        gs.rega[A_POLY + s] = p;
+        gs.rega[A_RPOLY + (10 - s)] = p;
         if constexpr (DBG) dbg->poly[s] = p;
     }
     wave_sync();
@@ -488,13 +516,13 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     // ---- bracket sign changes on the grid: sub-lane s owns intervals [16s, 16s+16) ---------------
     double p[11];
 #pragma unroll
-    for (int c = 0; c < 11; ++c) p[c] = gs[G_REGA + A_POLY + c];
+    for (int c = 0; c < 11; ++c) p[c] = gs.rega[A_POLY + c];
     uint32_t chg = 0, sgn = 0;
     {
-        bool sp = horner10(p, grid[16 * s]) < 0.0;
+        bool sp = horner10(p, kGridTab.v[16 * s]) < 0.0;
         sgn = sp ? 1u : 0u;
         for (int b = 0; b < 16; ++b) {
-            const bool sc = horner10(p, grid[16 * s + b + 1]) < 0.0;
+            const bool sc = horner10(p, kGridTab.v[16 * s + b + 1]) < 0.0;
             chg |= (sc != sp) ? (1u << b) : 0u;
             sgn |= sc ? (2u << b) : 0u;
             sp = sc;
@@ -504,7 +532,7 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
     const int incl = row_scan_incl_i(cnt);
     const int total = __shfl(incl, gbase + 15);
     int slot = incl - cnt;
-    int* brk = reinterpret_cast<int*>(gs + G_REGA + A_BRK);
+    int* brk = reinterpret_cast<int*>(gs.rega + A_BRK);
     while (chg) {
         const int b = __ffs(chg) - 1;
         chg &= chg - 1;
@@ -523,23 +551,22 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
         const int w = brk[s];
         const int j = w & 0xFFFF;
         const bool sprev = (w >> 16) & 1;
-        const double gprev = grid[j], g = grid[j + 1];
-        double z;
-        if (gprev >= 1.0 || g <= -1.0) {  // |z| > 1: solve for 1/z on the reversed polynomial
-            double rp[11];
+        const double gprev = kGridTab.v[j], g = kGridTab.v[j + 1];
+        // |z| > 1: solve for 1/z on the reversed polynomial (one coefficient array live either way)
+        const bool tail = (gprev >= 1.0) || (g <= -1.0);
+        const double* psrc = gs.rega + (tail ? A_RPOLY : A_POLY);
+        double q[11];
 #pragma unroll
-            for (int c = 0; c < 11; ++c) rp[c] = gs[G_REGA + A_RPOLY + c];
-            const double wv = refine_root(rp, 1.0 / g, 1.0 / gprev, !sprev);
-            z = 1.0 / wv;
-        } else {
-            z = refine_root(p, gprev, g, sprev);
-        }
+        for (int c = 0; c < 11; ++c) q[c] = psrc[c];
+        const double lo0 = tail ? 1.0 / g : gprev, hi0 = tail ? 1.0 / gprev : g;
+        const double rt = refine_root(q, lo0, hi0, tail ? !sprev : sprev);
+        const double z = tail ? 1.0 / rt : rt;
         if constexpr (DBG) dbg->roots[s] = z;
         prof.mark<PB + 4>();
         double rw[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double* b = gs + G_BROW + 13 * i;
+            const double* b = gs.brow + 13 * i;
             rw[i][0] = fma(fma(fma(b[3], z, b[2]), z, b[1]), z, b[0]);
             rw[i][1] = fma(fma(fma(b[7], z, b[6]), z, b[5]), z, b[4]);
             rw[i][2] = fma(fma(fma(fma(b[12], z, b[11]), z, b[10]), z, b[9]), z, b[8]);
@@ -559,14 +586,14 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
         double E[9], n2 = 0.0;
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
-            E[m] = fma(x, gs[G_BASIS + m], fma(y, gs[G_BASIS + 9 + m], fma(z, gs[G_BASIS + 18 + m], gs[G_BASIS + 27 + m])));
+            E[m] = fma(x, gs.basis[m], fma(y, gs.basis[9 + m], fma(z, gs.basis[18 + m], gs.basis[27 + m])));
             n2 = fma(E[m], E[m], n2);
         }
         valid = (n2 > 0.0) && (n2 < 1.0e300);
         const double inv = 1.0 / sqrt(n2);
 #pragma unroll
         for (int m = 0; m < 9; ++m) E[m] = E[m] * inv;
-        if (valid && smp) {  // oriented epipolar constraint on the minimal sample
+        if (CHECK && valid) {  // oriented epipolar constraint on the minimal sample
             const double c0[3] = {E[0], E[3], E[6]}, c1[3] = {E[1], E[4], E[7]}, c2[3] = {E[2], E[5], E[8]};
             double e01[3], e02[3], e12[3], ep[3];
             cross3(c0, c1, e01);
@@ -585,7 +612,8 @@ PGI_DEV bool backend_group(double* gs, const double* grid, int s, int gbase, con
             int npos = 0, nneg = 0;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const double x1 = smp[i].x, y1 = smp[i].y, x2 = smp[i].z, y2 = smp[i].w;
+                const float4 sp = sample(i);
+                const double x1 = sp.x, y1 = sp.y, x2 = sp.z, y2 = sp.w;
                 const double l0 = fma(E[0], x1, fma(E[1], y1, E[2]));
                 const double l1 = fma(E[3], x1, fma(E[4], y1, E[5]));
                 const double l2 = fma(E[6], x1, fma(E[7], y1, E[8]));

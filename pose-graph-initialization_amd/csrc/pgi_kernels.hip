@@ -28,7 +28,6 @@ namespace pgi {
 constexpr int NW = 4;          // wavefronts per workgroup
 constexpr int NT = NW * 64;    // threads per workgroup
 constexpr int QCAP = 40;       // models per wavefront pass (4 hypotheses x 10 roots)
-constexpr int GRID_PAD = 264;  // 257 grid points padded
 constexpr double QMAGIC = 393216.0;  // 1.5 * 2^18: summands rounded to multiples of 2^-34
 
 struct WgShared {
@@ -44,6 +43,7 @@ struct WgShared {
     uint32_t q_count[NW];
     uint32_t q_hyp[NW][QCAP];
     uint32_t pass_ctr;
+    uint32_t nbar;  // pre-verification bar of the next round (best's inliers after merge, before LO)
     uint32_t mask_cnt;
     double Rt[21];  // R1[9] R2[9] t[3]
 };
@@ -103,7 +103,11 @@ PGI_DEV float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlan
 template <bool LDS_PTS>
 PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float* queue,
                          const uint32_t* qhyp, int m_begin, int m_end, float thr2, int lane,
-                         int floor_score, int& b_score, uint32_t& b_ninl, uint32_t& b_hyp, int& b_idx) {
+                         int floor_score, uint32_t n_bar, int& b_score, uint32_t& b_ninl, uint32_t& b_hyp,
+                         int& b_idx) {
+    // pre-verification: rows within 1.5*thr among the first 64 must reach a quarter of what a model as
+    // good as the bar (n_bar inliers) is expected to show
+    const uint32_t k_min = n_bar ? (uint32_t)((16ull * n_bar) / n) : 0u;
     for (int m0 = m_begin; m0 < m_end; m0 += 4) {
         float e[4][9];
 #pragma unroll
@@ -114,9 +118,11 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
         }
         const int bar = __builtin_amdgcn_readfirstlane(max(floor_score, b_score));  // wave-uniform
         uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
+        uint32_t alive = 0xFu;
         bool dead = false;
         for (uint32_t base = 0; base < npad; base += 64) {
             const float4 p = rows.get(base + lane);
+            uint32_t c3v[4];
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
                 float r2, den;
@@ -128,10 +134,16 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
                 const uint32_t c3 = __popcll(__ballot(r2 < 2.25f * t));
                 sc[mm] += (c0 + c1) + (c2 + c3);
                 ni[mm] += c2;
+                c3v[mm] = c3;
+            }
+            if (base == 0) {
+                alive = (c3v[0] >= k_min ? 1u : 0u) | (c3v[1] >= k_min ? 2u : 0u) | (c3v[2] >= k_min ? 4u : 0u) |
+                        (c3v[3] >= k_min ? 8u : 0u);
             }
             const uint32_t seen = min(n, base + 64u);
-            const uint32_t smax = max(max(sc[0], sc[1]), max(sc[2], sc[3]));
-            if ((int)(smax + 4u * (n - seen)) <= bar) {
+            const uint32_t smax = max(max((alive & 1u) ? sc[0] : 0u, (alive & 2u) ? sc[1] : 0u),
+                                      max((alive & 4u) ? sc[2] : 0u, (alive & 8u) ? sc[3] : 0u));
+            if (!alive || (int)(smax + 4u * (n - seen)) <= bar) {
                 dead = true;
                 break;
             }
@@ -139,7 +151,7 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
         if (dead) continue;
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
-            if (m0 + mm < m_end && (int)sc[mm] > max(floor_score, b_score)) {
+            if (m0 + mm < m_end && ((alive >> mm) & 1u) && (int)sc[mm] > max(floor_score, b_score)) {
                 b_score = (int)sc[mm];
                 b_ninl = ni[mm];
                 b_hyp = qhyp ? qhyp[m0 + mm] : 0u;
@@ -168,40 +180,47 @@ template <bool LDS_PTS>
 PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                   double* loA, double* partial, WgShared* sh, int tid) {
     const int lane = tid & 63, w = tid >> 6;
-    double S[45];
-#pragma unroll
-    for (int i = 0; i < 45; ++i) S[i] = 0.0;
     uint32_t cnt = 0;
-    for (uint32_t base = 0; base < npad; base += NT) {
-        const uint32_t i = base + tid;
-        const float nanv = __builtin_nanf("");
-        const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
-        float r2, den;
-        sampson_terms(E, p.x, p.y, p.z, p.w, r2, den);
-        const bool in = r2 < tau2 * den;
-        cnt += __popcll(__ballot(in));
-        if (in) {
-            const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
-            double a[9];
-            a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
-            a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
-            a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+    // three sweeps of 15 accumulators each (rows 0-1, 2-4, 5-8 of the upper triangle) keep the
+    // register footprint at 30 VGPRs instead of 90; the Sampson test is recomputed per sweep.
 #pragma unroll
-            for (int ii = 0; ii < 9; ++ii)
+    for (int blk = 0; blk < 3; ++blk) {
+        constexpr int kLo[3] = {0, 17, 35}, kRow0[3] = {0, 2, 5}, kRow1[3] = {2, 5, 9};
+        double S[18];
 #pragma unroll
-                for (int jj = ii; jj < 9; ++jj) {
-                    constexpr int kTri[9] = {0, 9, 17, 24, 30, 35, 39, 42, 44};
-                    const int k = kTri[ii] + (jj - ii);
-                    double t = a[ii] * a[jj];
-                    t = (t + QMAGIC) - QMAGIC;
-                    S[k] = S[k] + t;
-                }
+        for (int i = 0; i < 18; ++i) S[i] = 0.0;
+        for (uint32_t base = 0; base < npad; base += NT) {
+            const uint32_t i = base + tid;
+            const float nanv = __builtin_nanf("");
+            const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
+            float r2, den;
+            sampson_terms(E, p.x, p.y, p.z, p.w, r2, den);
+            const bool in = r2 < tau2 * den;
+            if (blk == 0) cnt += __popcll(__ballot(in));
+            if (in) {
+                const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
+                double a[9];
+                a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
+                a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
+                a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+                constexpr int kTri[9] = {0, 9, 17, 24, 30, 35, 39, 42, 44};
+#pragma unroll
+                for (int ii = kRow0[blk]; ii < kRow1[blk]; ++ii)
+#pragma unroll
+                    for (int jj = ii; jj < 9; ++jj) {
+                        const int k = kTri[ii] + (jj - ii) - kLo[blk];
+                        double t = a[ii] * a[jj];
+                        t = (t + QMAGIC) - QMAGIC;
+                        S[k] = S[k] + t;
+                    }
+            }
         }
-    }
+        constexpr int kCnt[3] = {17, 18, 10};
 #pragma unroll
-    for (int i = 0; i < 45; ++i) {
-        const double v = wave_sum_exact(S[i]);
-        if (lane == 0) partial[45 * w + i] = v;
+        for (int i = 0; i < kCnt[blk]; ++i) {
+            const double v = wave_sum_exact(S[i]);
+            if (lane == 0) partial[45 * w + kLo[blk] + i] = v;
+        }
     }
     if (lane == 0) sh->wave_cnt[w] = cnt;
     __syncthreads();
@@ -229,7 +248,7 @@ PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, cons
 // Tournament-ordered cyclic Jacobi on the 9x9 matrix in LDS (one wavefront, 36 lanes:
 // pair m = lane / 9, index l = lane % 9), then the 4 smallest eigenvectors -> basis of
 // every group of this wavefront (W = smallest, then Z, Y, X).
-PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
+PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
     for (int i = lane; i < 81; i += 64) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
     wave_sync();
     const int m = lane / 9, l = lane - 9 * m;
@@ -277,7 +296,6 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) d[i] = A[10 * i];
     uint32_t taken = 0;
-    const int g = lane >> 4, s16 = lane & 15;
 #pragma unroll
     for (int rank = 0; rank < 4; ++rank) {
         int bi = -1;
@@ -291,7 +309,7 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
             }
         }
         taken |= 1u << bi;
-        if (s16 < 9) gscr[g * G_DOUBLES + G_BASIS + 9 * (3 - rank) + s16] = V[9 * s16 + bi];
+        if (lane < 9) basis0[9 * (3 - rank) + lane] = V[9 * lane + bi];
     }
     wave_sync();
 }
@@ -302,10 +320,16 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* gscr, int lane) {
 // `spare()` -- the caller uses it to start on the next round's hypotheses.
 template <bool LDS_PTS, class SPARE>
 PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
-                                 float thr2, double* loA, double* loV, double* partial, double* wscr,
-                                 const double* grid, float* queue0, WgShared* sh, int tid, int floor_score,
+                                 float thr2, double* wscr0, WgShared* sh, int tid, int floor_score,
+                                 uint32_t n_bar,
                                  int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, SPARE spare) {
     const int lane = tid & 63, w = tid >> 6;
+    // LO arrays alias wave 0's solver scratch (dead here): partial sums over basis/brow of groups
+    // 1..3, A and V over region A of groups 1..3; the refit queue is wave 0's queue (region A).
+    double* partial = wscr0 + G_BASIS_SZ;             // NW*45 doubles in [36, 216)
+    double* loA = wscr0 + W_REGA + G_REGA_SZ;         // 81
+    double* loV = loA + 81;                           // 81 (ends at W_REGA + 228 <= W_DOUBLES)
+    float* queue0 = reinterpret_cast<float*>(wscr0 + W_REGA);
     prof.mark<11>();
     const uint32_t ni = normal_matrix_wg<LDS_PTS>(rows, npad, E, tau2, loA, partial, sh, tid);
     prof.mark<12>();
@@ -313,11 +337,13 @@ PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const
     r_ninl = 0;
     if (ni < 5) return ni;  // uniform
     if (w == 0) {
-        jacobi9_wave(loA, loV, wscr, lane);
+        jacobi9_wave(loA, loV, wscr0 + W_BASIS, lane);
         prof.mark<13>();
         float E32[9];
-        const int g = lane >> 4, s = lane & 15;
-        const bool valid = backend_group<false, 14>(wscr + g * G_DOUBLES, grid, s, g * 16, nullptr, E32, nullptr, prof);
+        const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
+        const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
+                                                            [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
+        wave_sync();
         const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
         if (lane == 0) sh->q_count[0] = (uint32_t)cnt;
     } else {
@@ -330,8 +356,8 @@ PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const
     uint32_t b_ninl = 0, b_hyp = 0;
     const int mb = 4 * w, me = min(count, 4 * w + 4);
     if (mb < me)
-        score_queue<LDS_PTS>(rows, rows.n, npad, queue0, nullptr, mb, me, thr2, lane, floor_score, b_score, b_ninl, b_hyp,
-                             b_idx);
+        score_queue<LDS_PTS>(rows, rows.n, npad, queue0, nullptr, mb, me, thr2, lane, floor_score, n_bar, b_score, b_ninl,
+                             b_hyp, b_idx);
     if (lane == 0) {
         sh->cand_score[w] = b_score;
         sh->cand_ninl[w] = b_ninl;
@@ -357,7 +383,7 @@ PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const
 }
 
 template <bool LDS_PTS>
-__global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
+__global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t pair = blockIdx.x;
@@ -366,15 +392,10 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
     const uint32_t npad = (n + 63u) & ~63u;
 
     float4* pts = reinterpret_cast<float4*>(smem);
-    double* grid = reinterpret_cast<double*>(smem + (size_t)a.pts_cap * 16);
-    double* wscr_all = grid + GRID_PAD;                   // NW * 4 * G_DOUBLES
-    double* loA = wscr_all + NW * 4 * G_DOUBLES;          // 81
-    double* loV = loA + 81;                               // 81
-    double* partial = loV + 81;                           // NW * 45
-    float* queue_all = reinterpret_cast<float*>(partial + NW * 45 + 1);  // NW * QCAP * 9
-    WgShared* sh = reinterpret_cast<WgShared*>(queue_all + NW * QCAP * 9);
-    double* wscr = wscr_all + w * 4 * G_DOUBLES;
-    float* queue = queue_all + w * QCAP * 9;
+    double* wscr_all = reinterpret_cast<double*>(smem + (size_t)a.pts_cap * 16);  // NW * W_DOUBLES
+    WgShared* sh = reinterpret_cast<WgShared*>(wscr_all + NW * W_DOUBLES);
+    double* wscr = wscr_all + w * W_DOUBLES;
+    float* queue = reinterpret_cast<float*>(wscr + W_REGA);  // overlays region A after each solve
 
     Rows<LDS_PTS> rows;
     rows.lds = pts;
@@ -393,13 +414,13 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
             pts[i] = (i < n) ? make_float4(rows.x1[i], rows.y1[i], rows.x2[i], rows.y2[i])
                              : make_float4(nanv, nanv, nanv, nanv);
     }
-    for (int j = tid; j <= kGrid; j += NT) grid[j] = grid_point(j);
     if (tid == 0) {
         sh->best_score = -1;
         sh->best_ninl = 0;
         sh->votes[0] = sh->votes[1] = sh->votes[2] = sh->votes[3] = 0;
         sh->mask_cnt = 0;
         sh->pass_ctr = 0;
+        sh->nbar = 0;
     }
     __syncthreads();
     prof.mark<0>();
@@ -453,8 +474,8 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         int r_score;
         uint32_t r_ninl;
         float rE[9];
-        const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, loA, loV, partial, wscr_all, grid,
-                                                     queue_all, sh, tid, -1, r_score, r_ninl, rE, prof, [] {});
+        const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, wscr_all, sh, tid, -1, 0u, r_score,
+                                                     r_ninl, rE, prof, [] {});
         if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
             success = true;
             have_model = true;
@@ -483,40 +504,36 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         const int g = lane >> 4, s = lane & 15;
         const uint32_t n_pass = (rs + 3u) / 4u;
         // best of the round this wavefront is working on (first maximum in hypothesis order)
-        int wb_score = -1;
+        int wb_score = -1;  // its model is parked in sh->candE[w] (LDS), not in registers
         uint32_t wb_ninl = 0, wb_hyp = 0;
-        float wbE[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) wbE[c] = 0.f;
         // one pass = four hypotheses (one per 16-lane group): sample, solve, score
-        auto do_pass = [&](uint32_t pass, uint32_t base_hyp, int floor_score) {
+        auto do_pass = [&](uint32_t pass, uint32_t base_hyp, int floor_score, uint32_t n_bar) {
             const uint32_t local = pass * 4 + g;
             const bool active = local < rs;
             const uint32_t hyp = base_hyp + (active ? local : 0u);
             uint32_t idx[5];
             sample5(rng_base, hyp, n, idx);
-            float4 smp[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) smp[k] = rows.get(idx[k]);
-            float4 mine = smp[0];
+            uint32_t my = idx[0];
 #pragma unroll
             for (int k = 1; k < 5; ++k)
-                if (s == k) mine = smp[k];
+                if (s == k) my = idx[k];
+            const float4 mine = rows.get(my);
             prof.mark<1>();
-            nullspace5_group(mine, s, g * 16, wscr + g * G_DOUBLES);
+            const GroupScratch gs = group_scratch(wscr, g);
+            nullspace5_group(mine, s, g * 16, gs);
             prof.mark<2>();
             float E32[9];
-            const bool valid = backend_group<false, 3>(wscr + g * G_DOUBLES, grid, s, g * 16, smp, E32, nullptr, prof);
+            // the five sample rows are re-read from LDS for the orientation test (not kept in registers)
+            const bool valid = backend_group<false, 3, true>(
+                gs, s, g * 16, [&](int i) { return rows.get(idx[i]); }, E32, nullptr, prof);
+            wave_sync();  // every group is done with region A: the queue may overlay it
             const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
             wave_sync();
             prof.mark<9>();
             int bidx = -1;
-            score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, wb_score, wb_ninl,
-                                 wb_hyp, bidx);
-            if (bidx >= 0) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) wbE[c] = queue[9 * bidx + c];
-            }
+            score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, n_bar, wb_score,
+                                 wb_ninl, wb_hyp, bidx);
+            if (bidx >= 0 && lane < 9) sh->candE[w][lane] = queue[9 * bidx + lane];
             wave_sync();
             prof.mark<10>();
         };
@@ -529,18 +546,17 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
         while (hyps < budget) {
             {
                 const int floor_score = sh->best_score;
+                const uint32_t n_bar = sh->nbar;
                 for (;;) {
                     const uint32_t pass = pull_pass();
                     if (pass >= n_pass) break;
-                    do_pass(pass, hyps, floor_score);
+                    do_pass(pass, hyps, floor_score, n_bar);
                 }
             }
             if (lane == 0) {
                 sh->cand_score[w] = wb_score;
                 sh->cand_ninl[w] = wb_ninl;
                 sh->cand_hyp[w] = wb_hyp;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) sh->candE[w][c] = wbE[c];
             }
             wb_score = -1;  // from here on the wavefront state belongs to the NEXT round
             __syncthreads();
@@ -560,12 +576,16 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                 }
             }
             const bool improve = (rb >= 0) && (rb > sh->best_score);
-            if (tid == 0) sh->pass_ctr = 0;
+            if (tid == 0) {
+                sh->pass_ctr = 0;
+                if (!improve) sh->nbar = sh->best_score >= 0 ? sh->best_ninl : 0u;
+            }
             __syncthreads();
             if (improve) {
                 if (tid == 0) {
                     sh->best_score = rb;
                     sh->best_ninl = sh->cand_ninl[rbw];
+                    sh->nbar = sh->cand_ninl[rbw];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) sh->bestE[c] = sh->candE[rbw][c];
                 }
@@ -574,6 +594,7 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                 // the current best, so the wavefronts idle during the serial Jacobi already work on
                 // the next round (discarded if this refit ends the search): same results, less waiting.
                 const bool more = hyps < budget;
+                const uint32_t spec_nbar = sh->nbar;
                 for (uint32_t it = 0; it < prm.lo_iters; ++it) {
                     float bE[9];
 #pragma unroll
@@ -583,11 +604,11 @@ __global__ __launch_bounds__(NT) void estimate_pose_kernel(const K1Args a) {
                     uint32_t r_ninl;
                     float rE[9];
                     const uint32_t ni = refit_and_score<LDS_PTS>(
-                        rows, npad, bE, thr2, thr2, loA, loV, partial, wscr_all, grid, queue_all, sh, tid, cur_best,
-                        r_score, r_ninl, rE, prof, [&] {
+                        rows, npad, bE, thr2, thr2, wscr_all, sh, tid, cur_best, sh->best_ninl, r_score, r_ninl, rE, prof,
+                        [&] {
                             if (!more) return;
                             const uint32_t pass = pull_pass();
-                            if (pass < n_pass) do_pass(pass, hyps, cur_best);
+                            if (pass < n_pass) do_pass(pass, hyps, cur_best, spec_nbar);
                         });
                     if (ni < 5) break;
                     ++out_lo;
@@ -773,6 +794,7 @@ __global__ __launch_bounds__(256) void score_pose_kernel(const float* __restrict
     const float4* vy1 = reinterpret_cast<const float4*>(py1 + head);
     const float4* vx2 = reinterpret_cast<const float4*>(px2 + head);
     const float4* vy2 = reinterpret_cast<const float4*>(py2 + head);
+#pragma clang loop unroll(disable)
     for (uint32_t i = lane; i < nv; i += 64) {
         const float4 a = vx1[i], b = vy1[i], c = vx2[i], d = vy2[i];
         float r2, den;
@@ -907,11 +929,8 @@ __global__ __launch_bounds__(256) void decompose_kernel(const float* __restrict_
 __global__ __launch_bounds__(64) void five_point_kernel(const float* __restrict__ pts, uint32_t n_samples,
                                                         float* __restrict__ models, uint32_t* __restrict__ counts,
                                                         double* __restrict__ dbgout) {
-    __shared__ double grid[GRID_PAD];
-    __shared__ double scr[4 * G_DOUBLES];
+    __shared__ double scr[W_DOUBLES];
     const int lane = threadIdx.x, g = lane >> 4, s = lane & 15;
-    for (int j = lane; j <= kGrid; j += 64) grid[j] = grid_point(j);
-    __syncthreads();
     const uint32_t smp_i = min(blockIdx.x * 4 + g, n_samples - 1);
     const bool active = blockIdx.x * 4 + g < n_samples;
     float4 smp[5];
@@ -922,21 +941,21 @@ __global__ __launch_bounds__(64) void five_point_kernel(const float* __restrict_
     float4 mine = smp[0];
     for (int k = 1; k < 5; ++k)
         if (s == k) mine = smp[k];
-    double* gs = scr + g * G_DOUBLES;
+    const GroupScratch gs = group_scratch(scr, g);
     nullspace5_group(mine, s, g * 16, gs);
     float E32[9];
     bool valid;
     if (dbgout) {
         double* d = dbgout + (size_t)smp_i * PGI_DBG_DOUBLES;
         if (active && s < 9)
-            for (int f = 0; f < 4; ++f) d[9 * f + s] = gs[G_BASIS + 9 * f + s];
+            for (int f = 0; f < 4; ++f) d[9 * f + s] = gs.basis[9 * f + s];
         BackendDbg dbg{d + 36, d + 236, d + 336, d + 347, d + 357};
         if (active && s < 10) d[347 + s] = 0.0;
         Prof prof;
-        valid = backend_group<true>(gs, grid, s, g * 16, smp, E32, &dbg, prof);
+        valid = backend_group<true, 3, true>(gs, s, g * 16, [&](int i) { return smp[i]; }, E32, &dbg, prof);
     } else {
         Prof prof;
-        valid = backend_group<false>(gs, grid, s, g * 16, smp, E32, nullptr, prof);
+        valid = backend_group<false, 3, true>(gs, s, g * 16, [&](int i) { return smp[i]; }, E32, nullptr, prof);
     }
     // compact the valid roots of each group in root order
     const uint64_t bal = __ballot(valid);
@@ -961,10 +980,7 @@ std::string& last_error_ref() {
 }
 }  // namespace pgi
 
-static size_t k1_fixed_lds() {
-    return (size_t)GRID_PAD * 8 + (size_t)NW * 4 * G_DOUBLES * 8 + (81 + 81 + NW * 45 + 1) * 8 +
-           (size_t)NW * QCAP * 9 * 4 + sizeof(WgShared) + 64;
-}
+static size_t k1_fixed_lds() { return (size_t)NW * W_DOUBLES * 8 + sizeof(WgShared) + 64; }
 
 extern "C" {
 
