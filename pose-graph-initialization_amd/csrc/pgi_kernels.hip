@@ -154,7 +154,7 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
             if (m0 + mm < m_end && ((alive >> mm) & 1u) && (int)sc[mm] > max(floor_score, b_score)) {
                 b_score = (int)sc[mm];
                 b_ninl = ni[mm];
-                b_hyp = qhyp ? qhyp[m0 + mm] : 0u;
+                b_hyp = qhyp ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qhyp[m0 + mm]) : 0u;
                 b_idx = m0 + mm;
             }
         }
@@ -545,8 +545,9 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
         };
         while (hyps < budget) {
             {
-                const int floor_score = sh->best_score;
-                const uint32_t n_bar = sh->nbar;
+                // wave-uniform shared state goes to SGPRs (keeps VGPRs for the solver)
+                const int floor_score = __builtin_amdgcn_readfirstlane(sh->best_score);
+                const uint32_t n_bar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
                 for (;;) {
                     const uint32_t pass = pull_pass();
                     if (pass >= n_pass) break;
@@ -594,12 +595,12 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                 // the current best, so the wavefronts idle during the serial Jacobi already work on
                 // the next round (discarded if this refit ends the search): same results, less waiting.
                 const bool more = hyps < budget;
-                const uint32_t spec_nbar = sh->nbar;
+                const uint32_t spec_nbar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
                 for (uint32_t it = 0; it < prm.lo_iters; ++it) {
                     float bE[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
-                    const int cur_best = sh->best_score;
+                    const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
                     int r_score;
                     uint32_t r_ninl;
                     float rE[9];

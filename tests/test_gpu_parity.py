@@ -255,3 +255,31 @@ def test_full_size_properties(eng):
                                         7.5e-4, O.default_params(), 11, pair_id_base=20000)
     assert np.array_equal(m[:a], emasks)
     assert_edges_match(got[:h], exp)
+
+
+def test_python_builder_surface():
+    from pyposegraphbuilder import PoseGraphBuilder, findEssentialMatrix
+    b = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.5, 0.4, "img", "ws", "sim.txt", "focals.txt", True, True, True)
+    sizes = [300, 700, 40, 500]
+    batch = S.make_batch(range(8100, 8104), sizes)
+    pairs = []
+    for i, n in enumerate(sizes):
+        a, z = int(batch["offsets"][i]), int(batch["offsets"][i + 1])
+        pairs.append(dict(src=i, dst=i + 1, similarity=0.9 - 0.1 * i if i != 3 else 0.2, threshold=7.5e-4,
+                          correspondences=np.stack([batch[k][a:z] for k in ("x1", "y1", "x2", "y2")], 1)))
+    g = b.run(pairs)
+    assert set(g) == {(0, 1), (1, 2)}  # pair 2 has < kMinimumPointNumber matches, pair 3 is below the similarity threshold
+    for (s_, d_), e in g.items():
+        assert S.rot_err_deg(e["R"], batch["R"][s_]) < 1.0 and 0.3 < e["score"] < 0.7
+    ok, R, t, mask, n_inl = b.estimatePose(pairs[0]["correspondences"], 7.5e-4)
+    assert ok and n_inl == mask.sum() and S.rot_err_deg(R, batch["R"][0]) < 1.0
+    # historical binding shape: pixels + intrinsics in, (E, mask) out; bad shapes raise ValueError
+    K = np.array([[1000.0, 0, 640], [0, 1000.0, 480], [0, 0, 1]])
+    c = pairs[1]["correspondences"].astype(np.float64)
+    E, m = findEssentialMatrix(c[:, :2] * 1000 + [640, 480], c[:, 2:] * 1000 + [640, 480], K, K, threshold=0.75)
+    assert E is not None and m.dtype == bool and m.sum() > 300
+    Egt = np.cross(np.eye(3), batch["t"][1]) @ batch["R"][1]
+    Egt /= np.linalg.norm(Egt)
+    assert min(np.linalg.norm(E - Egt), np.linalg.norm(E + Egt)) < 2e-2
+    with pytest.raises(ValueError):
+        findEssentialMatrix(np.zeros((5, 3)), np.zeros((5, 3)), K, K)
