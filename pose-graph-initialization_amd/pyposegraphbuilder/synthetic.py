@@ -106,3 +106,83 @@ def auc_at(errors_deg, limit=5.0):
         return 0.0
     # recall(theta) steps by 1/n at each error; integral = sum (limit - e_i) / n
     return float(np.sum(limit - e) / (n * limit))
+
+
+# ---- scene-graph surrogates for BASELINE configs 3/4 (1DSfM data is not available on either box) -----------
+def make_pair_from_pose(pair_id, n, R, t, inlier_ratio=0.5, noise_px=0.25, seed_base=SEED_BASE):
+    """Like make_pair but for a GIVEN relative pose (x_dst ~ R x_src + t, |t| = 1)."""
+    rng = np.random.Generator(np.random.Philox(key=seed_base ^ 0x5CE7E ^ (int(pair_id) << 8)))
+    n_in = int(round(n * inlier_ratio))
+    p1 = np.zeros((0, 2))
+    p2 = np.zeros((0, 2))
+    tries = 0
+    lim = 0.5
+    while len(p1) < n_in:
+        m = 4 * max(n_in, 16)
+        z = rng.uniform(2.0, 8.0, m)
+        X = np.stack([rng.uniform(-0.45, 0.45, m) * z, rng.uniform(-0.45, 0.45, m) * z, z], 1)
+        Y = X @ R.T + t
+        ok = Y[:, 2] > 0.5
+        q = Y[:, :2] / np.where(ok, Y[:, 2], 1.0)[:, None]
+        ok &= (np.abs(q) < lim).all(1)
+        p1 = np.concatenate([p1, (X[:, :2] / X[:, 2:3])[ok]])
+        p2 = np.concatenate([p2, q[ok]])
+        tries += 1
+        if tries % 8 == 0:
+            lim *= 1.5  # barely overlapping views: widen the destination field of view
+    p1, p2 = p1[:n_in], p2[:n_in]
+    n_out = n - n_in
+    c = np.concatenate([np.concatenate([p1, p2], 1),
+                        np.concatenate([rng.uniform(-0.45, 0.45, (n_out, 2)), rng.uniform(-0.5, 0.5, (n_out, 2))], 1)])
+    c += rng.standard_normal(c.shape) * (noise_px / FOCAL_PX)
+    inl = np.zeros(n, bool)
+    inl[:n_in] = True
+    perm = rng.permutation(n)
+    c, inl = c[perm].astype(np.float32), inl[perm]
+    return dict(x1=c[:, 0].copy(), y1=c[:, 1].copy(), x2=c[:, 2].copy(), y2=c[:, 3].copy(), inlier=inl)
+
+
+def make_scene_graph(n_views, k=8, seed=0, median_corr=600, min_corr=60, max_corr=4000, inlier_lo=0.35,
+                     inlier_hi=0.8, outlier_pair_frac=0.05):
+    """Cameras on a jittered ring looking at the scene centre; candidate pairs = k nearest views.
+
+    Returns dict(R_gt[V,3,3] world->camera, pairs=(src,dst)[E,2], sizes[E], batch=<make_batch-like SoA>,
+    wrong[E] bool (pairs whose correspondences are all outliers: a wrongly retrieved image pair))."""
+    rng = np.random.Generator(np.random.Philox(key=SEED_BASE ^ 0xC0DE ^ seed))
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n_views))
+    radius = rng.uniform(9.0, 11.0, n_views)
+    C = np.stack([radius * np.cos(ang), rng.uniform(-0.5, 0.5, n_views), radius * np.sin(ang)], 1)  # centres
+    R_gt = np.empty((n_views, 3, 3))
+    for i in range(n_views):
+        zc = -C[i] / np.linalg.norm(C[i])
+        zc = rodrigues(rng.standard_normal(3), np.deg2rad(rng.uniform(0, 6.0))) @ zc  # pointing jitter
+        xc = np.cross([0.0, 1.0, 0.0], zc)
+        xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R_gt[i] = np.stack([xc, yc, zc])  # rows = camera axes in world: x_cam = R (X - C)
+    pairs = set()
+    for i in range(n_views):
+        d = np.abs(np.angle(np.exp(1j * (ang - ang[i]))))
+        for j in np.argsort(d)[1:k + 1]:
+            pairs.add((min(i, int(j)), max(i, int(j))))
+    pairs = np.array(sorted(pairs), np.int64)
+    E = len(pairs)
+    sizes = np.clip(rng.lognormal(np.log(median_corr), 0.6, E), min_corr, max_corr).astype(np.int64)
+    wrong = rng.random(E) < outlier_pair_frac
+    off = np.zeros(E + 1, np.uint64)
+    off[1:] = np.cumsum(sizes)
+    tot = int(off[-1])
+    b = dict(x1=np.empty(tot, np.float32), y1=np.empty(tot, np.float32), x2=np.empty(tot, np.float32),
+             y2=np.empty(tot, np.float32), inlier=np.empty(tot, bool), offsets=off,
+             R=np.empty((E, 3, 3)), t=np.empty((E, 3)))
+    for e, (i, j) in enumerate(pairs):
+        Rij = R_gt[j] @ R_gt[i].T
+        tij = R_gt[j] @ (C[i] - C[j])
+        tij /= np.linalg.norm(tij)
+        rho = 0.0 if wrong[e] else rng.uniform(inlier_lo, inlier_hi)
+        d = make_pair_from_pose(seed * 1000003 + e, int(sizes[e]), Rij, tij, inlier_ratio=rho)
+        a, z = int(off[e]), int(off[e + 1])
+        for key in ("x1", "y1", "x2", "y2", "inlier"):
+            b[key][a:z] = d[key]
+        b["R"][e], b["t"][e] = Rij, tij
+    return dict(R_gt=R_gt, pairs=pairs, sizes=sizes, batch=b, wrong=wrong)
