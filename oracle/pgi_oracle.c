@@ -130,14 +130,28 @@ uint64_t pgo_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-/* five distinct indices; counter-based, independent of execution order */
+/* murmur3 finaliser: the per-draw hash (32-bit multiplies only) */
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+uint32_t pgo_draw_index(uint64_t base, uint32_t hyp, uint32_t k, uint32_t n) {
+    const uint32_t lo = (uint32_t)base, hi = (uint32_t)(base >> 32);
+    const uint32_t h = fmix32((lo ^ (hyp * 0x9E3779B1u)) + (hi ^ (k * 0x85EBCA77u)));
+    return (uint32_t)(((uint64_t)h * (uint64_t)n) >> 32);
+}
+/* five distinct indices; counter-based, independent of execution order: draws k = 0,1,2,... are
+ * accepted in order unless they repeat an accepted index */
 void pgo_sample5(uint64_t seed, uint64_t pair_id, uint32_t hyp, uint32_t n, uint32_t idx[5]) {
     const uint64_t base = pgo_mix64(seed ^ pgo_mix64(pair_id));
     uint32_t k = 0, got = 0;
     while (got < 5) {
-        const uint64_t u = pgo_mix64(base ^ (((uint64_t)hyp << 16) | k));
+        const uint32_t j = pgo_draw_index(base, hyp, k, n);
         ++k;
-        const uint32_t j = (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
         int dup = 0;
         for (uint32_t q = 0; q < got; ++q) dup |= (idx[q] == j);
         if (!dup || k >= 64) idx[got++] = j; /* k>=64: give up on distinctness */
@@ -229,11 +243,12 @@ static void gauss_jordan(double* a, int R, int C, int P, int* prow) {
         prow[k] = p;
         const double inv = 1.0 / a[p * C + k];
         for (int j = k + 1; j < C; ++j) a[p * C + j] = a[p * C + j] * inv;
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r) { /* the pivot row runs the same update with factor 0 (lane-uniform code) */
+            const double f = (r == p) ? 0.0 : a[r * C + k];
             if (r == p) continue;
-            const double f = a[r * C + k];
             for (int j = k + 1; j < C; ++j) a[r * C + j] = fma(-f, a[p * C + j], a[r * C + j]);
         }
+        for (int j = k + 1; j < C; ++j) a[p * C + j] = fma(-0.0, a[p * C + j], a[p * C + j]);
     }
 }
 

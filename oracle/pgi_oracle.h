@@ -103,6 +103,7 @@ void pgo_ref_normalize_corr(const float* kp_src_xy, const float* kp_dst_xy,
 
 /* ---- engine spec pieces (bit-exact targets for the HIP kernels) -------- */
 uint64_t pgo_mix64(uint64_t z);
+uint32_t pgo_draw_index(uint64_t base, uint32_t hyp, uint32_t k, uint32_t n);
 void pgo_sample5(uint64_t seed, uint64_t pair_id, uint32_t hyp, uint32_t n, uint32_t idx[5]);
 
 /* multi-level Sampson score of one f32 model over f32 SoA points */

@@ -115,9 +115,18 @@ PGI_DEV uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+PGI_DEV uint32_t fmix32(uint32_t h) {  // murmur3 finaliser: 32-bit multiplies only
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
 PGI_DEV uint32_t draw_index(uint64_t base, uint32_t hyp, uint32_t k, uint32_t n) {
-    const uint64_t u = mix64(base ^ (((uint64_t)hyp << 16) | k));
-    return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
+    const uint32_t lo = (uint32_t)base, hi = (uint32_t)(base >> 32);
+    const uint32_t h = fmix32((lo ^ (hyp * 0x9E3779B1u)) + (hi ^ (k * 0x85EBCA77u)));
+    return __umulhi(h, n);
 }
 // Five distinct row indices: draws k = 0,1,2,... are accepted in order unless they repeat an
 // earlier accepted index.  The first eight draws are hashed up front (independent chains).
@@ -303,12 +312,12 @@ PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, const GroupScra
             mycol = k;
         }
         const double inv = 1.0 / a[k];
-        const double f = a[k];
+        const double f = is_p ? 0.0 : a[k];  // the pivot row runs the same update with factor 0
 #pragma unroll
         for (int j = k + 1; j < 9; ++j) {
             const double v = is_p ? a[j] * inv : a[j];
             const double pj = __shfl(v, pl);
-            a[j] = is_p ? v : fma(-f, pj, v);
+            a[j] = fma(-f, pj, v);
         }
     }
     // v_f[k] = -a[prow[k]][5+f]; v_f[5+g] = delta_fg
@@ -442,12 +451,12 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
             mycol = k;
         }
         const double inv = 1.0 / row[k];
-        const double f = row[k];
+        const double f = is_p ? 0.0 : row[k];  // the pivot row runs the same update with factor 0
 #pragma unroll
         for (int j = k + 1; j < 20; ++j) {
             const double v = is_p ? row[j] * inv : row[j];
             const double pj = __shfl(v, pl);
-            row[j] = is_p ? v : fma(-f, pj, v);
+            row[j] = fma(-f, pj, v);
         }
     }
     prof.mark<PB + 1>();
@@ -519,14 +528,24 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
     for (int c = 0; c < 11; ++c) p[c] = gs.rega[A_POLY + c];
     uint32_t chg = 0, sgn = 0;
     {
-        bool sp = horner10(p, kGridTab.v[16 * s]) < 0.0;
-        sgn = sp ? 1u : 0u;
-        for (int b = 0; b < 16; ++b) {
-            const bool sc = horner10(p, kGridTab.v[16 * s + b + 1]) < 0.0;
-            chg |= (sc != sp) ? (1u << b) : 0u;
-            sgn |= sc ? (2u << b) : 0u;
-            sp = sc;
+        sgn = horner10(p, kGridTab.v[16 * s]) < 0.0 ? 1u : 0u;
+        for (int b = 0; b < 16; b += 4) {  // four independent Horner chains per step (latency)
+            double v0 = p[10], v1 = p[10], v2 = p[10], v3 = p[10];
+            const double g0 = kGridTab.v[16 * s + b + 1], g1 = kGridTab.v[16 * s + b + 2],
+                         g2 = kGridTab.v[16 * s + b + 3], g3 = kGridTab.v[16 * s + b + 4];
+#pragma unroll
+            for (int c = 9; c >= 0; --c) {
+                v0 = fma(v0, g0, p[c]);
+                v1 = fma(v1, g1, p[c]);
+                v2 = fma(v2, g2, p[c]);
+                v3 = fma(v3, g3, p[c]);
+            }
+            sgn |= (v0 < 0.0 ? 2u : 0u) << b;
+            sgn |= (v1 < 0.0 ? 4u : 0u) << b;
+            sgn |= (v2 < 0.0 ? 8u : 0u) << b;
+            sgn |= (v3 < 0.0 ? 16u : 0u) << b;
         }
+        chg = (sgn ^ (sgn >> 1)) & 0xFFFFu;  // bit b: sign change across interval 16 s + b
     }
     const int cnt = __popc(chg);
     const int incl = row_scan_incl_i(cnt);
