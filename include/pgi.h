@@ -39,6 +39,7 @@ typedef enum {
 #define PGI_EDGE_FEW_INLIERS 0     /* false (pose_graph_builder.h:1053-1054)             */
 #define PGI_EDGE_NAN (-1)          /* false (pose_graph_builder.h:1069-1070)             */
 #define PGI_EDGE_FEW_POINTS (-2)   /* fewer than 5 rows                                  */
+#define PGI_EDGE_TOO_MANY_ROWS (-3) /* the pair has more rows than pgi_batch.max_corr promised */
 
 typedef struct pgi_ctx pgi_ctx;
 

@@ -407,6 +407,14 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     Prof prof;
     prof.start();
 
+    if (LDS_PTS && npad > a.pts_cap) {  // the caller's max_corr was too small: never overrun the LDS staging area
+        for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
+        if (tid == 0) {
+            edge_clear(edge);
+            edge->status = PGI_EDGE_TOO_MANY_ROWS;
+        }
+        return;
+    }
     // ---- stage the pair: coalesced SoA reads from HBM -> float4 rows in LDS ----
     if constexpr (LDS_PTS) {
         const float nanv = __builtin_nanf("");

@@ -283,3 +283,40 @@ def test_python_builder_surface():
     assert min(np.linalg.norm(E - Egt), np.linalg.norm(E + Egt)) < 2e-2
     with pytest.raises(ValueError):
         findEssentialMatrix(np.zeros((5, 3)), np.zeros((5, 3)), K, K)
+
+
+@pytest.mark.parametrize("kw", [dict(lo_iters=0), dict(lo_iters=1), dict(lo_iters=3), dict(round_size=16), dict(round_size=64),
+                                dict(round_size=20), dict(confidence=0.999), dict(max_iters=100), dict(min_inliers=200),
+                                dict(vote_all_rows=1), dict(guess_quirk=0), dict(fixed_budget=40, lo_iters=1)])
+def test_parameter_variants_match_oracle(eng, kw):
+    sizes = [300, 1000, 64, 2000, 150, 700, 450, 90]
+    b = S.make_batch(range(12000, 12000 + len(sizes)), sizes, inlier_ratio=0.45)
+    guesses = np.zeros((len(sizes), 12))
+    has = np.zeros(len(sizes), np.uint8)
+    for i in (1, 4):  # two pairs carry an (exact) pose guess
+        guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
+        has[i] = 1
+    base = dict(lo_iters=2, round_size=32, confidence=0.99, max_iters=1000, min_inliers=20, vote_all_rows=0,
+                guess_quirk=1, fixed_budget=0)
+    eng.set_params(**{**base, **kw})
+    try:
+        db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has,
+                        seed=23, pair_id_base=12000)
+        edges, masks = eng.estimate_pose_batch(db)
+        got = eng.edges_to_numpy(edges)
+    finally:
+        eng.set_params(**base)
+    exp, emasks = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4,
+                                        O.default_params(**kw), 23, pair_id_base=12000, guesses=guesses, has_guess=has)
+    assert np.array_equal(masks.cpu().numpy(), emasks)
+    assert_edges_match(got, exp)
+
+
+def test_understated_max_corr_is_reported_not_overrun(eng):
+    b = S.make_batch([13000, 13001], [200, 900])
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=1)
+    db["max_corr"] = 256  # lie: the second pair has 900 rows
+    edges, masks = eng.estimate_pose_batch(db)
+    got = eng.edges_to_numpy(edges)
+    assert got["status"][0] == 1 and got["status"][1] == -3
+    assert masks.cpu().numpy()[200:].sum() == 0
