@@ -1,6 +1,6 @@
 // pose_graph_builder.cpp -- implementation of the C++ host layer (links against libpgi.so).
 // HIP is used here for device buffers and copies only; every computation is a C-ABI call.
-#include "pose_graph_builder.hpp"
+#include "graph_traversal.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -61,7 +61,7 @@ struct DeviceBatch {
 }  // namespace
 
 size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
-                                       std::vector<pgi_edge>* edges_out) {
+                                       std::vector<pgi_edge>* edges_out, bool screenGuesses) {
     const size_t P = pairs.size();
     if (!P) return 0;
     std::vector<uint64_t> off(P + 1, 0);
@@ -96,16 +96,38 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     h2d(dx1.p, x1.data(), rows * 4); h2d(dy1.p, y1.data(), rows * 4);
     h2d(dx2.p, x2.data(), rows * 4); h2d(dy2.p, y2.data(), rows * 4);
     h2d(doff.p, off.data(), (P + 1) * 8); h2d(dthr.p, thr.data(), P * 8);
-    if (any_guess) {
-        h2d(dguess.p, guess.data(), P * 96);
-        h2d(dhas.p, has.data(), P);
-    }
     pgi_batch b{};
     b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
     b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
     b.d_guess_Rt = any_guess ? dguess.as<double>() : nullptr;
     b.d_has_guess = any_guess ? dhas.as<uint8_t>() : nullptr;
     b.n_pairs = (uint32_t)P; b.max_corr = max_corr; b.pair_id_base = 0; b.seed = seed;
+    if (any_guess && screenGuesses) {
+        // InTraversalPoseTester::test for every chained pose of the wave in ONE launch:
+        // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
+        std::vector<double> Eg(9 * P, 0.0), tau2(P, 0.0);
+        for (size_t i = 0; i < P; ++i) {
+            if (!has[i]) { Eg[9 * i] = 1.0; continue; }
+            const Matrix3d E = pose::getEssentialMatrixFromRelativePose(pairs[i].poseGuesses.back());
+            for (int c = 0; c < 9; ++c) Eg[9 * i + c] = E[c];
+            tau2[i] = (1.5 * thr[i]) * (1.5 * thr[i]);
+        }
+        DevBuf dE(P * 72), dtau(P * 8), dcnt(P * 4);
+        h2d(dE.p, Eg.data(), P * 72);
+        h2d(dtau.p, tau2.data(), P * 8);
+        b.d_guess_Rt = nullptr; b.d_has_guess = nullptr;
+        Engine::check(pgi_score_pose_batch(engine->get(), &b, dE.as<double>(), dtau.as<double>(), dcnt.as<uint32_t>(), nullptr));
+        Engine::check(pgi_synchronize(engine->get()));
+        std::vector<uint32_t> cnt(P);
+        d2h(cnt.data(), dcnt.p, P * 4);
+        for (size_t i = 0; i < P; ++i)
+            if (has[i] && cnt[i] < 5) has[i] = 0;
+        b.d_guess_Rt = dguess.as<double>(); b.d_has_guess = dhas.as<uint8_t>();
+    }
+    if (any_guess) {
+        h2d(dguess.p, guess.data(), P * 96);
+        h2d(dhas.p, has.data(), P);
+    }
     Engine::check(pgi_estimate_pose_batch(engine->get(), &b, dedges.as<pgi_edge>(), dmasks.as<uint8_t>()));
     Engine::check(pgi_synchronize(engine->get()));
     std::vector<pgi_edge> edges(P);
@@ -124,28 +146,63 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     return added;
 }
 
-void PoseGraphBuilder::run(std::vector<ViewPair>& cand, PoseGraph& poseGraph_, size_t waveSize) {
+PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& cand, PoseGraph& poseGraph_, size_t waveSize,
+                                                      const SimilarityTable* similarityTable) {
+    RunStatistics st;
     // descending similarity, ties by (src,dst): the order the reference pops its heap
     std::stable_sort(cand.begin(), cand.end(), [](const ViewPair& a, const ViewPair& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
         return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);
     });
+    ViewId maxId = 0;
+    for (const ViewPair& vp : cand) maxId = std::max(maxId, std::max(vp.src, vp.dst));
+    VisibilityTable visibilityTable(maxId + 1);  // :366-367
+    for (const EdgeId& id : poseGraph_.getEdgeIds()) visibilityTable.addLink(id.first, id.second);
+    const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
     std::vector<ViewPair> wave;
     uint64_t seed = 0;
+    auto flush = [&]() {
+        if (wave.empty()) return;
+        if (pathFinding) {  // findPath (:785-862) on the graph committed by the previous waves
+            ImageSimilarityHeuristics heuristics(*similarityTable);
+            AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
+                                                                kMaximumSearchDepth);
+            for (ViewPair& vp : wave) {
+                vp.poseGuesses.clear();
+                if (!visibilityTable.hasLink(vp.src, vp.dst)) continue;  // kAreViewsVisible (:456-457, 568)
+                std::vector<ViewId> path;
+                size_t touched = 0, found = 0;
+                bool exists = false;
+                traversal.getPath(vp.src, vp.dst, path, vp.poseGuesses, touched, found, exists);
+                ++st.pathsSearched;
+                st.touchedNodes += touched;
+                st.pathsFound += found;
+            }
+        }
+        std::vector<pgi_edge> edges;
+        const size_t added = estimatePoses(wave, poseGraph_, seed++, &edges, /*screenGuesses*/ pathFinding);
+        for (size_t i = 0; i < wave.size(); ++i) {
+            st.hypotheses += edges[i].iters;
+            st.posesFromGuess += edges[i].used_guess;
+            if (edges[i].status == PGI_EDGE_OK) visibilityTable.addLink(wave[i].src, wave[i].dst);  // :692
+        }
+        st.edgesAdded += added;
+        st.pairsProcessed += wave.size();
+        ++st.waves;
+        wave.clear();
+    };
     for (size_t i = 0; i < cand.size(); ++i) {
         ViewPair& vp = cand[i];
         if (vp.similarity < kSimilarityThreshold) break;                       // heap holds sim >= threshold only
-        if (poseGraph_.hasEdge(vp.src, vp.dst)) continue;                      // pose_graph_builder.h:426-431
+        if (poseGraph_.hasEdge(vp.src, vp.dst) || poseGraph_.hasEdge(vp.dst, vp.src)) continue;   // :426-431
         if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
-        if (!poseGraph_.hasVertex(vp.src)) poseGraph_.addVertex(vp.src);
-        if (!poseGraph_.hasVertex(vp.dst)) poseGraph_.addVertex(vp.dst);
+        poseGraph_.addVertex(vp.src);
+        poseGraph_.addVertex(vp.dst);
         wave.push_back(std::move(vp));
-        if (wave.size() == waveSize) {
-            estimatePoses(wave, poseGraph_, seed++);
-            wave.clear();
-        }
+        if (wave.size() == waveSize) flush();
     }
-    if (!wave.empty()) estimatePoses(wave, poseGraph_, seed++);
+    flush();
+    return st;
 }
 
 namespace pose {

@@ -161,38 +161,61 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         std::shared_lock<std::shared_mutex> l(mu);
         return edges.size();
     }
-    void addVertex(ViewId id) {
+    bool addVertex(ViewId id) {
         std::unique_lock<std::shared_mutex> l(mu);
-        vertices.emplace(id, PoseGraphVertex(id));
+        return vertices.emplace(id, PoseGraphVertex(id)).second;
     }
     bool hasVertex(ViewId id) const {
         std::shared_lock<std::shared_mutex> l(mu);
         return vertices.count(id) != 0;
     }
+    PoseGraphVertex getVertexById(ViewId id) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        auto it = vertices.find(id);
+        return it == vertices.end() ? PoseGraphVertex() : it->second;
+    }
     bool hasEdge(ViewId s, ViewId d) const {
         std::shared_lock<std::shared_mutex> l(mu);
         return edges.count({s, d}) != 0;
     }
-    void addEdge(ViewId s, ViewId d, const Pose& T, double score = 1.0) {
+    // pose_graph.h:201-224: refused unless both vertices exist and the directed edge is new
+    bool addEdge(ViewId s, ViewId d, const Pose& T, double score = 1.0) {
         std::unique_lock<std::shared_mutex> l(mu);
+        if (!vertices.count(s) || !vertices.count(d) || edges.count({s, d})) return false;
         edges.emplace(EdgeId{s, d}, PoseGraphEdge(s, d, T, score));
+        edges_ids.push_back({s, d});
+        edges_of_vertices[s].push_back({s, d});
+        edges_of_vertices[d].push_back({s, d});
+        return true;
     }
     PoseGraphEdge getEdgeById(const EdgeId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
         auto it = edges.find(id);
         return it == edges.end() ? PoseGraphEdge() : it->second;
     }
-    std::vector<EdgeId> getEdgeIds() const {
+    std::vector<EdgeId> getEdgeIds() const {  // insertion order, like the reference's edges_ids
         std::shared_lock<std::shared_mutex> l(mu);
-        std::vector<EdgeId> ids;
-        for (auto& kv : edges) ids.push_back(kv.first);
-        return ids;
+        return edges_ids;
+    }
+    bool getEdgesByVertex(const ViewId& id, std::vector<EdgeId>& out) const {  // pose_graph.h:139-151
+        std::shared_lock<std::shared_mutex> l(mu);
+        auto it = edges_of_vertices.find(id);
+        if (it == edges_of_vertices.end()) return false;
+        out = it->second;
+        return true;
+    }
+    size_t getEdgeNumberByVertex(const ViewId& id) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        auto it = edges_of_vertices.find(id);
+        return it == edges_of_vertices.end() ? 0 : it->second.size();
     }
 
    protected:
     mutable std::shared_mutex mu;
     std::map<ViewId, PoseGraphVertex> vertices;
     std::map<EdgeId, PoseGraphEdge> edges;
+    std::vector<EdgeId> edges_ids;
+    std::map<ViewId, std::vector<EdgeId>> edges_of_vertices;
 };
 
 // ---- the engine handle shared by the classes below ---------------------------------------------------
@@ -345,15 +368,26 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     }
 
     // Batched form used by run(): every pair of a wave in one launch; edges with score =
-    // inliers / matches are added to the pose graph (pose_graph_builder.h:645-654).
+    // inliers / matches are added to the pose graph (pose_graph_builder.h:645-654).  A pair's LAST
+    // poseGuess (if any) is first screened like InTraversalPoseTester::test does inside the A* traversal
+    // (>= 5 rows with squared Sampson distance < (1.5 thr)^2; pose_graph_builder.h:798-811) -- all
+    // screens of the wave in one score launch -- and only accepted guesses reach estimatePose.
     size_t estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed = 0,
-                         std::vector<pgi_edge>* edges_out = nullptr);
+                         std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false);
+
+    struct RunStatistics {  // the reference's RunningStatistics keys that concern this path (utils.h:15-73)
+        size_t pairsProcessed = 0, edgesAdded = 0, pathsSearched = 0, pathsFound = 0, touchedNodes = 0,
+               posesFromGuess = 0, hypotheses = 0, waves = 0;
+    };
 
     // Wave-scheduled run over caller-provided candidate pairs (the image / feature / matching stages of
     // the reference's run() -- pose_graph_builder.h:173-239, 352-715 -- are outside this build's scope,
     // DESIGN.md §6): pairs above kSimilarityThreshold with at least kMinimumPointNumber matches, in
-    // descending similarity (imagesimilarity_graph.h max-heap order), are estimated in batches.
-    void run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096);
+    // descending similarity (imagesimilarity_graph.h max-heap order), are estimated in batches.  With
+    // kUsePathFinding and a similarity table, pairs already connected in the graph (VisibilityTable) get
+    // an A* pose guess computed on the graph committed by the previous waves (findPath, :785-862).
+    RunStatistics run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096,
+                      const class SimilarityTable* similarityTable = nullptr);
 
     Engine& getEngine() { return *engine; }
 

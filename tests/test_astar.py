@@ -1,0 +1,96 @@
+"""Host A* pose-guess search (host/graph_traversal.hpp) against the Python restatement (oracle/astar_oracle.py)."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import astar_oracle as AO  # noqa: E402
+
+EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_astar")
+
+
+def random_graph(V, E, seed):
+    rng = np.random.default_rng(seed)
+    Rg = Rotation.random(V, random_state=seed).as_matrix()
+    C = rng.standard_normal((V, 3))
+    sim = rng.uniform(0, 1, (V, V)).round(3)   # similarity files carry %1.3f values
+    sim = np.triu(sim, 1) + np.triu(sim, 1).T + np.eye(V)
+    edges = {}
+    while len(edges) < E:
+        a, b = rng.integers(0, V, 2)
+        if a == b or (a, b) in edges or (b, a) in edges:
+            continue
+        R = Rg[b] @ Rg[a].T
+        t = Rg[b] @ (C[a] - C[b])
+        edges[(int(a), int(b))] = (R, t / np.linalg.norm(t), round(float(rng.uniform(0.1, 0.9)), 2))
+    return sim, edges, Rg
+
+
+def run_cpp(V, sim, edges, queries, weight, depth, tmp):
+    fin, fout = os.path.join(tmp, "g.bin"), os.path.join(tmp, "o.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<IIIdI", V, len(edges), len(queries), weight, depth))
+        f.write(sim.astype("<f8").tobytes())
+        for (a, b), (R, t, s) in edges.items():
+            f.write(struct.pack("<II", a, b) + R.astype("<f8").tobytes() + t.astype("<f8").tobytes() + struct.pack("<d", s))
+        for a, b in queries:
+            f.write(struct.pack("<II", a, b))
+    subprocess.check_call([EXE, fin, fout])
+    buf = open(fout, "rb").read()
+    pos, out = 0, []
+    for _ in queries:
+        n, touched = struct.unpack_from("<II", buf, pos)
+        pos += 8
+        path = list(struct.unpack_from("<%dI" % n, buf, pos))
+        pos += 4 * n
+        pose = None
+        if n:
+            R = np.frombuffer(buf, "<f8", 9, pos).reshape(3, 3)
+            t = np.frombuffer(buf, "<f8", 3, pos + 72)
+            pos += 96
+            pose = (R, t)
+        out.append((path, pose, touched))
+    assert pos == len(buf)
+    return out
+
+
+def test_astar_matches_oracle(tmp_path):
+    total_found = 0
+    for seed, (V, E, depth, weight) in enumerate([(12, 18, 5, 0.8), (30, 60, 5, 0.8), (30, 60, 3, 0.2), (60, 90, 6, 0.5),
+                                                  (8, 5, 5, 0.8)]):
+        sim, edges, Rg = random_graph(V, E, seed)
+        g = AO.PoseGraph()
+        for v in range(V):
+            g.add_vertex(v)
+        for (a, b), (R, t, s) in edges.items():
+            g.add_edge(a, b, R, t, s)
+        rng = np.random.default_rng(100 + seed)
+        queries = [tuple(int(x) for x in rng.choice(V, 2, replace=False)) for _ in range(40)]
+        got = run_cpp(V, sim, edges, queries, weight, depth, str(tmp_path))
+        for (a, b), (path, pose, touched) in zip(queries, got):
+            epath, epose, etouched = AO.astar_get_path(g, lambda i, j: sim[i, j], a, b, weight, depth)
+            assert touched == etouched
+            if epath is None or epose is None:
+                assert path == []
+                continue
+            total_found += 1
+            assert path == epath and path[0] == a and path[-1] == b and len(path) - 1 <= depth + 1
+            np.testing.assert_allclose(pose[0], epose[0], atol=1e-13)
+            np.testing.assert_allclose(pose[1], epose[1], atol=1e-13)
+            # exact relative rotations chain to the ground-truth relative rotation
+            np.testing.assert_allclose(pose[0], Rg[b] @ Rg[a].T, atol=1e-10)
+    assert total_found > 80
+
+
+def test_union_find_visibility():
+    uf = AO.UnionFind(6)
+    uf.add_link(0, 1)
+    uf.add_link(3, 4)
+    assert uf.has_link(1, 0) and not uf.has_link(1, 3)
+    uf.add_link(1, 4)
+    assert uf.has_link(0, 3) and not uf.has_link(5, 0)
