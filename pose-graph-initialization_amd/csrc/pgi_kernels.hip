@@ -45,6 +45,9 @@ struct WgShared {
     uint32_t pass_ctr;
     uint32_t nbar;  // pre-verification bar of the next round (best's inliers after merge, before LO)
     uint32_t mask_cnt;
+    int lo_score;       // results of a refit run by wave 0 (guess path) / refit counter
+    uint32_t lo_ninl, lo_ni, lo_runs;
+    float loE[9];
     double Rt[21];  // R1[9] R2[9] t[3]
 };
 
@@ -174,18 +177,76 @@ PGI_DEV int enqueue_models(bool valid, const float E32[9], uint32_t hyp, float* 
     return __popcll(bal);
 }
 
-// Inlier set of model E at bound tau2 -> exact 9x9 normal matrix in loA (LDS) and the
-// inlier count.  Summands are pre-rounded to 2^-34 so every summation order agrees.
+// Inlier set of model E at bound tau2 -> exact 9x9 normal matrix in loA (LDS) and the inlier
+// count, by ONE wavefront (local optimisation runs on wave 0 while the others solve hypotheses).
+// Summands are pre-rounded to 2^-34 so every summation order agrees.  Three sweeps of <= 18
+// accumulators keep the register footprint small; tri (45 doubles) is scratch for the triangle.
+template <bool LDS_PTS>
+PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
+                                    double* loA, double* tri, int lane) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        constexpr int kLo[3] = {0, 17, 35}, kRow0[3] = {0, 2, 5}, kRow1[3] = {2, 5, 9}, kCnt[3] = {17, 18, 10};
+        double S[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) S[i] = 0.0;
+        for (uint32_t base = 0; base < npad; base += 64) {
+            const float4 p = rows.get(base + lane);
+            float r2, den;
+            sampson_terms(E, p.x, p.y, p.z, p.w, r2, den);
+            const bool in = r2 < tau2 * den;
+            if (blk == 0) cnt += __popcll(__ballot(in));
+            if (in) {
+                const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
+                double a[9];
+                a[0] = x2 * x1; a[1] = x2 * y1; a[2] = x2;
+                a[3] = y2 * x1; a[4] = y2 * y1; a[5] = y2;
+                a[6] = x1;      a[7] = y1;      a[8] = 1.0;
+                constexpr int kTri[9] = {0, 9, 17, 24, 30, 35, 39, 42, 44};
+#pragma unroll
+                for (int ii = kRow0[blk]; ii < kRow1[blk]; ++ii)
+#pragma unroll
+                    for (int jj = ii; jj < 9; ++jj) {
+                        const int k = kTri[ii] + (jj - ii) - kLo[blk];
+                        double t = a[ii] * a[jj];
+                        t = (t + QMAGIC) - QMAGIC;
+                        S[k] = S[k] + t;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kCnt[blk]; ++i) {
+            const double v = wave_sum_exact(S[i]);
+            if (lane == 0) tri[kLo[blk] + i] = v;
+        }
+    }
+    wave_sync();
+    if (lane < 45) {  // unrank lane -> (i,j), i <= j
+        int i = 0, rem = lane;
+        while (rem >= 9 - i) {
+            rem -= 9 - i;
+            ++i;
+        }
+        const int j = i + rem;
+        const double v = tri[lane];
+        loA[9 * i + j] = v;
+        loA[9 * j + i] = v;
+    }
+    wave_sync();
+    return cnt;
+}
+
+// Workgroup-cooperative variant (all NW wavefronts; two barriers): used for the FIRST refit after a
+// merge, where every wavefront is synchronised anyway.  partial: NW*45 doubles of dead scratch.
 template <bool LDS_PTS>
 PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                   double* loA, double* partial, WgShared* sh, int tid) {
     const int lane = tid & 63, w = tid >> 6;
     uint32_t cnt = 0;
-    // three sweeps of 15 accumulators each (rows 0-1, 2-4, 5-8 of the upper triangle) keep the
-    // register footprint at 30 VGPRs instead of 90; the Sampson test is recomputed per sweep.
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        constexpr int kLo[3] = {0, 17, 35}, kRow0[3] = {0, 2, 5}, kRow1[3] = {2, 5, 9};
+        constexpr int kLo[3] = {0, 17, 35}, kRow0[3] = {0, 2, 5}, kRow1[3] = {2, 5, 9}, kCnt[3] = {17, 18, 10};
         double S[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) S[i] = 0.0;
@@ -215,7 +276,6 @@ PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, cons
                     }
             }
         }
-        constexpr int kCnt[3] = {17, 18, 10};
 #pragma unroll
         for (int i = 0; i < kCnt[blk]; ++i) {
             const double v = wave_sum_exact(S[i]);
@@ -228,7 +288,6 @@ PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, cons
         double v = partial[tid];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) v = v + partial[45 * ww + tid];
-        // unrank tid -> (i,j), i <= j
         int i = 0, rem = tid;
         while (rem >= 9 - i) {
             rem -= 9 - i;
@@ -314,70 +373,44 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
     wave_sync();
 }
 
-// n-point refit of model E's inlier set (bound tau2) -> models in wave 0's queue, scored
-// by all wavefronts.  Returns the inlier count; outputs the best refit model.
-// While wave 0 runs the serial section (9x9 Jacobi + back-end) the other wavefronts call
-// `spare()` -- the caller uses it to start on the next round's hypotheses.
-template <bool LDS_PTS, class SPARE>
-PGI_DEV uint32_t refit_and_score(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
-                                 float thr2, double* wscr0, WgShared* sh, int tid, int floor_score,
-                                 uint32_t n_bar,
-                                 int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, SPARE spare) {
-    const int lane = tid & 63, w = tid >> 6;
-    // LO arrays alias wave 0's solver scratch (dead here): partial sums over basis/brow of groups
-    // 1..3, A and V over region A of groups 1..3; the refit queue is wave 0's queue (region A).
-    double* partial = wscr0 + G_BASIS_SZ;             // NW*45 doubles in [36, 216)
-    double* loA = wscr0 + W_REGA + G_REGA_SZ;         // 81
-    double* loV = loA + 81;                           // 81 (ends at W_REGA + 228 <= W_DOUBLES)
+// n-point refit of model E's inlier set (bound tau2), executed by ONE wavefront (wave 0) without any
+// workgroup barrier: normal matrix -> 9x9 Jacobi -> Nister back-end -> score the <= 10 roots.
+// Outputs the inlier count and the best refit model that beats `floor_score` (r_score = -1: none).
+// LDS: A, V and the triangle scratch alias wave 0's unused solver groups; the queue is wave 0's.
+template <bool LDS_PTS>
+PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
+                             float thr2, double* wscr0, WgShared* sh, int lane, int floor_score, uint32_t n_bar,
+                             int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, int ni_pre = -1) {
+    double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
+    double* loV = loA + 81;                    // 81 (ends at W_REGA + 228 <= W_DOUBLES)
+    double* tri = wscr0 + G_BASIS_SZ;          // 45 doubles over basis of groups 1..2
     float* queue0 = reinterpret_cast<float*>(wscr0 + W_REGA);
-    prof.mark<11>();
-    const uint32_t ni = normal_matrix_wg<LDS_PTS>(rows, npad, E, tau2, loA, partial, sh, tid);
-    prof.mark<12>();
     r_score = -1;
     r_ninl = 0;
-    if (ni < 5) return ni;  // uniform
-    if (w == 0) {
-        jacobi9_wave(loA, loV, wscr0 + W_BASIS, lane);
-        prof.mark<13>();
-        float E32[9];
-        const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
-        const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
-                                                            [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
-        wave_sync();
-        const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
-        if (lane == 0) sh->q_count[0] = (uint32_t)cnt;
-    } else {
-        spare();
-    }
-    __syncthreads();
+    prof.mark<11>();
+    const uint32_t ni = ni_pre >= 0 ? (uint32_t)ni_pre  // the workgroup already built A (first refit after a merge)
+                                    : normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane);
+    prof.mark<12>();
+    if (ni < 5) return ni;  // wave-uniform
+    jacobi9_wave(loA, loV, wscr0 + W_BASIS, lane);
+    prof.mark<13>();
+    float E32[9];
+    const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
+    const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
+                                                        [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
+    wave_sync();
+    const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
+    wave_sync();
     prof.mark<20>();
-    const int count = (int)sh->q_count[0];
-    int b_score = -1, b_idx = -1;
-    uint32_t b_ninl = 0, b_hyp = 0;
-    const int mb = 4 * w, me = min(count, 4 * w + 4);
-    if (mb < me)
-        score_queue<LDS_PTS>(rows, rows.n, npad, queue0, nullptr, mb, me, thr2, lane, floor_score, n_bar, b_score, b_ninl,
-                             b_hyp, b_idx);
-    if (lane == 0) {
-        sh->cand_score[w] = b_score;
-        sh->cand_ninl[w] = b_ninl;
-        sh->cand_hyp[w] = (uint32_t)b_idx;
-    }
-    __syncthreads();
-    int bw = -1;
+    int b_idx = -1;
+    uint32_t b_hyp = 0;
+    score_queue<LDS_PTS>(rows, n, npad, queue0, nullptr, 0, cnt, thr2, lane, floor_score, n_bar, r_score, r_ninl, b_hyp,
+                         b_idx);
+    if (b_idx >= 0) {
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww)
-        if (sh->cand_score[ww] > r_score) {
-            r_score = sh->cand_score[ww];
-            bw = ww;
-        }
-    if (bw >= 0) {
-        r_ninl = sh->cand_ninl[bw];
-        const int idx = (int)sh->cand_hyp[bw];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) rE[c] = queue0[9 * idx + c];
+        for (int c = 0; c < 9; ++c) rE[c] = queue0[9 * b_idx + c];
     }
-    __syncthreads();
+    wave_sync();
     prof.mark<21>();
     return ni;
 }
@@ -429,6 +462,7 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
         sh->mask_cnt = 0;
         sh->pass_ctr = 0;
         sh->nbar = 0;
+        sh->lo_runs = 0;
     }
     __syncthreads();
     prof.mark<0>();
@@ -479,11 +513,25 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
         for (int m = 0; m < 9; ++m) Ef[m] = (float)(Eg[m] * inv);
         const double trunc = 1.5 * thr;
         const float tau2 = prm.guess_quirk ? (float)trunc : (float)(trunc * trunc);
-        int r_score;
-        uint32_t r_ninl;
+        if (w == 0) {  // all-inlier refit of the guess (:1013-1020) on wave 0; the others wait
+            int rs0;
+            uint32_t rn0;
+            float rE0[9];
+            const uint32_t ni0 = refit_wave0<LDS_PTS>(rows, n, npad, Ef, tau2, thr2, wscr_all, sh, lane, -1, 0u, rs0, rn0, rE0, prof);
+            if (lane == 0) {
+                sh->lo_ni = ni0;
+                sh->lo_score = rs0;
+                sh->lo_ninl = rn0;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sh->loE[c] = rE0[c];
+            }
+        }
+        __syncthreads();
+        const uint32_t ni = sh->lo_ni;
+        const int r_score = sh->lo_score;
         float rE[9];
-        const uint32_t ni = refit_and_score<LDS_PTS>(rows, npad, Ef, tau2, thr2, wscr_all, sh, tid, -1, 0u, r_score,
-                                                     r_ninl, rE, prof, [] {});
+#pragma unroll
+        for (int c = 0; c < 9; ++c) rE[c] = sh->loE[c];
         if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
             success = true;
             have_model = true;
@@ -551,25 +599,38 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
             if (lane == 0) pass = atomicAdd(&sh->pass_ctr, 1u);
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);
         };
+        // Local optimisation runs on wave 0 ALONE while the other wavefronts already solve the next round:
+        // hypotheses never depend on the current best, so the result equals the sequential order
+        // (merge -> LO -> termination test -> next round); the termination test of an improving round
+        // is simply evaluated one barrier later, and the speculative round is dropped if it fires.
+        int floor_score = -1;   // best score after the last merge (pre-LO): exact bail-out bar
+        uint32_t n_bar = 0;     // pre-verification bar of the round in flight (spec: post-merge, pre-LO)
+        bool deferred = false;  // an LO may be running on wave 0; its termination test is pending
+        auto terminated = [&](uint32_t at_hyps) {
+            if (prm.fixed_budget || sh->best_score < 0 || sh->best_ninl < 5) return false;
+            const double rho = (double)sh->best_ninl / (double)n;
+            const double r5 = ((rho * rho) * (rho * rho)) * rho;
+            const double q = 1.0 - r5;
+            return pow_uint(q, at_hyps) <= 1.0 - prm.confidence;
+        };
         while (hyps < budget) {
-            {
-                // wave-uniform shared state goes to SGPRs (keeps VGPRs for the solver)
-                const int floor_score = __builtin_amdgcn_readfirstlane(sh->best_score);
-                const uint32_t n_bar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
-                for (;;) {
-                    const uint32_t pass = pull_pass();
-                    if (pass >= n_pass) break;
-                    do_pass(pass, hyps, floor_score, n_bar);
-                }
+            for (;;) {
+                const uint32_t pass = pull_pass();
+                if (pass >= n_pass) break;
+                do_pass(pass, hyps, floor_score, n_bar);
             }
             if (lane == 0) {
                 sh->cand_score[w] = wb_score;
                 sh->cand_ninl[w] = wb_ninl;
                 sh->cand_hyp[w] = wb_hyp;
             }
-            wb_score = -1;  // from here on the wavefront state belongs to the NEXT round
-            __syncthreads();
+            wb_score = -1;
+            __syncthreads();  // A: the round's passes are done, and so is a concurrent LO on wave 0
             prof.mark<22>();
+            if (deferred) {  // termination test of the previous (improving) round with its post-LO best
+                deferred = false;
+                if (terminated(hyps)) break;  // the round just computed is discarded (hyps not advanced)
+            }
             hyps += rs;
             // round best: score desc, hypothesis index asc
             int rb = -1, rbw = -1;
@@ -585,61 +646,62 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                 }
             }
             const bool improve = (rb >= 0) && (rb > sh->best_score);
+            __syncthreads();  // B: everyone has read the candidates and the best
             if (tid == 0) {
                 sh->pass_ctr = 0;
-                if (!improve) sh->nbar = sh->best_score >= 0 ? sh->best_ninl : 0u;
-            }
-            __syncthreads();
-            if (improve) {
-                if (tid == 0) {
+                if (improve) {
                     sh->best_score = rb;
                     sh->best_ninl = sh->cand_ninl[rbw];
                     sh->nbar = sh->cand_ninl[rbw];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) sh->bestE[c] = sh->candE[rbw][c];
-                }
-                __syncthreads();
-                // local optimisation: n-point refits while they improve.  Hypotheses never depend on
-                // the current best, so the wavefronts idle during the serial Jacobi already work on
-                // the next round (discarded if this refit ends the search): same results, less waiting.
-                const bool more = hyps < budget;
-                const uint32_t spec_nbar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
-                for (uint32_t it = 0; it < prm.lo_iters; ++it) {
-                    float bE[9];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
-                    const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
-                    int r_score;
-                    uint32_t r_ninl;
-                    float rE[9];
-                    const uint32_t ni = refit_and_score<LDS_PTS>(
-                        rows, npad, bE, thr2, thr2, wscr_all, sh, tid, cur_best, sh->best_ninl, r_score, r_ninl, rE, prof,
-                        [&] {
-                            if (!more) return;
-                            const uint32_t pass = pull_pass();
-                            if (pass < n_pass) do_pass(pass, hyps, cur_best, spec_nbar);
-                        });
-                    if (ni < 5) break;
-                    ++out_lo;
-                    const bool better = r_score > sh->best_score;
-                    __syncthreads();
-                    if (!better) break;
-                    if (tid == 0) {
-                        sh->best_score = r_score;
-                        sh->best_ninl = r_ninl;
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
-                    }
-                    __syncthreads();
+                } else {
+                    sh->nbar = sh->best_score >= 0 ? sh->best_ninl : 0u;
                 }
             }
-            if (!prm.fixed_budget && sh->best_score >= 0 && sh->best_ninl >= 5) {
-                const double rho = (double)sh->best_ninl / (double)n;
-                const double r5 = ((rho * rho) * (rho * rho)) * rho;
-                const double q = 1.0 - r5;
-                if (pow_uint(q, hyps) <= 1.0 - prm.confidence) break;
+            __syncthreads();  // C
+            floor_score = __builtin_amdgcn_readfirstlane(sh->best_score);
+            n_bar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
+            if (improve) {
+                int ni_first = -1;
+                if (prm.lo_iters) {  // every wavefront is here anyway: build the first refit's normal matrix together
+                    float bE0[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
+                    ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ,
+                                                              wscr_all + W_DOUBLES, sh, tid);
+                }
+                if (w == 0) {  // n-point refits while they improve (only wave 0 touches the best from here to A)
+                    for (uint32_t it = 0; it < prm.lo_iters; ++it) {
+                        float bE[9];
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
+                        const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
+                        const uint32_t cur_ninl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->best_ninl);
+                        int r_score;
+                        uint32_t r_ninl;
+                        float rE[9];
+                        const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, lane, cur_best,
+                                                                 cur_ninl, r_score, r_ninl, rE, prof, it == 0 ? ni_first : -1);
+                        if (ni < 5) break;
+                        if (lane == 0) sh->lo_runs += 1;
+                        if (!(r_score > cur_best)) break;
+                        if (lane == 0) {
+                            sh->best_score = r_score;
+                            sh->best_ninl = r_ninl;
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
+                        }
+                        wave_sync();
+                    }
+                }
+                deferred = true;
+            } else if (terminated(hyps)) {
+                break;
             }
         }
+        __syncthreads();  // a refit may still be running on wave 0 when the budget ends the loop
+        out_lo = sh->lo_runs;
         out_iters = hyps;
         have_model = sh->best_score >= 0;
         if (have_model) {

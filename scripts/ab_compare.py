@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""A/B two builds of libpgi.so in ONE process on several workloads (interleaved rounds, median)."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+import torch
+from pyposegraphbuilder import _lib as L, synthetic as S
+from pyposegraphbuilder.engine import Engine
+libs = sys.argv[1:]
+engs = []
+for path in libs:
+    L._lib = None
+    L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
+    engs.append(Engine())
+P = 8192
+for rho, N, thr, fb in ((0.5, 2000, 7.5e-4, 0), (0.5, 2000, 7.5e-4, 256), (0.7, 2000, 7.5e-4, 0), (0.3, 2000, 7.5e-4, 0), (0.5, 600, 7.5e-4, 0)):
+    b = S.make_batch(np.arange(P), N, inlier_ratio=rho)
+    res = {i: [] for i in range(len(engs))}
+    outs = {}
+    for i, e in enumerate(engs):
+        e.set_params(fixed_budget=fb)
+    dbs = [e.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=1) for e in engs]
+    for rnd in range(5):
+        for i, e in enumerate(engs):
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); ed, m = e.estimate_pose_batch(dbs[i]); z.record(); torch.cuda.synchronize()
+            if rnd: res[i].append(a.elapsed_time(z))
+            outs[i] = ed.cpu().numpy().tobytes()
+    same = all(outs[i] == outs[0] for i in outs)
+    print("rho %.1f N %4d budget %3d: " % (rho, N, fb) + "  ".join("%s %.3f ms (%.0f k/s)" % (libs[i], np.median(res[i]), P / np.median(res[i])) for i in res) + "  identical=%s" % same)
