@@ -658,9 +658,13 @@ void pgo_svd3(const double E[9], double U[9], double S[3], double V[9]) {
             const double be = fma(G[q], G[q], fma(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
             const double ga = fma(G[p], G[q], fma(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
             if (ga == 0.0) continue;
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-            const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;
+            /* same one-division rotation as pgo_jacobi9: al' = be - al, be' = 2 ga */
+            const double da = be - al, db = 2.0 * ga;
+            const double h = sqrt(fma(da, da, db * db));
+            const double d = fabs(da) + h;
+            const double r = sqrt(fma(d, d, db * db));
+            const double inv = 1.0 / r;
+            const double c = d * inv, s = (da >= 0.0 ? db : -db) * inv;
             for (int l = 0; l < 3; ++l) {
                 const double gp = G[3 * l + p], gq = G[3 * l + q];
                 G[3 * l + p] = fma(c, gp, -(s * gq));

@@ -42,7 +42,7 @@ extern "C" {
 #define PGO_JACOBI9_SWEEPS 6   /* cyclic (tournament-ordered) Jacobi sweeps, 9x9  */
 #endif
 #ifndef PGO_SVD3_SWEEPS
-#define PGO_SVD3_SWEEPS 6      /* one-sided Jacobi sweeps, 3x3                    */
+#define PGO_SVD3_SWEEPS 4      /* one-sided Jacobi sweeps, 3x3                    */
 #endif
 
 /* status codes of an edge */

@@ -25,7 +25,7 @@ namespace pgi {
 constexpr int kGrid = 256;       // root-bracketing intervals
 constexpr int kNewton = 10;      // safeguarded Newton iterations
 constexpr int kJacobiSweeps = 6; // 9x9 tournament Jacobi sweeps
-constexpr int kSvdSweeps = 6;    // 3x3 one-sided Jacobi sweeps
+constexpr int kSvdSweeps = 4;    // 3x3 one-sided Jacobi sweeps
 constexpr int kMaxModels = 10;
 
 // ---- optional per-phase cycle accounting (-DPGI_PROFILE; scripts/profile_phases.py) ----
@@ -233,6 +233,9 @@ PGI_DEV double refine_root(const double p[11], double lo, double hi, bool slo) {
         if ((v < 0.0) == slo) lo = x; else hi = x;
         double xn = x - v / d;
         if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+        // fixpoint: the next iteration would evaluate the same x, change neither bracket nor best --
+        // leaving now returns exactly what all kNewton iterations would
+        if (xn == x) break;
         x = xn;
     }
     return xbest;
@@ -311,11 +314,11 @@ PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, const GroupScra
             used = true;
             mycol = k;
         }
-        const double inv = 1.0 / a[k];
-        const double f = is_p ? 0.0 : a[k];  // the pivot row runs the same update with factor 0
+        const double scale = is_p ? 1.0 / a[k] : 1.0;  // x * 1.0 == x exactly: no per-column select
+        const double f = is_p ? 0.0 : a[k];             // the pivot row runs the same update with factor 0
 #pragma unroll
         for (int j = k + 1; j < 9; ++j) {
-            const double v = is_p ? a[j] * inv : a[j];
+            const double v = a[j] * scale;
             const double pj = __shfl(v, pl);
             a[j] = fma(-f, pj, v);
         }
@@ -450,11 +453,11 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
             used = true;
             mycol = k;
         }
-        const double inv = 1.0 / row[k];
-        const double f = is_p ? 0.0 : row[k];  // the pivot row runs the same update with factor 0
+        const double scale = is_p ? 1.0 / row[k] : 1.0;  // x * 1.0 == x exactly: no per-column select
+        const double f = is_p ? 0.0 : row[k];             // the pivot row runs the same update with factor 0
 #pragma unroll
         for (int j = k + 1; j < 20; ++j) {
-            const double v = is_p ? row[j] * inv : row[j];
+            const double v = row[j] * scale;
             const double pj = __shfl(v, pl);
             row[j] = fma(-f, pj, v);
         }
@@ -669,9 +672,13 @@ PGI_DEV void svd3(const double E[9], double U[9], double S[3], double V[9]) {
             const double be = fma(G[q], G[q], fma(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
             const double ga = fma(G[p], G[q], fma(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
             if (ga == 0.0) continue;
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-            const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;
+            // one division + two square roots per rotation (as in the 9x9 Jacobi)
+            const double da = be - al, db = 2.0 * ga;
+            const double h = sqrt(fma(da, da, db * db));
+            const double d = fabs(da) + h;
+            const double r = sqrt(fma(d, d, db * db));
+            const double inv = 1.0 / r;
+            const double c = d * inv, s = (da >= 0.0 ? db : -db) * inv;
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const double gp = G[3 * l + p], gq = G[3 * l + q];
