@@ -119,15 +119,17 @@ def main():
     value = world * P * args.steps / dt
     bytes_per_launch = P * algorithmic_bytes_per_edge(N)
     achieved_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic.json")
+    traffic, pmc = None, None
+    tf = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")  # PMC passes of this exact workload (scripts/profile_k1.sh)
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            if tj.get("pairs") == P and tj.get("corrs") == N:
+            if tj.get("pairs") == P and tj.get("corrs") == N and not args.fixed_budget:
                 traffic = tj.get("hbm_bytes_per_launch")
+                pmc = {"valu_active_frac_of_simd_cycles": tj.get("valu_active_frac_of_simd_cycles"),
+                       "wave_lifetime_split": tj.get("wave_lifetime_split"), "source": "profiles/r01_k1_pmc.json"}
         except Exception:
-            traffic = None
+            traffic, pmc = None, None
     out = {
         "metric": "pose-graph edges/sec (essential+decompose)",
         "value": round(value, 1), "unit": "edges/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -143,19 +145,15 @@ def main():
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "estimate_pose_kernel", "kernel_ms": round(kern_ms, 3),
                      "bytes_per_edge": algorithmic_bytes_per_edge(N),
-                     "note": "K1 stages rows once into LDS; it is VALU/LDS-bound by design (SURVEY 8d), see 'valu'"},
+                     "note": "K1 stages rows once into LDS: VALU / LDS-latency bound by design (SURVEY 8d), see 'valu'; traffic above algorithmic bytes = register-spill scratch"},
         "quality": {"rot_err_auc_at_5deg": round(auc5, 4), "edges_ok": int(ok.sum()),
                     "median_rot_err_deg": round(float(np.median(errs)), 4), "mean_hypotheses": float(got["iters"].mean()),
                     "mean_lo_refits": float(got["lo_runs"].mean())},
         "setup": {"gen_s": round(gen_s, 1)},
     }
-    # compute-side figure: residual evaluations dominate; ~2.6 models survive per hypothesis after the
-    # oriented-constraint prune, 34 flop per residual+levels, ~1.2e4 flop (f64) per 5-point solve
-    hyp = float(got["iters"].mean())
-    flop_edge = hyp * (1.2e4 + 2.6 * N * 34.0) + float(got["lo_runs"].mean()) * (N * 250.0 + 10 * N * 34.0)
-    out["valu"] = {"flop_per_edge_est": round(flop_edge), "achieved_tflops_est": round(P * flop_edge / (kern_ms * 1e-3) / 1e12, 3),
-                   "peak_tflops_f32": VALU_F32_PEAK_TF,
-                   "frac_est": round(P * flop_edge / (kern_ms * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4)}
+    # compute side (the kernel is VALU / LDS-latency bound, not HBM bound): measured by PMC, not estimated
+    if pmc:
+        out["valu"] = pmc
 
     if rank == 0 and world == 1 and not args.no_extra:
         # secondary lines (not `value`): fixed budget of 256 hypotheses; the HBM-bound K2 score kernel
