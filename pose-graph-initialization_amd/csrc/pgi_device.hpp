@@ -531,11 +531,14 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
     for (int c = 0; c < 11; ++c) p[c] = gs.rega[A_POLY + c];
     uint32_t chg = 0, sgn = 0;
     {
-        sgn = horner10(p, kGridTab.v[16 * s]) < 0.0 ? 1u : 0u;
+        double gv[17];  // all 17 grid abscissae of this sub-lane up front: one constant-memory latency, not five
+#pragma unroll
+        for (int b = 0; b < 17; ++b) gv[b] = kGridTab.v[16 * s + b];
+        sgn = horner10(p, gv[0]) < 0.0 ? 1u : 0u;
+#pragma unroll
         for (int b = 0; b < 16; b += 4) {  // four independent Horner chains per step (latency)
             double v0 = p[10], v1 = p[10], v2 = p[10], v3 = p[10];
-            const double g0 = kGridTab.v[16 * s + b + 1], g1 = kGridTab.v[16 * s + b + 2],
-                         g2 = kGridTab.v[16 * s + b + 3], g3 = kGridTab.v[16 * s + b + 4];
+            const double g0 = gv[b + 1], g1 = gv[b + 2], g2 = gv[b + 3], g3 = gv[b + 4];
 #pragma unroll
             for (int c = 9; c >= 0; --c) {
                 v0 = fma(v0, g0, p[c]);
