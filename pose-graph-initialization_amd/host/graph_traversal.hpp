@@ -13,7 +13,9 @@
 // the tests of a whole wave after the searches (equivalent: the search ends at the first recovered path).
 #pragma once
 #include <algorithm>
+#include <fstream>
 #include <functional>
+#include <sstream>
 #include <queue>
 #include <tuple>
 #include <unordered_map>
@@ -44,6 +46,35 @@ class SimilarityTable {
     double getSimilarity(ViewId from, ViewId to) const {
         if (from >= size || to >= size) return -1.0;  // NO_SUCH_VERTEX
         return similarity[from][to];
+    }
+    // imagesimilarity_graph.h:108-171: whitespace-separated N x N text ("%1.3f" from get_image_similarity.py).
+    // Pairs enter the heap while the mirrored cell still holds its initial 1.0, i.e. only (i<j) for a
+    // symmetric file -- and never for a similarity of exactly 1.0 (the reference's test, reproduced).
+    bool loadFromFile(const std::string& fname) {
+        std::ifstream file(fname);
+        if (!file.is_open()) return false;
+        std::vector<std::vector<double>> temp;
+        std::string line;
+        while (std::getline(file, line)) {
+            std::stringstream ss(line);
+            temp.emplace_back();
+            double value;
+            while (ss >> value) temp.back().push_back(value);
+        }
+        if (temp.size() != similarity.size()) return false;
+        for (size_t i = 0; i < similarity.size(); ++i) {
+            if (temp[i].size() != similarity[i].size()) return false;
+            for (size_t j = 0; j < temp[i].size(); ++j) {
+                similarity[i][j] = temp[i][j];
+                if (build_priority_queue && i != j && image_similarity_threshold <= similarity[i][j] &&
+                    similarity[j][i] != similarity[i][j]) {
+                    views.insert(i);
+                    views.insert(j);
+                    view_pair_queue.emplace(similarity[i][j], i, j);
+                }
+            }
+        }
+        return true;
     }
     std::priority_queue<std::tuple<double, ViewId, ViewId>>& getMutablePrioritizedViewPairs() { return view_pair_queue; }
     const std::unordered_set<ViewId>& getKeptViews() const { return views; }

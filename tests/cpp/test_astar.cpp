@@ -4,10 +4,40 @@
 #include <fstream>
 
 #include "graph_traversal.hpp"
+#include "utils.hpp"
 
 using namespace reconstruction;
 
+// mode "formats": <similarity.txt> <N> <threshold> <list_with_focals.txt> <out.txt>
+static int formats(char** argv) {
+    const size_t N = (size_t)std::atoi(argv[3]);
+    SimilarityTable sim(N, std::atof(argv[4]));
+    std::FILE* out = std::fopen(argv[6], "w");
+    std::fprintf(out, "load %d\n", (int)sim.loadFromFile(argv[2]));
+    auto& q = sim.getMutablePrioritizedViewPairs();
+    std::fprintf(out, "pairs %zu views %zu\n", q.size(), sim.getKeptViews().size());
+    while (!q.empty()) {
+        auto t = q.top();
+        q.pop();
+        std::fprintf(out, "%.3f %zu %zu\n", std::get<0>(t), (size_t)std::get<1>(t), (size_t)std::get<2>(t));
+    }
+    std::fprintf(out, "sim01 %.3f sim10 %.3f\n", sim.getSimilarity(0, 1), sim.getSimilarity(1, 0));
+    size_t total = 0;
+    std::vector<std::tuple<std::string, double, double, double>> imgs;
+    std::fprintf(out, "list %d\n", (int)load1DSfMImageList(argv[5], total, imgs));
+    std::fprintf(out, "total %zu\n", total);
+    for (auto& t : imgs) std::fprintf(out, "%s %.4f\n", std::get<0>(t).c_str(), std::get<1>(t));
+    RunningStatistics st;
+    st.addValue("[Pose estimation]", 2.0);
+    st.addValue("[Pose estimation]", 4.0);
+    std::fprintf(out, "stat %.1f %zu %.1f\n", st.getSum("[Pose estimation]"), st.getCount("[Pose estimation]"),
+                 st.getAverage("[Pose estimation]"));
+    std::fclose(out);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 7 && std::string(argv[1]) == "formats") return formats(argv);
     if (argc < 3) return 2;
     std::ifstream in(argv[1], std::ios::binary);
     uint32_t V, E, Q;

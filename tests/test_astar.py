@@ -94,3 +94,29 @@ def test_union_find_visibility():
     assert uf.has_link(1, 0) and not uf.has_link(1, 3)
     uf.add_link(1, 4)
     assert uf.has_link(0, 3) and not uf.has_link(5, 0)
+
+
+def test_text_formats_similarity_matrix_and_image_list(tmp_path):
+    """SURVEY §8f-4 text formats: N x N '%1.3f' similarity matrix (imagesimilarity_graph.h:108-171) and
+    list_with_focals.txt (utils.h:122-182), against a direct Python restatement."""
+    rng = np.random.default_rng(4)
+    N = 9
+    sim = np.triu(rng.uniform(0, 1, (N, N)).round(3), 1)
+    sim[0, 3] = 1.0  # exactly 1.0 never enters the heap (the reference compares with the 1.0-initialised mirror cell)
+    sim = sim + sim.T + np.eye(N)
+    fs, fl, fo = tmp_path / "sim.txt", tmp_path / "list.txt", tmp_path / "out.txt"
+    np.savetxt(fs, sim, fmt="%1.3f")
+    fl.write_text("images/a_001.jpg 0 1234.5\nimages/b.jpg\nimages/c.png 0 800\n")
+    thr = 0.5
+    subprocess.check_call([EXE, "formats", str(fs), str(N), str(thr), str(fl), str(fo)])
+    lines = fo.read_text().split("\n")
+    exp_pairs = sorted([(sim[i, j], i, j) for i in range(N) for j in range(i + 1, N) if thr <= sim[i, j] and sim[i, j] != 1.0],
+                       reverse=True)  # std::priority_queue<tuple>: largest (sim, i, j) first
+    assert lines[0] == "load 1"
+    assert lines[1] == "pairs %d views %d" % (len(exp_pairs), len({v for _, i, j in exp_pairs for v in (i, j)}))
+    got = [tuple(float(x) if k == 0 else int(x) for k, x in enumerate(l.split())) for l in lines[2:2 + len(exp_pairs)]]
+    assert got == [(round(s, 3), i, j) for s, i, j in exp_pairs]
+    rest = lines[2 + len(exp_pairs):]
+    assert rest[0] == "sim01 %.3f sim10 %.3f" % (sim[0, 1], sim[1, 0])
+    assert rest[1:6] == ["list 1", "total 3", "a_001.jpg 1234.5000", "b.jpg 0.0000", "c.png 800.0000"]
+    assert rest[6] == "stat 6.0 2 3.0"
