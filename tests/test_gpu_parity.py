@@ -320,3 +320,50 @@ def test_understated_max_corr_is_reported_not_overrun(eng):
     got = eng.edges_to_numpy(edges)
     assert got["status"][0] == 1 and got["status"][1] == -3
     assert masks.cpu().numpy()[200:].sum() == 0
+
+
+def test_degenerate_inputs_match_oracle_and_terminate(eng):
+    """Planar scene, pure rotation (E undefined), duplicated rows, NaN / huge coordinates: no hang, same result as the oracle."""
+    r = np.random.default_rng(11)
+    n = 400
+    cases = []
+    # planar scene (a known degenerate configuration for the five-point problem)
+    d = S.make_pair(14000, n, inlier_ratio=0.6)
+    Rg, tg = d["R"], d["t"]
+    X = np.stack([r.uniform(-1.5, 1.5, n), r.uniform(-1.5, 1.5, n), np.full(n, 5.0)], 1)
+    Y = X @ Rg.T + tg
+    cases.append(np.concatenate([X[:, :2] / X[:, 2:], Y[:, :2] / Y[:, 2:]], 1))
+    # pure rotation: t = 0
+    Y = X * [1, 1, 1] @ Rg.T
+    Xr = np.stack([r.uniform(-2, 2, n), r.uniform(-2, 2, n), r.uniform(3, 8, n)], 1)
+    Yr = Xr @ Rg.T
+    cases.append(np.concatenate([Xr[:, :2] / Xr[:, 2:], Yr[:, :2] / Yr[:, 2:]], 1))
+    # every row identical
+    cases.append(np.tile([[0.1, -0.2, 0.15, -0.18]], (n, 1)))
+    # only 7 distinct rows, repeated
+    base = np.stack([d[k][:7] for k in ("x1", "y1", "x2", "y2")], 1)
+    cases.append(np.tile(base, (n // 7 + 1, 1))[:n])
+    # NaN and huge values mixed into an otherwise good pair
+    good = np.stack([d[k] for k in ("x1", "y1", "x2", "y2")], 1).astype(np.float64)
+    bad = good.copy()
+    bad[::17, 0] = np.nan
+    bad[5::23, 3] = 1e30
+    bad[7::29, 1] = -np.inf
+    cases.append(bad)
+    # all zeros
+    cases.append(np.zeros((n, 4)))
+    c = np.concatenate(cases).astype(np.float32)
+    off = np.arange(len(cases) + 1) * n
+    db = eng.upload(c[:, 0], c[:, 1], c[:, 2], c[:, 3], off, 7.5e-4, seed=3, pair_id_base=14000)
+    edges, masks = eng.estimate_pose_batch(db)
+    got = eng.edges_to_numpy(edges)
+    exp, emasks = O.estimate_pose_batch(c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy(), c[:, 3].copy(), off, 7.5e-4,
+                                        O.default_params(), 3, pair_id_base=14000)
+    assert np.array_equal(masks.cpu().numpy(), emasks)
+    assert list(got["status"]) == list(exp["status"]) and list(got["n_inl"]) == list(exp["n_inl"])
+    assert list(got["iters"]) == list(exp["iters"])
+    ok = exp["status"] == 1
+    assert np.array_equal(got["E"][ok], exp["E"][ok])
+    np.testing.assert_allclose(got["R"][ok], exp["R"][ok], atol=1e-9)
+    # the contaminated pair still recovers the pose from its clean rows
+    assert got["status"][4] == 1 and S.rot_err_deg(got["R"][4].reshape(3, 3), Rg) < 0.5
