@@ -29,4 +29,7 @@ struct pgi_ctx {
     size_t scratch_bytes = 0;
     int max_lds = 0;
     unsigned long long* d_prof = nullptr;
+    uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
+    size_t bucket_bytes = 0;
+    bool lds_attr_set = false;
 };

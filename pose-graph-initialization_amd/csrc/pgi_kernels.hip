@@ -16,6 +16,7 @@
 #include "pgi_device.hpp"
 #include "pgi_internal.hpp"
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -68,6 +69,8 @@ struct K1Args {
     uint64_t seed;
     pgi_params prm;
     unsigned long long* prof;  // kProfSlots counters (profiling builds) or nullptr
+    const uint32_t* pair_list;   // size bucket: indices of the pairs of this launch (nullptr: all pairs)
+    const uint32_t* pair_count;  // number of valid entries in pair_list
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -419,7 +422,11 @@ template <bool LDS_PTS>
 __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t pair = blockIdx.x;
+    uint32_t pair = blockIdx.x;
+    if (a.pair_list) {  // this launch serves one size bucket (its own LDS size => its own occupancy)
+        if (blockIdx.x >= *a.pair_count) return;
+        pair = a.pair_list[blockIdx.x];
+    }
     const uint64_t o = a.off[pair];
     const uint32_t n = (uint32_t)(a.off[pair + 1] - o);
     const uint32_t npad = (n + 63u) & ~63u;
@@ -819,6 +826,20 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     prof.flush(a.prof, lane);
 }
 
+// Size buckets: dynamic LDS is per launch, so ragged batches are split by row count and every bucket
+// is launched with the LDS (hence the occupancy) its pairs need.  caps[b] = largest row count of
+// bucket b (ascending); pairs above caps[2] go to bucket 3 (rows stay in HBM/L2).
+__global__ __launch_bounds__(256) void bucket_pairs_kernel(const uint64_t* __restrict__ off, uint32_t n_pairs, uint32_t cap0,
+                                                           uint32_t cap1, uint32_t cap2, uint32_t* __restrict__ lists,
+                                                           uint32_t* __restrict__ counts) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t n = (uint32_t)(off[p + 1] - off[p]);
+    const int b = n <= cap0 ? 0 : n <= cap1 ? 1 : n <= cap2 ? 2 : 3;
+    const uint32_t i = atomicAdd(&counts[b], 1u);  // order inside a bucket is irrelevant: results are per pair
+    lists[(size_t)b * n_pairs + i] = p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: one model per pair; one wavefront per pair streams the SoA rows with float4 loads.
 // ------------------------------------------------------------------------------------------------
@@ -1106,6 +1127,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
 void pgi_destroy(pgi_ctx* ctx) {
     if (!ctx) return;
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
     delete ctx;
 }
 
@@ -1146,18 +1168,58 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     a.edges = d_edges; a.masks = d_masks; a.n_pairs = b->n_pairs;
     a.pair_id_base = b->pair_id_base; a.seed = b->seed; a.prm = ctx->prm;
     a.prof = ctx->d_prof;
+    a.pair_list = nullptr;
+    a.pair_count = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    const uint32_t cap = (b->max_corr + 63u) & ~63u;
-    const size_t lds_rows = (size_t)cap * 16 + k1_fixed_lds();
-    if (lds_rows <= (size_t)ctx->max_lds) {
-        a.pts_cap = cap;
-        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-        hipLaunchKernelGGL(estimate_pose_kernel<true>, dim3(b->n_pairs), dim3(NT), lds_rows, ctx->stream, a);
-    } else {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
+    const size_t fixed = k1_fixed_lds();
+    auto rows_cap = [&](int wgs_per_cu) {  // largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
+        const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
+        return budget > fixed ? (uint32_t)(((budget - fixed) / 16) & ~(size_t)63) : 0u;
+    };
+    const uint32_t cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
+    auto launch_lds = [&](uint32_t cap_rows) {
+        a.pts_cap = cap_rows;
+        const size_t lds = (size_t)cap_rows * 16 + fixed;
+        hipLaunchKernelGGL(estimate_pose_kernel<true>, dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+    };
+    auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        const size_t lds = k1_fixed_lds();
-        hipLaunchKernelGGL(estimate_pose_kernel<false>, dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+        hipLaunchKernelGGL(estimate_pose_kernel<false>, dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
+    };
+    if (!ctx->lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ctx->max_lds));
+        ctx->lds_attr_set = true;
+    }
+    const uint32_t cap = (b->max_corr + 63u) & ~63u;
+    if (cap <= cap3 || b->n_pairs < 64) {  // uniform enough (or tiny): one launch sized for the largest pair
+        if (cap <= cap1) launch_lds(cap); else launch_global();
+    } else {  // ragged: bucket by row count on the device, one launch per occupancy class
+        const size_t need = ((size_t)4 * b->n_pairs + 8) * sizeof(uint32_t);
+        if (need > ctx->bucket_bytes) {
+            if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
+            ctx->d_bucket = nullptr;
+            ctx->bucket_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->d_bucket, need));
+            ctx->bucket_bytes = need;
+        }
+        uint32_t* counts = ctx->d_bucket;
+        uint32_t* lists = ctx->d_bucket + 8;
+        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, ctx->stream, b->d_offsets,
+                           b->n_pairs, cap3, cap2, cap1, lists, counts);
+        const uint32_t caps[3] = {cap3, cap2, cap1};
+        for (int k = 0; k < 3; ++k) {
+            if (k > 0 && cap <= caps[k - 1]) break;  // no pair can be this large
+            a.pair_list = lists + (size_t)k * b->n_pairs;
+            a.pair_count = counts + k;
+            launch_lds(std::min(caps[k], cap));
+        }
+        if (cap > cap1) {
+            a.pair_list = lists + (size_t)3 * b->n_pairs;
+            a.pair_count = counts + 3;
+            launch_global();
+        }
     }
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;

@@ -367,3 +367,20 @@ def test_degenerate_inputs_match_oracle_and_terminate(eng):
     np.testing.assert_allclose(got["R"][ok], exp["R"][ok], atol=1e-9)
     # the contaminated pair still recovers the pose from its clean rows
     assert got["status"][4] == 1 and S.rot_err_deg(got["R"][4].reshape(3, 3), Rg) < 0.5
+
+
+def test_size_bucketed_launches_match_oracle(eng):
+    """>= 64 pairs spanning every occupancy class (<= 2176, <= 3904, <= 9024 rows in LDS, beyond: rows from HBM)."""
+    sizes = ([60, 300, 2300, 1500, 4000, 2176, 2177, 900] * 9)[:70] + [9100, 9024]
+    ids = np.arange(15000, 15000 + len(sizes))
+    b = S.make_batch(ids, sizes)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=4, pair_id_base=15000)
+    edges, masks = eng.estimate_pose_batch(db)
+    got = eng.edges_to_numpy(edges)
+    exp, emasks = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4,
+                                        O.default_params(), 4, pair_id_base=15000)
+    assert np.array_equal(masks.cpu().numpy(), emasks)
+    assert_edges_match(got, exp)
+    # a second call reuses the bucket workspace and is bit-identical
+    edges2, masks2 = eng.estimate_pose_batch(db)
+    assert np.array_equal(edges.cpu().numpy(), edges2.cpu().numpy())
