@@ -32,4 +32,5 @@ struct pgi_ctx {
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
     bool lds_attr_set = false;
+    int lds_min_wgs = 2;  // stage rows in LDS only if this many workgroups still fit per CU
 };

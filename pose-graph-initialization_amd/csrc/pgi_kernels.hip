@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace pgi {
@@ -1121,6 +1122,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     int lds = 0;
     (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     c->max_lds = lds > 0 ? lds : 65536;
+    if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     return c;
 }
 
@@ -1192,8 +1194,12 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
         ctx->lds_attr_set = true;
     }
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
+    // Rows are staged in LDS only while at least `lds_min_wgs` workgroups still fit per CU; bigger pairs read
+    // their rows from HBM/L2 at full occupancy instead (measured: faster than LDS at one workgroup per CU,
+    // scripts/lds_capacity_probe.py).  PGI_LDS_MIN_WGS overrides the default for experiments.
+    const uint32_t lds_cap = ctx->lds_min_wgs >= 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
     if (cap <= cap3 || b->n_pairs < 64) {  // uniform enough (or tiny): one launch sized for the largest pair
-        if (cap <= cap1) launch_lds(cap); else launch_global();
+        if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // ragged: bucket by row count on the device, one launch per occupancy class
         const size_t need = ((size_t)4 * b->n_pairs + 8) * sizeof(uint32_t);
         if (need > ctx->bucket_bytes) {
@@ -1209,16 +1215,11 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
         hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, ctx->stream, b->d_offsets,
                            b->n_pairs, cap3, cap2, cap1, lists, counts);
         const uint32_t caps[3] = {cap3, cap2, cap1};
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (k > 0 && cap <= caps[k - 1]) break;  // no pair can be this large
             a.pair_list = lists + (size_t)k * b->n_pairs;
             a.pair_count = counts + k;
-            launch_lds(std::min(caps[k], cap));
-        }
-        if (cap > cap1) {
-            a.pair_list = lists + (size_t)3 * b->n_pairs;
-            a.pair_count = counts + 3;
-            launch_global();
+            if (k < 3 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
         }
     }
     HIP_TRY(hipGetLastError());

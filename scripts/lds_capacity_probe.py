@@ -1,18 +1,21 @@
-import torch, ctypes as C
-hip=C.CDLL('libamdhip64.so')
-v=C.c_int(0)
-for name,idx in (('MaxSharedMemoryPerBlock',None),):
-    pass
-p=torch.cuda.get_device_properties(0)
-print(p.name, 'shared_memory_per_block', getattr(p,'shared_memory_per_block',None), 'per_block_optin', getattr(p,'shared_memory_per_block_optin',None), 'multi_processor_count', p.multi_processor_count)
-import sys; sys.path.insert(0,'pose-graph-initialization_amd')
-from pyposegraphbuilder import Engine, synthetic as S
+#!/usr/bin/env python3
+"""Throughput vs rows per pair (uniform batches of 2048 pairs): shows the occupancy classes."""
+import os, sys
 import numpy as np
-eng=Engine()
-for N in (2048, 2816, 3072, 4096, 8000, 8192, 9000):
-    b=S.make_batch(np.arange(512),N)
-    db=eng.upload(b['x1'],b['y1'],b['x2'],b['y2'],b['offsets'],7.5e-4,seed=1)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+import torch
+from pyposegraphbuilder import Engine, synthetic as S
+eng = Engine()
+P = 2048
+for N in (512, 1024, 2048, 2176, 3072, 3904, 4096, 6000, 7872, 8000, 9000, 12000):
+    b = S.make_batch(np.arange(256), N)
+    rep = P // 256  # replicate 256 generated pairs (same rows, different seeds via pair ids)
+    x = {k: np.tile(b[k], rep) for k in ("x1", "y1", "x2", "y2")}
+    off = np.arange(P + 1, dtype=np.uint64) * N
+    db = eng.upload(x["x1"], x["y1"], x["x2"], x["y2"], off, 7.5e-4, seed=1)
     eng.estimate_pose_batch(db); torch.cuda.synchronize()
-    a,z=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); eng.estimate_pose_batch(db); z.record(); torch.cuda.synchronize()
-    print(N, '%.3f ms'%a.elapsed_time(z), '%.0f edges/s'%(512/a.elapsed_time(z)*1e3))
+    ms = a.elapsed_time(z)
+    print("N=%5d: %7.3f ms  %8.0f edges/s  %6.0f Mrows/s" % (N, ms, P / ms * 1e3, P * N / ms / 1e3))

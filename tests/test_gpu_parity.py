@@ -370,8 +370,9 @@ def test_degenerate_inputs_match_oracle_and_terminate(eng):
 
 
 def test_size_bucketed_launches_match_oracle(eng):
-    """>= 64 pairs spanning every occupancy class (<= 2176, <= 3904, <= 9024 rows in LDS, beyond: rows from HBM)."""
-    sizes = ([60, 300, 2300, 1500, 4000, 2176, 2177, 900] * 9)[:70] + [9100, 9024]
+    """>= 64 pairs spanning every occupancy class (<= 2176 and <= 3904 rows: 4-wave workgroups; <= 7872: 8-wave
+    workgroups; <= 9024: 4-wave, one per CU; beyond: rows from HBM)."""
+    sizes = ([60, 300, 2300, 1500, 4000, 2176, 2177, 900] * 9)[:68] + [9100, 9024, 7000, 7900]
     ids = np.arange(15000, 15000 + len(sizes))
     b = S.make_batch(ids, sizes)
     db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=4, pair_id_base=15000)
