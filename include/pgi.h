@@ -165,6 +165,34 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
                          uint32_t n_views, const pgi_rotavg_params* prm, double* h_R_out,
                          uint32_t* h_iters_out);
 
+/* ---- descriptor matching (feature_utils.h:135-202) ----------
+ * The step that produces the correspondences estimatePose consumes: two brute-force
+ * L2 kNN(2) searches (cv::BFMatcher, :151-163), Lowe ratio 0.90 and mutual-best test
+ * (:165-176), matches sorted by the ratio (:178-180).  Descriptors are PGI_DESC_DIM
+ * floats (RootSIFT, feature_utils.h:26-133).  Distances come from the exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32 == an fmaf chain over k = 0..127), so the result is
+ * bit-identical to the scalar specification in oracle/pgi_oracle.c. */
+#define PGI_DESC_DIM 128
+#define PGI_DESC_MAX 16384 /* keypoints per image supported by the selection kernel */
+/* rounds n up to the padded keypoint count used by the transposed layout */
+uint32_t pgi_desc_padded(uint32_t n);
+/* d_desc: n x 128 row-major floats (cv::Mat descriptors).  Writes the transposed copy
+ * d_desc_t (128 x pgi_desc_padded(n), zero padded) and the squared norms d_norm
+ * (pgi_desc_padded(n)).  Done once per image; every pair the image takes part in reuses it. */
+int pgi_desc_prepare(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_desc_t, float* d_norm);
+typedef struct {
+    const float* d_desc_t; /* 128 x n_pad */
+    const float* d_norm;   /* n_pad       */
+    uint32_t n;
+    uint32_t n_pad;        /* == pgi_desc_padded(n) */
+} pgi_desc_view;
+/* Pair p matches image h_src[p] (queries) against h_dst[p].  Outputs, per pair p at
+ * stride max_matches: d_match_src / d_match_dst (keypoint indices, :183-197) and d_ratio,
+ * sorted by (ratio, src index); d_counts[p] = number of matches.  Asynchronous on the stream. */
+int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst,
+                                uint32_t n_pairs, uint32_t max_matches, uint32_t* d_match_src,
+                                uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -944,3 +944,67 @@ void pgo_estimate_pose_batch(const float* x1, const float* y1, const float* x2,
     }
     (void)threads;
 }
+
+/* ======================================================================= */
+/* descriptor matching: feature_utils.h:135-202              */
+/* ======================================================================= */
+/* The reference runs two OpenCV brute-force kNN(2) searches (L2) and keeps query i iff
+ * dist1 < 0.90*dist2 and the best match of its best match is i (:165-176), sorted by
+ * dist1/dist2 (:178-180).  OpenCV is external, so the distance arithmetic is specified here:
+ *   s_ij = fmaf chain over k = 0..D-1 of a_ik*b_jk (from 0)      [== v_mfma_f32_32x32x2_f32 accumulation]
+ *   na_i, nb_j = the same chain of squares;  d2_ij = max(0, (na_i + nb_j) - 2*s_ij)
+ * row-wise the two smallest d2 (ties: lower j), column-wise the smallest (ties: lower i);
+ * dist = sqrtf(d2); test in double as the reference's `float < 0.90 * float`; ratio = dist1 / dist2 (float). */
+static inline float chain_dot(const float* a, const float* b, uint32_t d) {
+    float s = 0.0f;
+    for (uint32_t k = 0; k < d; ++k) s = fmaf(a[k], b[k], s);
+    return s;
+}
+uint32_t pgo_match_descriptors(const float* A, uint32_t k1, const float* B, uint32_t k2, uint32_t d,
+                               uint32_t* out_i, uint32_t* out_j, double* out_ratio) {
+    if (k1 < 2 || k2 < 2) return 0; /* :167-168: both directions need two neighbours */
+    float* na = (float*)malloc(sizeof(float) * k1);
+    float* nb = (float*)malloc(sizeof(float) * k2);
+    float* r1 = (float*)malloc(sizeof(float) * k1);
+    float* r2 = (float*)malloc(sizeof(float) * k1);
+    uint32_t* rj = (uint32_t*)malloc(sizeof(uint32_t) * k1);
+    float* c1 = (float*)malloc(sizeof(float) * k2);
+    uint32_t* ci = (uint32_t*)malloc(sizeof(uint32_t) * k2);
+    for (uint32_t i = 0; i < k1; ++i) na[i] = chain_dot(A + (size_t)i * d, A + (size_t)i * d, d);
+    for (uint32_t j = 0; j < k2; ++j) { nb[j] = chain_dot(B + (size_t)j * d, B + (size_t)j * d, d); c1[j] = INFINITY; ci[j] = 0; }
+    for (uint32_t i = 0; i < k1; ++i) {
+        float b1 = INFINITY, b2 = INFINITY;
+        uint32_t j1 = 0;
+        for (uint32_t j = 0; j < k2; ++j) {
+            const float s = chain_dot(A + (size_t)i * d, B + (size_t)j * d, d);
+            const float t = na[i] + nb[j];
+            float d2 = t - 2.0f * s;
+            d2 = d2 > 0.0f ? d2 : 0.0f;
+            if (d2 < b1) { b2 = b1; b1 = d2; j1 = j; }
+            else if (d2 < b2) { b2 = d2; }
+            if (d2 < c1[j]) { c1[j] = d2; ci[j] = i; }
+        }
+        r1[i] = b1; r2[i] = b2; rj[i] = j1;
+    }
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < k1; ++i) {
+        const float dist1 = sqrtf(r1[i]), dist2 = sqrtf(r2[i]);
+        if ((double)dist1 < 0.90 * (double)dist2 && ci[rj[i]] == i) {
+            out_i[m] = i; out_j[m] = rj[i]; out_ratio[m] = (double)(dist1 / dist2);
+            ++m;
+        }
+    }
+    /* std::sort on (ratio, pointer) == (ratio, i): insertion sort is fine for test sizes */
+    for (uint32_t a = 1; a < m; ++a) {
+        const uint32_t vi = out_i[a], vj = out_j[a];
+        const double vr = out_ratio[a];
+        uint32_t b = a;
+        while (b > 0 && (out_ratio[b - 1] > vr || (out_ratio[b - 1] == vr && out_i[b - 1] > vi))) {
+            out_i[b] = out_i[b - 1]; out_j[b] = out_j[b - 1]; out_ratio[b] = out_ratio[b - 1];
+            --b;
+        }
+        out_i[b] = vi; out_j[b] = vj; out_ratio[b] = vr;
+    }
+    free(na); free(nb); free(r1); free(r2); free(rj); free(c1); free(ci);
+    return m;
+}

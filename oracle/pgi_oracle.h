@@ -156,6 +156,10 @@ void pgo_estimate_pose(const float* x1, const float* y1, const float* x2, const 
                        const pgo_params* prm, uint64_t seed, uint64_t pair_id, pgo_edge* out,
                        uint8_t* mask);
 
+/* mutual nearest neighbour + ratio test of two descriptor sets (feature_utils.h:135-202); returns #matches */
+uint32_t pgo_match_descriptors(const float* A, uint32_t k1, const float* B, uint32_t k2, uint32_t d,
+                               uint32_t* out_i, uint32_t* out_j, double* out_ratio);
+
 /* batch over a flattened (pair,corr) SoA; OpenMP over pairs (threads<=0: all) */
 void pgo_estimate_pose_batch(const float* x1, const float* y1, const float* x2,
                              const float* y2, const uint64_t* offsets, uint32_t n_pairs,

@@ -32,5 +32,7 @@ struct pgi_ctx {
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
     bool lds_attr_set = false;
+    void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
+    size_t match_ws_bytes = 0;
     int lds_min_wgs = 2;  // stage rows in LDS only if this many workgroups still fit per CU
 };

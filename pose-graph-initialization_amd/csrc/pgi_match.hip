@@ -1,0 +1,309 @@
+// pgi_match.hip -- descriptor matching on the exact-f32 matrix cores.
+//
+// Replaces feature_utils.h:135-202 of the reference (two cv::BFMatcher kNN(2) searches, Lowe ratio 0.90,
+// mutual-best test, sort by ratio).  The K1 x K2 x 128 inner products are the only GEMM-shaped work next to the
+// hot path; they run on v_mfma_f32_32x32x2_f32, whose accumulation is bitwise an fmaf chain over k = 0..127, so
+// the matches are bit-identical to the scalar specification (oracle/pgi_oracle.c: pgo_match_descriptors).
+//
+//   desc_prepare_kernel   n x 128 row-major -> 128 x n_pad transposed (+ squared norms), once per image
+//   desc_top2_kernel      per (128-row block, column split): distances tile by tile, running row top-2 in
+//                         registers, column best through 64-bit atomicMin on (d2 bits, row)
+//   match_select_kernel   per pair: merge the splits, ratio + mutual test, bitonic sort by (ratio, row)
+#include <vector>
+#include "pgi_internal.hpp"
+
+namespace {
+constexpr int kD = PGI_DESC_DIM;   // 128
+constexpr int kRowsWg = 128;       // rows of A per workgroup: 4 wavefronts x one 32-row MFMA tile
+constexpr int kTileJ = 64;         // columns of B staged per step: 2 MFMA tiles per wavefront
+constexpr int kLdsStride = 96;     // words per k-row of the staged tile: 64 + 32, so lanes 32..63 (k odd) hit the other banks
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct RowBest {
+    float b1, b2;  // smallest and second-smallest squared distance of the row
+    uint32_t j1;   // column of the smallest (ties: lowest column)
+    uint32_t pad;
+};
+struct MatchPair {
+    const float *at, *na, *bt, *nb;
+    uint32_t n_a, n_a_pad, n_b, n_b_pad;
+    uint64_t row_off;  // RowBest index of (split 0, row 0) of this pair
+    uint64_t col_off;  // column-best index of column 0 of this pair
+};
+
+// C/D layout of the 32x32 MFMA: register r of lane (c = lane & 31, h = lane >> 5) holds C[row][c]
+__device__ __forceinline__ uint32_t mfma_row(int r, uint32_t h) { return (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h; }
+
+__global__ __launch_bounds__(256) void desc_prepare_kernel(const float* __restrict__ desc, uint32_t n, uint32_t n_pad,
+                                                           float* __restrict__ desc_t, float* __restrict__ norm) {
+    __shared__ float tile[64 * (kD + 1)];
+    const uint32_t j0 = blockIdx.x * 64u, tid = threadIdx.x;
+    for (uint32_t idx = tid; idx < 64u * (kD / 4); idx += 256u) {
+        const uint32_t jj = idx / (kD / 4), k4 = idx % (kD / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j0 + jj < n) v = *reinterpret_cast<const float4*>(desc + (size_t)(j0 + jj) * kD + 4 * k4);
+        float* dst = tile + jj * (kD + 1) + 4 * k4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < 64u * kD; idx += 256u) {
+        const uint32_t k = idx >> 6, jj = idx & 63u;
+        desc_t[(size_t)k * n_pad + j0 + jj] = tile[jj * (kD + 1) + k];
+    }
+    if (tid < 64u) {
+        float s = 0.0f;
+        for (int k = 0; k < kD; ++k) { const float v = tile[tid * (kD + 1) + k]; s = fmaf(v, v, s); }
+        norm[j0 + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void desc_top2_kernel(const MatchPair* __restrict__ pairs, RowBest* __restrict__ rowpart,
+                                                           unsigned long long* __restrict__ colbest, uint32_t splits) {
+    __shared__ float bt[kD * kLdsStride];  // 48 KB
+    __shared__ unsigned long long cb[kTileJ];
+    const MatchPair P = pairs[blockIdx.y];
+    const uint32_t rb = blockIdx.x / splits, split = blockIdx.x % splits;
+    if (rb * kRowsWg >= P.n_a_pad) return;
+    const uint32_t tiles = P.n_b_pad / kTileJ;
+    const uint32_t t0 = (uint32_t)((uint64_t)tiles * split / splits), t1 = (uint32_t)((uint64_t)tiles * (split + 1) / splits);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
+    const uint32_t row_base = rb * kRowsWg + w * 32u;
+
+    // A fragment of the whole K range: a[s] = A[row_base + c][2s + h]
+    float a[kD / 2];
+#pragma unroll
+    for (int s = 0; s < kD / 2; ++s) a[s] = P.at[(size_t)(2 * s + (int)h) * P.n_a_pad + row_base + c];
+    float nar[16], b1[16], b2[16];
+    uint32_t j1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        nar[r] = P.na[row_base + mfma_row(r, h)];
+        b1[r] = INFINITY; b2[r] = INFINITY; j1[r] = 0u;
+    }
+
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        __syncthreads();  // the previous tile's readers of bt / cb are done
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t idx = tid + 256u * q, k = idx >> 4, j4 = idx & 15u;
+            const float4 v = *reinterpret_cast<const float4*>(P.bt + (size_t)k * P.n_b_pad + tile * kTileJ + 4u * j4);
+            *reinterpret_cast<float4*>(bt + k * kLdsStride + 4u * j4) = v;
+        }
+        if (tid < (uint32_t)kTileJ) cb[tid] = ~0ull;
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < kD / 2; ++s) {
+            const float x0 = bt[(2 * s + (int)h) * kLdsStride + c];
+            const float x1 = bt[(2 * s + (int)h) * kLdsStride + 32 + c];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t j = tile * kTileJ + 32u * sub + c;
+            const float nbj = P.nb[j];
+            const bool jvalid = j < P.n_b;
+            unsigned long long ckey = ~0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = nar[r] + nbj;
+                float d2 = t - 2.0f * acc[sub][r];
+                d2 = d2 > 0.0f ? d2 : 0.0f;
+                if (jvalid) {
+                    if (d2 < b1[r]) { b2[r] = b1[r]; b1[r] = d2; j1[r] = j; }
+                    else if (d2 < b2[r]) { b2[r] = d2; }
+                }
+                const uint32_t i = row_base + mfma_row(r, h);
+                if (i < P.n_a) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | i;
+                    ckey = key < ckey ? key : ckey;
+                }
+            }
+            const unsigned long long other = __shfl_xor(ckey, 32);
+            ckey = other < ckey ? other : ckey;
+            if (h == 0u && jvalid) atomicMin(&cb[32 * sub + c], ckey);
+        }
+        __syncthreads();
+        if (tid < (uint32_t)kTileJ) {
+            const uint32_t j = tile * kTileJ + tid;
+            const unsigned long long v = cb[tid];
+            if (j < P.n_b && v != ~0ull) atomicMin(&colbest[P.col_off + j], v);
+        }
+    }
+    // row top-2 across the 32 lanes that share a row (same h): xor butterfly inside each half-wave
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float x1 = b1[r], x2 = b2[r];
+        uint32_t xj = j1[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float o1 = __shfl_xor(x1, m), o2 = __shfl_xor(x2, m);
+            const uint32_t oj = (uint32_t)__shfl_xor((int)xj, m);
+            const bool take = o1 < x1 || (o1 == x1 && oj < xj);
+            const float n2 = fminf(fmaxf(x1, o1), fminf(x2, o2));
+            if (take) { x1 = o1; xj = oj; }
+            x2 = n2;
+        }
+        if (c == 0u) {
+            RowBest rbst;
+            rbst.b1 = x1; rbst.b2 = x2; rbst.j1 = xj; rbst.pad = 0u;
+            rowpart[P.row_off + (uint64_t)split * P.n_a_pad + row_base + mfma_row(r, h)] = rbst;
+        }
+    }
+}
+
+// one workgroup per pair; keys[] = dynamic LDS, np = power of two >= n_a
+__global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __restrict__ pairs, RowBest* __restrict__ rowpart,
+                                                            const unsigned long long* __restrict__ colbest, uint32_t splits,
+                                                            uint32_t max_matches, uint32_t* __restrict__ out_src,
+                                                            uint32_t* __restrict__ out_dst, double* __restrict__ out_ratio,
+                                                            uint32_t* __restrict__ out_count) {
+    extern __shared__ unsigned long long keys[];
+    __shared__ uint32_t s_count;
+    const MatchPair P = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    uint32_t np = 2;
+    while (np < P.n_a) np <<= 1;
+    if (tid == 0) s_count = 0u;
+    const bool both = P.n_a >= 2u && P.n_b >= 2u;  // feature_utils.h:167-168
+    for (uint32_t i = tid; i < np; i += 1024u) {
+        unsigned long long key = ~0ull;
+        if (i < P.n_a && both) {
+            RowBest m = rowpart[P.row_off + i];
+            for (uint32_t s = 1; s < splits; ++s) {  // later splits hold higher columns: ties keep the earlier one
+                const RowBest o = rowpart[P.row_off + (uint64_t)s * P.n_a_pad + i];
+                const bool take = o.b1 < m.b1;
+                const float n2 = fminf(fmaxf(m.b1, o.b1), fminf(m.b2, o.b2));
+                if (take) { m.b1 = o.b1; m.j1 = o.j1; }
+                m.b2 = n2;
+            }
+            const float dist1 = sqrtf(m.b1), dist2 = sqrtf(m.b2);
+            const bool mutual = (uint32_t)(colbest[P.col_off + m.j1] & 0xffffffffull) == i;
+            if ((double)dist1 < 0.90 * (double)dist2 && mutual) {
+                const float ratio = dist1 / dist2;
+                key = ((unsigned long long)__float_as_uint(ratio) << 32) | i;
+                rowpart[P.row_off + i].j1 = m.j1;  // merged best column, read back after the sort
+            }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= np; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < np; i += 1024u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = keys[i], y = keys[l];
+                    const bool up = (i & k) == 0u;
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < np; i += 1024u) {
+        if (keys[i] != ~0ull && (i + 1 == np || keys[i + 1] == ~0ull)) s_count = i + 1;
+    }
+    __syncthreads();
+    const uint32_t count = s_count < max_matches ? s_count : max_matches;
+    for (uint32_t i = tid; i < count; i += 1024u) {
+        const unsigned long long key = keys[i];
+        const uint32_t src = (uint32_t)(key & 0xffffffffull);
+        const size_t o = (size_t)blockIdx.x * max_matches + i;
+        out_src[o] = src;
+        out_dst[o] = rowpart[P.row_off + src].j1;
+        out_ratio[o] = (double)__uint_as_float((uint32_t)(key >> 32));
+    }
+    if (tid == 0) out_count[blockIdx.x] = count;
+}
+}  // namespace
+
+extern "C" {
+uint32_t pgi_desc_padded(uint32_t n) { return (n + (uint32_t)kRowsWg - 1u) / (uint32_t)kRowsWg * (uint32_t)kRowsWg; }
+
+int pgi_desc_prepare(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_desc_t, float* d_norm) {
+    if (!ctx || !d_desc_t || !d_norm || (n && !d_desc)) return pgi::fail(PGI_ERR_INVALID, "pgi_desc_prepare: null argument");
+    if (n > PGI_DESC_MAX) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_desc_prepare: more than PGI_DESC_MAX keypoints");
+    const uint32_t n_pad = pgi_desc_padded(n);
+    if (n_pad == 0) return PGI_SUCCESS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(desc_prepare_kernel, dim3(n_pad / 64), dim3(256), 0, ctx->stream, d_desc, n, n_pad, d_desc_t, d_norm);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst, uint32_t n_pairs,
+                                uint32_t max_matches, uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio,
+                                uint32_t* d_counts) {
+    if (!ctx || !d_counts) return pgi::fail(PGI_ERR_INVALID, "pgi_match_descriptors_batch: null argument");
+    if (n_pairs == 0) return PGI_SUCCESS;
+    if (!h_src || !h_dst || !d_match_src || !d_match_dst || !d_ratio || max_matches == 0)
+        return pgi::fail(PGI_ERR_INVALID, "pgi_match_descriptors_batch: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<MatchPair> hp(n_pairs);
+    uint64_t row_blocks = 0, rows_total = 0, cols_total = 0;
+    uint32_t max_rb = 0, min_tiles = ~0u, max_na = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const pgi_desc_view &a = h_src[p], &b = h_dst[p];
+        if (a.n_pad != pgi_desc_padded(a.n) || b.n_pad != pgi_desc_padded(b.n) || (a.n && (!a.d_desc_t || !a.d_norm)) ||
+            (b.n && (!b.d_desc_t || !b.d_norm)))
+            return pgi::fail(PGI_ERR_INVALID, "pgi_match_descriptors_batch: bad descriptor view");
+        if (a.n > PGI_DESC_MAX || b.n > PGI_DESC_MAX)
+            return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_match_descriptors_batch: more than PGI_DESC_MAX keypoints");
+        hp[p] = MatchPair{a.d_desc_t, a.d_norm, b.d_desc_t, b.d_norm, a.n, a.n_pad, b.n, b.n_pad, 0, cols_total};
+        const uint32_t rb = a.n_pad / kRowsWg, tiles = b.n_pad / kTileJ;
+        row_blocks += (b.n ? rb : 0);
+        max_rb = rb > max_rb ? rb : max_rb;
+        if (a.n && b.n) min_tiles = tiles < min_tiles ? tiles : min_tiles;
+        max_na = a.n > max_na ? a.n : max_na;
+        rows_total += a.n_pad;
+        cols_total += b.n_pad;
+    }
+    // column splits: enough workgroups to cover the 256 CUs a few times over, never more splits than tiles
+    uint32_t splits = 1;
+    if (row_blocks > 0 && row_blocks < 1024) splits = (uint32_t)((1024 + row_blocks - 1) / row_blocks);
+    if (splits > 8) splits = 8;
+    if (min_tiles != ~0u && splits > min_tiles) splits = min_tiles;
+    if (splits < 1) splits = 1;
+    uint64_t acc = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) { hp[p].row_off = acc; acc += (uint64_t)splits * hp[p].n_a_pad; }
+    const size_t pair_bytes = ((size_t)n_pairs * sizeof(MatchPair) + 255) / 256 * 256;
+    const size_t row_bytes = ((size_t)rows_total * splits * sizeof(RowBest) + 255) / 256 * 256;
+    const size_t col_bytes = (size_t)cols_total * sizeof(unsigned long long);
+    const size_t bytes = pair_bytes + row_bytes + col_bytes + 256;
+    if (bytes > ctx->match_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
+        ctx->d_match_ws = nullptr;
+        ctx->match_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
+        ctx->match_ws_bytes = bytes;
+    }
+    char* ws = (char*)ctx->d_match_ws;
+    MatchPair* d_pairs = (MatchPair*)ws;
+    RowBest* d_rows = (RowBest*)(ws + pair_bytes);
+    unsigned long long* d_cols = (unsigned long long*)(ws + pair_bytes + row_bytes);
+    HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), (size_t)n_pairs * sizeof(MatchPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
+    if (col_bytes) HIP_TRY(hipMemsetAsync(d_cols, 0xFF, col_bytes, ctx->stream));
+    if (max_rb > 0 && min_tiles != ~0u) {
+        hipLaunchKernelGGL(desc_top2_kernel, dim3(max_rb * splits, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_rows, d_cols,
+                           splits);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t np = 2;
+    while (np < max_na) np <<= 1;
+    const size_t lds = (size_t)np * sizeof(unsigned long long);
+    static_assert(PGI_DESC_MAX * sizeof(unsigned long long) <= 128 * 1024, "selection keys must fit in LDS");
+    HIP_TRY(hipFuncSetAttribute((const void*)match_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipLaunchKernelGGL(match_select_kernel, dim3(n_pairs), dim3(1024), lds, ctx->stream, d_pairs, d_rows, d_cols, splits, max_matches,
+                       d_match_src, d_match_dst, d_ratio, d_counts);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+}  // extern "C"

@@ -50,9 +50,15 @@ assert ROT_EDGE_DTYPE.itemsize == C.sizeof(RotEdge)
 SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_create", "pgi_destroy",
            "pgi_set_stream", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch",
            "pgi_estimate_pose", "pgi_score_pose_batch", "pgi_score_pose_f64", "pgi_decompose_batch",
-           "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average"]
+           "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
+           "pgi_desc_prepare", "pgi_match_descriptors_batch"]
 
 _lib = None
+
+
+class DescView(C.Structure):
+    """pgi_desc_view (include/pgi.h)."""
+    _fields_ = [("d_desc_t", C.c_void_p), ("d_norm", C.c_void_p), ("n", C.c_uint32), ("n_pad", C.c_uint32)]
 
 
 class PgiError(RuntimeError):
@@ -75,6 +81,11 @@ def load():
     lib.pgi_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.pgi_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     lib.pgi_synchronize.argtypes = [C.c_void_p]
+    lib.pgi_desc_padded.restype = C.c_uint32
+    lib.pgi_desc_padded.argtypes = [C.c_uint32]
+    lib.pgi_desc_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.pgi_match_descriptors_batch.argtypes = [C.c_void_p, C.POINTER(DescView), C.POINTER(DescView), C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]

@@ -162,6 +162,44 @@ class Engine:
                                                R.ctypes.data_as(C.c_void_p), C.byref(iters)))
         return R, iters.value
 
+    # ---- descriptor matching (feature_utils.h:135-202) ------------------------------------------
+    def prepare_descriptors(self, desc):
+        """n x 128 float32 (numpy or device tensor) -> prepared image (transposed copy + norms in HBM)."""
+        d = torch.as_tensor(np.ascontiguousarray(desc, np.float32) if isinstance(desc, np.ndarray) else desc,
+                            dtype=torch.float32, device=self.device).contiguous()
+        n = int(d.shape[0])
+        if n and d.shape[1] != 128:
+            raise ValueError("descriptors must be n x 128")
+        n_pad = int(self._lib.pgi_desc_padded(n))
+        dt = torch.empty((128, max(n_pad, 1)), dtype=torch.float32, device=self.device)
+        nrm = torch.empty(max(n_pad, 1), dtype=torch.float32, device=self.device)
+        self._bind_stream()
+        L.check(self._lib.pgi_desc_prepare(self._ctx, _ptr(d) if n else None, n, _ptr(dt), _ptr(nrm)))
+        return {"t": dt, "norm": nrm, "n": n, "n_pad": n_pad}
+
+    def match_descriptors_batch(self, images, pairs, max_matches=None, raw=False):
+        """images: list of prepared images; pairs: [(src, dst)] -> per pair (src_idx, dst_idx, ratio) sorted by ratio.
+        raw=True returns the device tensors (src, dst, ratio, counts) without a host copy."""
+        P = len(pairs)
+        if max_matches is None:
+            max_matches = max([images[s]["n"] for s, _ in pairs] + [1])
+        va, vb = (L.DescView * max(P, 1))(), (L.DescView * max(P, 1))()
+        for p, (s, d) in enumerate(pairs):
+            for v, im in ((va[p], images[s]), (vb[p], images[d])):
+                v.d_desc_t, v.d_norm, v.n, v.n_pad = im["t"].data_ptr(), im["norm"].data_ptr(), im["n"], im["n_pad"]
+        src = torch.empty((max(P, 1), max_matches), dtype=torch.int32, device=self.device)
+        dst = torch.empty_like(src)
+        ratio = torch.empty((max(P, 1), max_matches), dtype=torch.float64, device=self.device)
+        counts = torch.zeros(max(P, 1), dtype=torch.int32, device=self.device)
+        self._bind_stream()
+        L.check(self._lib.pgi_match_descriptors_batch(self._ctx, va, vb, P, max_matches, _ptr(src), _ptr(dst), _ptr(ratio),
+                                                      _ptr(counts)))
+        if raw:
+            return src, dst, ratio, counts
+        c = counts.cpu().numpy()
+        s_h, d_h, r_h = src.cpu().numpy(), dst.cpu().numpy(), ratio.cpu().numpy()
+        return [(s_h[p, :c[p]].astype(np.uint32), d_h[p, :c[p]].astype(np.uint32), r_h[p, :c[p]]) for p in range(P)]
+
     # ---- single-pair drop-in (host pointers) --------------------------------------------------
     def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
         """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""

@@ -186,3 +186,24 @@ def make_scene_graph(n_views, k=8, seed=0, median_corr=600, min_corr=60, max_cor
             b[key][a:z] = d[key]
         b["R"][e], b["t"][e] = Rij, tij
     return dict(R_gt=R_gt, pairs=pairs, sizes=sizes, batch=b, wrong=wrong)
+
+
+def make_descriptors(rng, n_a, n_b, overlap=0.6, noise=0.05, dim=128, duplicates=0):
+    """Two RootSIFT-like descriptor sets (non-negative, unit L2 norm): `overlap` of A re-appears in B, perturbed and
+    permuted; `duplicates` rows of B are exact copies of other rows (distance ties)."""
+    def unit(x):
+        x = np.abs(x).astype(np.float32)
+        return x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12).astype(np.float32)
+    A = unit(rng.standard_normal((n_a, dim)))
+    B = unit(rng.standard_normal((n_b, dim)))
+    m = int(min(n_a, n_b) * overlap)
+    ia, ib = rng.permutation(n_a)[:m], rng.permutation(n_b)[:m]
+    if m:
+        B[ib] = unit(A[ia] + noise * rng.standard_normal((m, dim)))
+    for _ in range(duplicates):
+        if n_b >= 2:
+            s, d = rng.integers(0, n_b, 2)
+            B[d] = B[s]
+    truth = np.full(n_a, -1, np.int64)
+    truth[ia] = ib
+    return A.astype(np.float32), B.astype(np.float32), truth

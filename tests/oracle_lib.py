@@ -250,3 +250,12 @@ def estimate_pose_batch(x1, y1, x2, y2, offsets, thr, prm, seed, pair_id_base=0,
                                   _p(thr), _p(g), _p(hg), C.byref(prm), C.c_uint64(seed),
                                   C.c_uint64(pair_id_base), _p(out), _p(masks), C.c_int(threads))
     return out, masks
+
+
+def match_descriptors(A, B):
+    A, B = f32(A), f32(B)
+    k1, k2, d = len(A), len(B), A.shape[1]
+    oi, oj, orr = np.zeros(k1, np.uint32), np.zeros(k1, np.uint32), np.zeros(k1)
+    lib().pgo_match_descriptors.restype = C.c_uint32
+    m = lib().pgo_match_descriptors(_p(A), C.c_uint32(k1), _p(B), C.c_uint32(k2), C.c_uint32(d), _p(oi), _p(oj), _p(orr))
+    return oi[:m], oj[:m], orr[:m]
