@@ -1123,6 +1123,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     c->max_lds = lds > 0 ? lds : 65536;
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
+    if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     return c;
 }
 

@@ -14,9 +14,8 @@
 
 namespace {
 constexpr int kD = PGI_DESC_DIM;   // 128
-constexpr int kRowsWg = 128;       // rows of A per workgroup: 4 wavefronts x one 32-row MFMA tile
+constexpr int kPadRows = 256;      // keypoint padding: the largest workgroup covers 8 wavefronts x one 32-row MFMA tile
 constexpr int kTileJ = 64;         // columns of B staged per step: 2 MFMA tiles per wavefront
-constexpr int kLdsStride = 96;     // words per k-row of the staged tile: 64 + 32, so lanes 32..63 (k odd) hit the other banks
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct RowBest {
@@ -57,17 +56,28 @@ __global__ __launch_bounds__(256) void desc_prepare_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256, 2) void desc_top2_kernel(const MatchPair* __restrict__ pairs, RowBest* __restrict__ rowpart,
-                                                           unsigned long long* __restrict__ colbest, uint32_t splits) {
-    __shared__ float bt[kD * kLdsStride];  // 48 KB
-    __shared__ unsigned long long cb[kTileJ];
-    const MatchPair P = pairs[blockIdx.y];
-    const uint32_t rb = blockIdx.x / splits, split = blockIdx.x % splits;
-    if (rb * kRowsWg >= P.n_a_pad) return;
+// One workgroup = NW wavefronts = NW*32 rows of A against one column split of B.  B tiles (64 columns x 128 k) are
+// DMA'd global -> LDS (global_load_lds_dwordx4, no staging registers) into a double buffer in MFMA operand order:
+// word s*128 + sub*64 + lane holds B[k = 2s + (lane >> 5)][tile*64 + sub*32 + (lane & 31)], so one conflict-free
+// ds_read2_b32 feeds both MFMA column tiles of step s.  One barrier per tile.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(const MatchPair* __restrict__ pairs,
+                                                                             RowBest* __restrict__ rowpart,
+                                                                             unsigned long long* __restrict__ colbest,
+                                                                             uint32_t splits, uint32_t wgs_per_pair) {
+    __shared__ float bt[2][kTileJ * kD];  // 2 x 32 KB
+    // XCD-aware order: the workgroups an XCD runs back to back are consecutive row blocks of the same pair, so the B
+    // panel they all stream stays in that XCD's L2 (bijective remap of the round-robin blockIdx -> XCD assignment)
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, qq = nwg >> 3, rr = nwg & 7u;
+    const uint32_t wgid = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const MatchPair P = pairs[wgid / wgs_per_pair];
+    const uint32_t x = wgid % wgs_per_pair, rb = x / splits, split = x % splits;
+    constexpr uint32_t kRows = NW * 32u;
+    if (rb * kRows >= P.n_a_pad) return;
     const uint32_t tiles = P.n_b_pad / kTileJ;
     const uint32_t t0 = (uint32_t)((uint64_t)tiles * split / splits), t1 = (uint32_t)((uint64_t)tiles * (split + 1) / splits);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
-    const uint32_t row_base = rb * kRowsWg + w * 32u;
+    const uint32_t row_base = rb * kRows + w * 32u;
 
     // A fragment of the whole K range: a[s] = A[row_base + c][2s + h]
     float a[kD / 2];
@@ -80,57 +90,69 @@ __global__ __launch_bounds__(256, 2) void desc_top2_kernel(const MatchPair* __re
         nar[r] = P.na[row_base + mfma_row(r, h)];
         b1[r] = INFINITY; b2[r] = INFINITY; j1[r] = 0u;
     }
-
-    for (uint32_t tile = t0; tile < t1; ++tile) {
-        __syncthreads();  // the previous tile's readers of bt / cb are done
+    // per-lane source of chunk q (1 KiB per wavefront instruction): LDS words [ch*256 + 4*lane, +4)
+    auto stage = [&](uint32_t tile, uint32_t buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t idx = tid + 256u * q, k = idx >> 4, j4 = idx & 15u;
-            const float4 v = *reinterpret_cast<const float4*>(P.bt + (size_t)k * P.n_b_pad + tile * kTileJ + 4u * j4);
-            *reinterpret_cast<float4*>(bt + k * kLdsStride + 4u * j4) = v;
+        for (int q = 0; q < 32 / NW; ++q) {
+            const uint32_t ch = (uint32_t)q * NW + w, wd = ch * 256u + 4u * lane;
+            const uint32_t s = wd >> 7, sub = (wd >> 6) & 1u, hh = (wd >> 5) & 1u, cc = wd & 31u;
+            const float* src = P.bt + (size_t)(2u * s + hh) * P.n_b_pad + tile * kTileJ + sub * 32u + cc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&bt[buf][ch * 256u]), 16, 0, 0);
         }
-        if (tid < (uint32_t)kTileJ) cb[tid] = ~0ull;
-        __syncthreads();
+    };
+    if (t0 < t1) stage(t0, 0u);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint32_t cur = (tile - t0) & 1u;
+        __syncthreads();  // tile landed in bt[cur] (vmcnt(0) precedes the barrier); everyone is done reading bt[cur ^ 1]
+        if (tile + 1 < t1) stage(tile + 1, cur ^ 1u);
+        // column state of this lane's two columns: norm and the best key so far (stale reads are conservative)
+        float nbj[2];
+        unsigned long long seen[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t j = tile * kTileJ + 32u * sub + c;
+            nbj[sub] = P.nb[j];
+            seen[sub] = __builtin_nontemporal_load(&colbest[P.col_off + j]);
+        }
+        const float* bcur = &bt[cur][lane];
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
 #pragma unroll
         for (int s = 0; s < kD / 2; ++s) {
-            const float x0 = bt[(2 * s + (int)h) * kLdsStride + c];
-            const float x1 = bt[(2 * s + (int)h) * kLdsStride + 32 + c];
+            const float x0 = bcur[s * 128], x1 = bcur[s * 128 + 64];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1, acc[1], 0, 0, 0);
         }
+        // branch-free epilogue: every update is a compare + selects
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t j = tile * kTileJ + 32u * sub + c;
-            const float nbj = P.nb[j];
             const bool jvalid = j < P.n_b;
-            unsigned long long ckey = ~0ull;
+            float cbest = INFINITY;
+            uint32_t ci = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float t = nar[r] + nbj;
-                float d2 = t - 2.0f * acc[sub][r];
+                const float t = nar[r] + nbj[sub];
+                float d2 = fmaf(-2.0f, acc[sub][r], t);  // == t - 2*acc: the product is exact
                 d2 = d2 > 0.0f ? d2 : 0.0f;
-                if (jvalid) {
-                    if (d2 < b1[r]) { b2[r] = b1[r]; b1[r] = d2; j1[r] = j; }
-                    else if (d2 < b2[r]) { b2[r] = d2; }
-                }
-                const uint32_t i = row_base + mfma_row(r, h);
-                if (i < P.n_a) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | i;
-                    ckey = key < ckey ? key : ckey;
-                }
+                const float dr = jvalid ? d2 : INFINITY;  // padded columns never enter a row's top-2
+                const bool lt1 = dr < b1[r], lt2 = dr < b2[r];
+                const float keep2 = lt2 ? dr : b2[r];
+                b2[r] = lt1 ? b1[r] : keep2;
+                b1[r] = lt1 ? dr : b1[r];
+                j1[r] = lt1 ? j : j1[r];
+                const uint32_t i = row_base + mfma_row(r, h);  // ascending in r: strict < keeps the lowest row on ties
+                const float dc = i < P.n_a ? d2 : INFINITY;
+                const bool ltc = dc < cbest;
+                cbest = ltc ? dc : cbest;
+                ci = ltc ? i : ci;
             }
+            unsigned long long ckey = ((unsigned long long)__float_as_uint(cbest) << 32) | ci;
             const unsigned long long other = __shfl_xor(ckey, 32);
             ckey = other < ckey ? other : ckey;
-            if (h == 0u && jvalid) atomicMin(&cb[32 * sub + c], ckey);
-        }
-        __syncthreads();
-        if (tid < (uint32_t)kTileJ) {
-            const uint32_t j = tile * kTileJ + tid;
-            const unsigned long long v = cb[tid];
-            if (j < P.n_b && v != ~0ull) atomicMin(&colbest[P.col_off + j], v);
+            if (h == 0u && jvalid && ckey < seen[sub]) atomicMin(&colbest[P.col_off + j], ckey);
         }
     }
     // row top-2 across the 32 lanes that share a row (same h): xor butterfly inside each half-wave
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
 }  // namespace
 
 extern "C" {
-uint32_t pgi_desc_padded(uint32_t n) { return (n + (uint32_t)kRowsWg - 1u) / (uint32_t)kRowsWg * (uint32_t)kRowsWg; }
+uint32_t pgi_desc_padded(uint32_t n) { return (n + (uint32_t)kPadRows - 1u) / (uint32_t)kPadRows * (uint32_t)kPadRows; }
 
 int pgi_desc_prepare(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_desc_t, float* d_norm) {
     if (!ctx || !d_desc_t || !d_norm || (n && !d_desc)) return pgi::fail(PGI_ERR_INVALID, "pgi_desc_prepare: null argument");
@@ -246,6 +268,7 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<MatchPair> hp(n_pairs);
+    const uint32_t nw = ctx->match_waves == 8 ? 8u : 4u, rows_wg = nw * 32u;
     uint64_t row_blocks = 0, rows_total = 0, cols_total = 0;
     uint32_t max_rb = 0, min_tiles = ~0u, max_na = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -256,7 +279,7 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
         if (a.n > PGI_DESC_MAX || b.n > PGI_DESC_MAX)
             return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_match_descriptors_batch: more than PGI_DESC_MAX keypoints");
         hp[p] = MatchPair{a.d_desc_t, a.d_norm, b.d_desc_t, b.d_norm, a.n, a.n_pad, b.n, b.n_pad, 0, cols_total};
-        const uint32_t rb = a.n_pad / kRowsWg, tiles = b.n_pad / kTileJ;
+        const uint32_t rb = a.n_pad / rows_wg, tiles = b.n_pad / kTileJ;
         row_blocks += (b.n ? rb : 0);
         max_rb = rb > max_rb ? rb : max_rb;
         if (a.n && b.n) min_tiles = tiles < min_tiles ? tiles : min_tiles;
@@ -292,8 +315,11 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
     if (col_bytes) HIP_TRY(hipMemsetAsync(d_cols, 0xFF, col_bytes, ctx->stream));
     if (max_rb > 0 && min_tiles != ~0u) {
-        hipLaunchKernelGGL(desc_top2_kernel, dim3(max_rb * splits, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_rows, d_cols,
-                           splits);
+        const uint32_t per_pair = max_rb * splits, total = per_pair * n_pairs;
+        if (nw == 8)
+            hipLaunchKernelGGL(desc_top2_kernel<8>, dim3(total), dim3(512), 0, ctx->stream, d_pairs, d_rows, d_cols, splits, per_pair);
+        else
+            hipLaunchKernelGGL(desc_top2_kernel<4>, dim3(total), dim3(256), 0, ctx->stream, d_pairs, d_rows, d_cols, splits, per_pair);
         HIP_TRY(hipGetLastError());
     }
     uint32_t np = 2;

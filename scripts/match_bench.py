@@ -1,5 +1,5 @@
 """Descriptor-matching throughput: P pairs of K x K SIFT-sized sets; reports pairs/s and the f32-MFMA roofline
-fraction (2*K_pad^2*128 flop per pair; peak 157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+fraction (2*K^2*128 flop per pair; peak 157.3 TFLOP/s, MI355X_MICROARCH.md)."""
 import os
 import sys
 import time
@@ -38,8 +38,7 @@ def main():
             out = eng.match_descriptors_batch(images, sel, raw=True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        kp = images[0]["n_pad"]
-        flop = 2.0 * kp * kp * 128 * P
+        flop = 2.0 * K * K * 128 * P          # useful flop: the padding to 256 rows is not counted
         print("K=%d pairs=%d: %.3f ms  %.1f pairs/s  %.1f TFLOP/s (%.1f%% of 157.3)  mean matches %.0f" %
               (K, P, dt * 1e3, P / dt, flop / dt / 1e12, 100 * flop / dt / 157.3e12, out[3][:P].float().mean().item()))
     t0 = time.perf_counter()
