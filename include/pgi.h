@@ -193,6 +193,27 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
                                 uint32_t n_pairs, uint32_t max_matches, uint32_t* d_match_src,
                                 uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts);
 
+/* ---- createCorrespondenceMatrix on the device (pose_graph_builder.h:864-938) ------------
+ * Turns the matcher's output into the pgi_batch the estimator consumes, without a host round
+ * trip: gathers cv::KeyPoint::pt of every match, normalises with the pinhole intrinsics
+ * K = [fx 0 cx; 0 fy cy; 0 0 1] (:286) in double, rounds to f32, normalises the threshold
+ * (:934-937) and writes the row offsets (exclusive scan of the kept counts). */
+typedef struct {
+    const float* d_xy; /* n x 2 pixel coordinates (x, y) */
+    uint32_t n;
+    uint32_t reserved;
+    double fx, fy, cx, cy;
+} pgi_keypoint_view;
+/* top_k: keep only the first top_k matches of a pair (0 = all; the tracklet path keeps 100,
+ * pose_graph_builder.h:759-772).  dst_uses_src_intrinsics = 1 reproduces :908-912.
+ * d_x1..d_y2 need room for n_pairs * min(max_matches, top_k) floats each; d_offsets n_pairs + 1;
+ * d_thr n_pairs.  Asynchronous on the stream. */
+int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, const pgi_keypoint_view* h_dst,
+                              uint32_t n_pairs, uint32_t max_matches, const uint32_t* d_match_src,
+                              const uint32_t* d_match_dst, const uint32_t* d_counts, uint32_t top_k,
+                              double thr_px, uint32_t dst_uses_src_intrinsics, float* d_x1, float* d_y1,
+                              float* d_x2, float* d_y2, uint64_t* d_offsets, double* d_thr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1239,7 +1239,6 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
     const size_t bytes = 4 * nf * 4 + 16 + 8 + 96 + 8 + sizeof(pgi_edge) + nf + 64;
     if (bytes > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
         ctx->d_scratch = nullptr;
         ctx->scratch_bytes = 0;
         HIP_TRY(hipMalloc(&ctx->d_scratch, bytes));

@@ -241,6 +241,58 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
     }
     if (tid == 0) out_count[blockIdx.x] = count;
 }
+struct KpPair {
+    const float *src, *dst;
+    uint32_t n_src, n_dst;
+    double sfx, sfy, scx, scy, dfx, dfy, dcx, dcy;
+};
+
+// exclusive scan of min(count, top_k) over the pairs: one workgroup, chunked
+__global__ __launch_bounds__(1024) void corr_offsets_kernel(const uint32_t* __restrict__ counts, uint32_t n_pairs, uint32_t top_k,
+                                                            unsigned long long* __restrict__ offsets) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry = 0ull;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_pairs; base += 1024u) {
+        const uint32_t p = base + tid;
+        const unsigned long long v = p < n_pairs ? (unsigned long long)(counts[p] < top_k ? counts[p] : top_k) : 0ull;
+        part[tid] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {
+            const unsigned long long add = tid >= d ? part[tid - d] : 0ull;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        if (p < n_pairs) offsets[p] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023u) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n_pairs] = carry;
+}
+
+__global__ __launch_bounds__(256) void corr_gather_kernel(const KpPair* __restrict__ pairs, const uint32_t* __restrict__ msrc,
+                                                          const uint32_t* __restrict__ mdst, uint32_t max_matches,
+                                                          const unsigned long long* __restrict__ offsets, double thr_px,
+                                                          float* __restrict__ x1, float* __restrict__ y1, float* __restrict__ x2,
+                                                          float* __restrict__ y2, double* __restrict__ thr) {
+    const KpPair P = pairs[blockIdx.x];
+    const unsigned long long o = offsets[blockIdx.x];
+    const uint32_t m = (uint32_t)(offsets[blockIdx.x + 1] - o);
+    for (uint32_t k = threadIdx.x; k < m; k += 256u) {
+        const uint32_t i = msrc[(size_t)blockIdx.x * max_matches + k], j = mdst[(size_t)blockIdx.x * max_matches + k];
+        const float2 a = i < P.n_src ? *reinterpret_cast<const float2*>(P.src + 2 * (size_t)i) : make_float2(NAN, NAN);
+        const float2 b = j < P.n_dst ? *reinterpret_cast<const float2*>(P.dst + 2 * (size_t)j) : make_float2(NAN, NAN);
+        x1[o + k] = (float)(((double)a.x - P.scx) / P.sfx);
+        y1[o + k] = (float)(((double)a.y - P.scy) / P.sfy);
+        x2[o + k] = (float)(((double)b.x - P.dcx) / P.dfx);
+        y2[o + k] = (float)(((double)b.y - P.dcy) / P.dfy);
+    }
+    if (threadIdx.x == 0) thr[blockIdx.x] = thr_px / ((P.sfx + P.sfy + P.dfx + P.dfy) / 4.0);
+}
 }  // namespace
 
 extern "C" {
@@ -329,6 +381,48 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
     HIP_TRY(hipFuncSetAttribute((const void*)match_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipLaunchKernelGGL(match_select_kernel, dim3(n_pairs), dim3(1024), lds, ctx->stream, d_pairs, d_rows, d_cols, splits, max_matches,
                        d_match_src, d_match_dst, d_ratio, d_counts);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, const pgi_keypoint_view* h_dst, uint32_t n_pairs,
+                              uint32_t max_matches, const uint32_t* d_match_src, const uint32_t* d_match_dst,
+                              const uint32_t* d_counts, uint32_t top_k, double thr_px, uint32_t dst_uses_src_intrinsics,
+                              float* d_x1, float* d_y1, float* d_x2, float* d_y2, uint64_t* d_offsets, double* d_thr) {
+    if (!ctx || !d_offsets) return pgi::fail(PGI_ERR_INVALID, "pgi_build_correspondences: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n_pairs == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), ctx->stream));
+        return PGI_SUCCESS;
+    }
+    if (!h_src || !h_dst || !d_match_src || !d_match_dst || !d_counts || !d_x1 || !d_y1 || !d_x2 || !d_y2 || !d_thr ||
+        max_matches == 0)
+        return pgi::fail(PGI_ERR_INVALID, "pgi_build_correspondences: null argument");
+    std::vector<KpPair> hp(n_pairs);
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const pgi_keypoint_view &a = h_src[p], &b = h_dst[p];
+        if ((a.n && !a.d_xy) || (b.n && !b.d_xy)) return pgi::fail(PGI_ERR_INVALID, "pgi_build_correspondences: bad keypoint view");
+        const pgi_keypoint_view& k = dst_uses_src_intrinsics ? a : b;  // pose_graph_builder.h:908-912 when set
+        hp[p] = KpPair{a.d_xy, b.d_xy, a.n, b.n, a.fx, a.fy, a.cx, a.cy, k.fx, k.fy, k.cx, k.cy};
+    }
+    const size_t bytes = (size_t)n_pairs * sizeof(KpPair);
+    if (bytes > ctx->match_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
+        ctx->d_match_ws = nullptr;
+        ctx->match_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
+        ctx->match_ws_bytes = bytes;
+    }
+    KpPair* d_pairs = (KpPair*)ctx->d_match_ws;
+    HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
+    const uint32_t keep = top_k ? top_k : 0xffffffffu;
+    hipLaunchKernelGGL(corr_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_counts, n_pairs, keep,
+                       (unsigned long long*)d_offsets);
+    hipLaunchKernelGGL(corr_gather_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_match_src, d_match_dst, max_matches,
+                       (const unsigned long long*)d_offsets, thr_px, d_x1, d_y1, d_x2, d_y2, d_thr);
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
 }

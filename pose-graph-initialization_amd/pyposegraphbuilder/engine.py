@@ -200,6 +200,37 @@ class Engine:
         s_h, d_h, r_h = src.cpu().numpy(), dst.cpu().numpy(), ratio.cpu().numpy()
         return [(s_h[p, :c[p]].astype(np.uint32), d_h[p, :c[p]].astype(np.uint32), r_h[p, :c[p]]) for p in range(P)]
 
+    def upload_keypoints(self, xy, f, w, h):
+        """cv::KeyPoint::pt array (n x 2 pixels) + pinhole camera K = [f 0 w/2; 0 f h/2] (pose_graph_builder.h:286)."""
+        t = torch.as_tensor(np.ascontiguousarray(xy, np.float32).reshape(-1, 2)).to(self.device)
+        return {"xy": t, "n": int(t.shape[0]), "fx": float(f), "fy": float(f), "cx": w / 2.0, "cy": h / 2.0}
+
+    def build_correspondences(self, keypoints, pairs, matches, thr_px, top_k=0, dst_uses_src_intrinsics=False, seed=0,
+                              pair_id_base=0):
+        """createCorrespondenceMatrix on the device (pose_graph_builder.h:864-938): `matches` is the raw output of
+        match_descriptors_batch(..., raw=True); returns a batch dict for estimate_pose_batch."""
+        src, dst, _, counts = matches
+        P, mm = len(pairs), int(src.shape[1])
+        va, vb = (L.KeypointView * max(P, 1))(), (L.KeypointView * max(P, 1))()
+        for p, (s, d) in enumerate(pairs):
+            for v, kp in ((va[p], keypoints[s]), (vb[p], keypoints[d])):
+                v.d_xy, v.n = (kp["xy"].data_ptr() if kp["n"] else None), kp["n"]
+                v.fx, v.fy, v.cx, v.cy = kp["fx"], kp["fy"], kp["cx"], kp["cy"]
+        cap = min(mm, top_k) if top_k else mm
+        rows = max(P * cap, 1)
+        b = dict(x1=torch.empty(rows, dtype=torch.float32, device=self.device), guesses=None, has_guess=None, n_pairs=P,
+                 max_corr=cap, seed=int(seed), pair_id_base=int(pair_id_base))
+        for k in ("y1", "x2", "y2"):
+            b[k] = torch.empty_like(b["x1"])
+        b["offsets"] = torch.zeros(P + 1, dtype=torch.int64, device=self.device)
+        b["thr"] = torch.zeros(max(P, 1), dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        L.check(self._lib.pgi_build_correspondences(
+            self._ctx, va, vb, P, mm, _ptr(src), _ptr(dst), _ptr(counts), int(top_k), float(thr_px),
+            int(bool(dst_uses_src_intrinsics)), _ptr(b["x1"]), _ptr(b["y1"]), _ptr(b["x2"]), _ptr(b["y2"]), _ptr(b["offsets"]),
+            _ptr(b["thr"])))
+        return b
+
     # ---- single-pair drop-in (host pointers) --------------------------------------------------
     def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
         """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""

@@ -207,3 +207,34 @@ def make_descriptors(rng, n_a, n_b, overlap=0.6, noise=0.05, dim=128, duplicates
     truth = np.full(n_a, -1, np.int64)
     truth[ia] = ib
     return A.astype(np.float32), B.astype(np.float32), truth
+
+
+def make_feature_views(rng, n_views=3, n_points=1500, n_clutter=500, f=1000.0, w=1600.0, h=1200.0, desc_noise=0.04,
+                       px_noise=0.3):
+    """A small scene seen by n_views cameras: every view detects a random ~75% of the 3-D points (pixel keypoints +
+    a noisy copy of the point's RootSIFT-like descriptor) plus unmatched clutter.  Returns views[v] = dict(xy, desc,
+    point_id) and the ground-truth world->camera poses."""
+    def unit(x):
+        x = np.abs(x).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    X = np.stack([rng.uniform(-2, 2, n_points), rng.uniform(-1.5, 1.5, n_points), rng.uniform(4, 8, n_points)], 1)
+    D = unit(rng.standard_normal((n_points, 128)))
+    views, poses = [], []
+    for v in range(n_views):
+        ax = rng.standard_normal(3)
+        R = rodrigues(ax / np.linalg.norm(ax), np.radians(rng.uniform(2, 12))) if v else np.eye(3)
+        t = rng.uniform(-0.6, 0.6, 3) * np.array([1, 0.5, 0.3]) if v else np.zeros(3)
+        Y = X @ R.T + t
+        px = np.stack([f * Y[:, 0] / Y[:, 2] + w / 2, f * Y[:, 1] / Y[:, 2] + h / 2], 1)
+        vis = (Y[:, 2] > 0.5) & (px[:, 0] > 0) & (px[:, 0] < w) & (px[:, 1] > 0) & (px[:, 1] < h) & (rng.random(n_points) < 0.75)
+        ids = np.nonzero(vis)[0]
+        xy = px[ids] + px_noise * rng.standard_normal((len(ids), 2))
+        desc = unit(D[ids] + desc_noise * rng.standard_normal((len(ids), 128)))
+        cxy = np.stack([rng.uniform(0, w, n_clutter), rng.uniform(0, h, n_clutter)], 1)
+        cdesc = unit(rng.standard_normal((n_clutter, 128)))
+        perm = rng.permutation(len(ids) + n_clutter)
+        views.append(dict(xy=np.concatenate([xy, cxy])[perm].astype(np.float32),
+                          desc=np.concatenate([desc, cdesc])[perm].astype(np.float32),
+                          point_id=np.concatenate([ids, -np.ones(n_clutter, np.int64)])[perm]))
+        poses.append((R, t))
+    return views, poses, (f, w, h)

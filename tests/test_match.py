@@ -107,3 +107,44 @@ def test_gpu_match_full_size_properties(eng):
     oi, oj, orr = O.match_descriptors(A[:256], B)
     got = eng.match_descriptors_batch([eng.prepare_descriptors(A[:256]), images[1]], [(0, 1)])[0]
     assert np.array_equal(got[0], oi) and np.array_equal(got[1], oj) and np.array_equal(got[2], orr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quirk,top_k", [(False, 0), (True, 0), (False, 100)])
+def test_gpu_descriptors_to_pose_on_device(eng, quirk, top_k):
+    """descriptors -> matches -> createCorrespondenceMatrix -> estimatePose without leaving the device, against the
+    same chain through the oracle: identical matches, bit-identical normalised rows and threshold, identical edges."""
+    rng = np.random.default_rng(21)
+    views, poses, cam = S.make_feature_views(rng, n_views=3)
+    pairs = [(0, 1), (0, 2), (1, 2), (2, 0)]
+    images = [eng.prepare_descriptors(v["desc"]) for v in views]
+    kps = [eng.upload_keypoints(v["xy"], *cam) for v in views]
+    raw = eng.match_descriptors_batch(images, pairs, raw=True)
+    b = eng.build_correspondences(kps, pairs, raw, thr_px=2.0, top_k=top_k, dst_uses_src_intrinsics=quirk, seed=77)
+    edges, masks = eng.estimate_pose_batch(b)
+    e = eng.edges_to_numpy(edges)
+    off = b["offsets"].cpu().numpy()
+    masks = masks.cpu().numpy()
+    x1, y1, x2, y2, thr = (b[k].cpu().numpy() for k in ("x1", "y1", "x2", "y2", "thr"))
+    rows = []
+    for p, (s, d) in enumerate(pairs):
+        oi, oj, _ = O.match_descriptors(views[s]["desc"], views[d]["desc"])
+        if top_k:
+            oi, oj = oi[:top_k], oj[:top_k]
+        assert off[p + 1] - off[p] == len(oi)
+        c, t = O.ref_normalize_corr(views[s]["xy"], views[d]["xy"], oi, oj, cam, cam, quirk, 2.0)
+        c = c.astype(np.float32)
+        sl = slice(off[p], off[p + 1])
+        assert np.array_equal(np.stack([x1[sl], y1[sl], x2[sl], y2[sl]], 1), c) and thr[p] == t
+        rows.append(c)
+    n = int(off[-1])
+    c = np.concatenate(rows)
+    oe, om = O.estimate_pose_batch(c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy(), c[:, 3].copy(), off.astype(np.uint64),
+                                   thr[:len(pairs)], O.default_params(), seed=77)
+    for k in ("status", "n_inl", "score", "iters", "E", "R", "t"):
+        assert np.array_equal(e[k], oe[k]), k
+    assert np.array_equal(masks[:n], om)
+    if not top_k:
+        for p, (s, d) in enumerate(pairs):
+            R_rel = poses[d][0] @ poses[s][0].T
+            assert e["status"][p] == 1 and S.rot_err_deg(e["R"][p].reshape(3, 3), R_rel) < 0.5
