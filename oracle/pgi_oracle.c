@@ -5,6 +5,7 @@
  * Every FP statement is one IEEE op in a fixed order (the HIP kernels mirror it).
  */
 #include "pgi_oracle.h"
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1006,5 +1007,78 @@ uint32_t pgo_match_descriptors(const float* A, uint32_t k1, const float* B, uint
         out_i[b] = vi; out_j[b] = vj; out_ratio[b] = vr;
     }
     free(na); free(nb); free(r1); free(r2); free(rj); free(c1); free(ci);
+    return m;
+}
+
+/* ======================================================================= */
+/* guided matching with a known pose: matcher.h:199-405      */
+/* ======================================================================= */
+/* F = K_dst^-T * E * K_src^-1 for pinhole K = [fx 0 cx; 0 fy cy; 0 0 1] (matcher.h:216-217), written out:
+ * K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1].  G = E * K_src^-1 first, then F = K_dst^-T * G. */
+void pgo_fundamental_from_essential(const double E[9], const double ks[4], const double kd[4], double F[9]) {
+    double G[9];
+    for (int r = 0; r < 3; ++r) {
+        G[3 * r + 0] = E[3 * r + 0] / ks[0];
+        G[3 * r + 1] = E[3 * r + 1] / ks[1];
+        G[3 * r + 2] = (E[3 * r + 2] - G[3 * r + 0] * ks[2]) - G[3 * r + 1] * ks[3];
+    }
+    for (int c = 0; c < 3; ++c) {
+        F[c] = G[c] / kd[0];
+        F[3 + c] = G[3 + c] / kd[1];
+        F[6 + c] = (G[6 + c] - F[c] * kd[2]) - F[3 + c] * kd[3];
+    }
+}
+
+/* The candidate loop of HashingBasedMatcherWithPose::match (matcher.h:333-401).  The 45 angular bins of :258-301
+ * only pre-select candidates; this restatement visits every destination keypoint in index order, which is the
+ * loop the reference keeps commented at :327 -- every point the bins would offer plus the ones they miss.
+ * Arithmetic follows the reference statement by statement: symmetric epipolar distance in pixels (:340-352), gate
+ * at 0.75^2 (:354), f32 descriptor differences squared and summed in double (:359-365), "second best" = the best
+ * before the last improvement (:367-372), the count-adapted ratio (:375-392).
+ * Returns the number of matches, in source order; ratio[] = dist_ratio_sq_adapted. */
+uint32_t pgo_guided_match(const double F[9], const float* kp1, uint32_t n1, const float* kp2, uint32_t n2,
+                          const float* d1, const float* d2, uint32_t dim, uint32_t* out_i, uint32_t* out_j,
+                          double* out_ratio) {
+    const double e11 = F[0], e12 = F[1], e13 = F[2], e21 = F[3], e22 = F[4], e23 = F[5], e31 = F[6], e32 = F[7],
+                 e33 = F[8];
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n1; ++i) {
+        const double x1 = kp1[2 * i], y1 = kp1[2 * i + 1];
+        double second = DBL_MAX, best = DBL_MAX;
+        int best_index = -1;
+        uint32_t count = 0;
+        const double rx = (e11 * x1 + e12 * y1) + e13;
+        const double ry = (e21 * x1 + e22 * y1) + e23;
+        const double b1 = rx * rx + ry * ry;
+        for (uint32_t j = 0; j < n2; ++j) {
+            const double x2 = kp2[2 * j], y2 = kp2[2 * j + 1];
+            const double rxc = (e11 * x2 + e21 * y2) + e31;
+            const double ryc = (e12 * x2 + e22 * y2) + e32;
+            const double rwc = (e13 * x2 + e23 * y2) + e33;
+            const double r = (x1 * rxc + y1 * ryc) + rwc;
+            const double a1 = rxc * rxc + ryc * ryc;
+            const double dist = ((r * r) * (a1 + b1)) / (a1 * b1);
+            if (dist >= 0.75 * 0.75) continue;
+            ++count;
+            double dd = 0.0;
+            for (uint32_t k = 0; k < dim; ++k) {
+                const float df = d1[(size_t)i * dim + k] - d2[(size_t)j * dim + k];
+                const double dv = df;
+                dd = dd + dv * dv;
+            }
+            if (dd < best) { second = best; best = dd; best_index = (int)j; }
+        }
+        double corr = 1.0;
+        if (count < 20) corr = 0.65 * 0.65;
+        if (count < 10) corr = 0.6 * 0.6;
+        if (count < 5) corr = 0.5 * 0.5;
+        if (count < 3) corr = 0.25 * 0.25;
+        const double ratio = (best / second) / corr;
+        if (ratio < 0.00001) continue;
+        if (best_index > -1 && (ratio < 0.8 * 0.8 || count == 1)) {
+            out_i[m] = i; out_j[m] = (uint32_t)best_index; out_ratio[m] = ratio;
+            ++m;
+        }
+    }
     return m;
 }

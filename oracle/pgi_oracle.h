@@ -160,6 +160,12 @@ void pgo_estimate_pose(const float* x1, const float* y1, const float* x2, const 
 uint32_t pgo_match_descriptors(const float* A, uint32_t k1, const float* B, uint32_t k2, uint32_t d,
                                uint32_t* out_i, uint32_t* out_j, double* out_ratio);
 
+/* guided matching with a known pose (matcher.h:199-405), exhaustive candidate loop; returns #matches in source order */
+void pgo_fundamental_from_essential(const double E[9], const double k_src[4], const double k_dst[4], double F[9]);
+uint32_t pgo_guided_match(const double F[9], const float* kp1, uint32_t n1, const float* kp2, uint32_t n2,
+                          const float* d1, const float* d2, uint32_t dim, uint32_t* out_i, uint32_t* out_j,
+                          double* out_ratio);
+
 /* batch over a flattened (pair,corr) SoA; OpenMP over pairs (threads<=0: all) */
 void pgo_estimate_pose_batch(const float* x1, const float* y1, const float* x2,
                              const float* y2, const uint64_t* offsets, uint32_t n_pairs,

@@ -9,6 +9,7 @@
 //   desc_top2_kernel      per (128-row block, column split): distances tile by tile, running row top-2 in
 //                         registers, column best through 64-bit atomicMin on (d2 bits, row)
 //   match_select_kernel   per pair: merge the splits, ratio + mutual test, bitonic sort by (ratio, row)
+#include <cfloat>
 #include <vector>
 #include "pgi_internal.hpp"
 
@@ -241,6 +242,159 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
     }
     if (tid == 0) out_count[blockIdx.x] = count;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// guided matching with a known pose (matcher.h:199-405)
+struct GuidedPair {
+    const float *kp1, *kp2, *d1, *d2;
+    uint32_t n1, n2;
+    double F[9];
+    uint64_t off;  // first per-source scratch slot of this pair
+};
+constexpr int kGmTile = 512;  // destination keypoints whose epipolar-line records are staged per step
+constexpr int kGmList = 32;   // candidates a thread collects before the wavefront evaluates their descriptors
+
+// One thread per source keypoint.  The per-destination part of the symmetric epipolar distance (F^T x2 and its
+// squared norm) is computed once per tile into LDS and read as a broadcast; the gate is a handful of f64 operations
+// per (i, j).  The rare survivors (~0.1 %) are queued per thread and their 128-d SSDs evaluated together, so the
+// wavefront does not run a 128-step loop for one lane at a time.  Order and arithmetic of matcher.h:333-401 are
+// kept: candidates in ascending j, f32 differences squared and summed in double, "second" = the best before the
+// last improvement.
+__global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __restrict__ pairs, int32_t* __restrict__ best_out,
+                                                          double* __restrict__ ratio_out) {
+    __shared__ double rec[kGmTile][4];
+    __shared__ uint32_t list[kGmList][256];
+    const GuidedPair P = pairs[blockIdx.y];
+    if (blockIdx.x * 256u >= P.n1) return;
+    const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid;
+    const bool active = i < P.n1;
+    const double e11 = P.F[0], e12 = P.F[1], e13 = P.F[2], e21 = P.F[3], e22 = P.F[4], e23 = P.F[5], e31 = P.F[6], e32 = P.F[7],
+                 e33 = P.F[8];
+    double x1 = 0.0, y1 = 0.0;
+    if (active) { x1 = (double)P.kp1[2 * (size_t)i]; y1 = (double)P.kp1[2 * (size_t)i + 1]; }
+    const double rx = (e11 * x1 + e12 * y1) + e13;
+    const double ry = (e21 * x1 + e22 * y1) + e23;
+    const double b1 = rx * rx + ry * ry;
+    double best = DBL_MAX, second = DBL_MAX;
+    int32_t best_index = -1;
+    uint32_t count = 0, nlist = 0;
+    const float4* arow = reinterpret_cast<const float4*>(P.d1 + (size_t)(active ? i : 0u) * kD);
+    auto flush = [&]() {
+        uint32_t longest = nlist;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
+        for (uint32_t c = 0; c < longest; ++c) {
+            if (c < nlist) {
+                const uint32_t j = list[c][tid];
+                const float4* brow = reinterpret_cast<const float4*>(P.d2 + (size_t)j * kD);
+                double dd = 0.0;
+                for (int k = 0; k < kD / 4; ++k) {
+                    const float4 a = arow[k], b = brow[k];
+                    const double v0 = (double)(a.x - b.x), v1 = (double)(a.y - b.y), v2 = (double)(a.z - b.z), v3 = (double)(a.w - b.w);
+                    dd = dd + v0 * v0;
+                    dd = dd + v1 * v1;
+                    dd = dd + v2 * v2;
+                    dd = dd + v3 * v3;
+                }
+                ++count;
+                if (dd < best) { second = best; best = dd; best_index = (int32_t)j; }
+            }
+        }
+        nlist = 0;
+    };
+    for (uint32_t j0 = 0; j0 < P.n2; j0 += (uint32_t)kGmTile) {
+        __syncthreads();
+        const uint32_t lim = P.n2 - j0 < (uint32_t)kGmTile ? P.n2 - j0 : (uint32_t)kGmTile;
+        for (uint32_t jj = tid; jj < lim; jj += 256u) {
+            const double x2 = (double)P.kp2[2 * (size_t)(j0 + jj)], y2 = (double)P.kp2[2 * (size_t)(j0 + jj) + 1];
+            const double rxc = (e11 * x2 + e21 * y2) + e31;
+            const double ryc = (e12 * x2 + e22 * y2) + e32;
+            const double rwc = (e13 * x2 + e23 * y2) + e33;
+            rec[jj][0] = rxc; rec[jj][1] = ryc; rec[jj][2] = rwc; rec[jj][3] = rxc * rxc + ryc * ryc;
+        }
+        __syncthreads();
+        for (uint32_t jj = 0; jj < lim; ++jj) {
+            const double rxc = rec[jj][0], ryc = rec[jj][1], rwc = rec[jj][2], a1 = rec[jj][3];
+            const double r = (x1 * rxc + y1 * ryc) + rwc;
+            const double num = (r * r) * (a1 + b1), den = a1 * b1;
+            // cheap sufficient test for "dist >= 0.75^2" (no division); everything else takes the exact path
+            const bool surely_far = den > 0.0 && num >= 0.57 * den;
+            if (active && !surely_far) {
+                const double dist = num / den;
+                if (!(dist >= 0.75 * 0.75)) { list[nlist][tid] = j0 + jj; ++nlist; }
+            }
+            if (__any(nlist == (uint32_t)kGmList)) flush();
+        }
+    }
+    flush();
+    if (active) {
+        double corr = 1.0;
+        if (count < 20u) corr = 0.65 * 0.65;
+        if (count < 10u) corr = 0.6 * 0.6;
+        if (count < 5u) corr = 0.5 * 0.5;
+        if (count < 3u) corr = 0.25 * 0.25;
+        const double ratio = (best / second) / corr;
+        const bool keep = !(ratio < 0.00001) && best_index > -1 && (ratio < 0.8 * 0.8 || count == 1u);
+        best_out[P.off + i] = keep ? best_index : -1;
+        ratio_out[P.off + i] = ratio;
+    }
+}
+
+// one workgroup per pair: compaction in source order, then (only if more than max_n survive) rank by (ratio, position)
+__global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* __restrict__ pairs, const int32_t* __restrict__ best_in,
+                                                             const double* __restrict__ ratio_in, uint32_t* __restrict__ ci,
+                                                             uint32_t* __restrict__ cj, double* __restrict__ cr, uint32_t max_n,
+                                                             uint32_t out_stride, uint32_t* __restrict__ out_src,
+                                                             uint32_t* __restrict__ out_dst, double* __restrict__ out_ratio,
+                                                             uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const GuidedPair P = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < P.n1; base += 1024u) {
+        const uint32_t i = base + tid;
+        const int32_t bj = i < P.n1 ? best_in[P.off + i] : -1;
+        const uint32_t v = bj >= 0 ? 1u : 0u;
+        part[tid] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {
+            const uint32_t add = tid >= d ? part[tid - d] : 0u;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        if (v) {
+            const uint32_t pos = carry + part[tid] - 1u;
+            ci[P.off + pos] = i; cj[P.off + pos] = (uint32_t)bj; cr[P.off + pos] = ratio_in[P.off + i];
+        }
+        __syncthreads();
+        if (tid == 1023u) carry += part[1023];
+        __syncthreads();
+    }
+    const uint32_t m = carry;
+    __threadfence_block();
+    __syncthreads();
+    const size_t o = (size_t)blockIdx.x * out_stride;
+    if (max_n == 0u || m <= max_n) {
+        const uint32_t lim = m < out_stride ? m : out_stride;
+        for (uint32_t k = tid; k < lim; k += 1024u) { out_src[o + k] = ci[P.off + k]; out_dst[o + k] = cj[P.off + k]; out_ratio[o + k] = cr[P.off + k]; }
+        if (tid == 0) out_count[blockIdx.x] = lim;
+    } else {
+        const uint32_t lim = max_n < out_stride ? max_n : out_stride;
+        for (uint32_t k = tid; k < m; k += 1024u) {
+            const double rk = cr[P.off + k];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < m; ++q) {
+                const double rq = cr[P.off + q];
+                rank += (rq < rk || (rq == rk && q < k)) ? 1u : 0u;
+            }
+            if (rank < lim) { out_src[o + rank] = ci[P.off + k]; out_dst[o + rank] = cj[P.off + k]; out_ratio[o + rank] = rk; }
+        }
+        if (tid == 0) out_count[blockIdx.x] = lim;
+    }
+}
+
 struct KpPair {
     const float *src, *dst;
     uint32_t n_src, n_dst;
@@ -423,6 +577,78 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
                        (unsigned long long*)d_offsets);
     hipLaunchKernelGGL(corr_gather_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_match_src, d_match_dst, max_matches,
                        (const unsigned long long*)d_offsets, thr_px, d_x1, d_y1, d_x2, d_y2, d_thr);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pgi_feature_view* h_dst, uint32_t n_pairs,
+                           const double* h_pose_Rt, uint32_t max_n, uint32_t out_stride, uint32_t* d_match_src,
+                           uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
+    if (!ctx || !d_counts) return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: null argument");
+    if (n_pairs == 0) return PGI_SUCCESS;
+    if (!h_src || !h_dst || !h_pose_Rt || !d_match_src || !d_match_dst || !d_ratio || out_stride == 0)
+        return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<GuidedPair> hp(n_pairs);
+    uint64_t total = 0;
+    uint32_t max_n1 = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const pgi_feature_view &a = h_src[p], &b = h_dst[p];
+        if ((a.n && (!a.d_xy || !a.d_desc)) || (b.n && (!b.d_xy || !b.d_desc)))
+            return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: bad feature view");
+        GuidedPair g{a.d_xy, b.d_xy, a.d_desc, b.d_desc, a.n, b.n, {}, total};
+        // E = [t]x R (pose.h:50, pose_utils.h), F = K_dst^-T E K_src^-1 (matcher.h:216-217), operation order as in the oracle
+        const double* R = h_pose_Rt + 12 * (size_t)p;
+        const double* t = R + 9;
+        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        double E[9], G[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += tx[3 * r + k] * R[3 * k + c];
+                E[3 * r + c] = s;
+            }
+        for (int r = 0; r < 3; ++r) {
+            G[3 * r + 0] = E[3 * r + 0] / a.fx;
+            G[3 * r + 1] = E[3 * r + 1] / a.fy;
+            G[3 * r + 2] = (E[3 * r + 2] - G[3 * r + 0] * a.cx) - G[3 * r + 1] * a.cy;
+        }
+        for (int c = 0; c < 3; ++c) {
+            g.F[c] = G[c] / b.fx;
+            g.F[3 + c] = G[3 + c] / b.fy;
+            g.F[6 + c] = (G[6 + c] - g.F[c] * b.cx) - g.F[3 + c] * b.cy;
+        }
+        hp[p] = g;
+        total += a.n;
+        max_n1 = a.n > max_n1 ? a.n : max_n1;
+    }
+    const size_t pair_bytes = ((size_t)n_pairs * sizeof(GuidedPair) + 255) / 256 * 256;
+    const size_t slot = ((size_t)total * 8 + 255) / 256 * 256;  // one 8-byte array of `total` entries
+    const size_t bytes = pair_bytes + 5 * slot + 256;
+    if (bytes > ctx->match_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
+        ctx->d_match_ws = nullptr;
+        ctx->match_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
+        ctx->match_ws_bytes = bytes;
+    }
+    char* ws = (char*)ctx->d_match_ws;
+    GuidedPair* d_pairs = (GuidedPair*)ws;
+    double* d_rat = (double*)(ws + pair_bytes);
+    double* d_cr = (double*)(ws + pair_bytes + slot);
+    int32_t* d_best = (int32_t*)(ws + pair_bytes + 2 * slot);
+    uint32_t* d_ci = (uint32_t*)(ws + pair_bytes + 3 * slot);
+    uint32_t* d_cj = (uint32_t*)(ws + pair_bytes + 4 * slot);
+    HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), (size_t)n_pairs * sizeof(GuidedPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
+    if (max_n1 > 0) {
+        hipLaunchKernelGGL(guided_scan_kernel, dim3((max_n1 + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_best, d_rat);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(guided_select_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_best, d_rat, d_ci, d_cj, d_cr, max_n,
+                       out_stride, d_match_src, d_match_dst, d_ratio, d_counts);
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
 }

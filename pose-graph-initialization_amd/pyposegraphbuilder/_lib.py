@@ -51,7 +51,7 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_set_stream", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch",
            "pgi_estimate_pose", "pgi_score_pose_batch", "pgi_score_pose_f64", "pgi_decompose_batch",
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
-           "pgi_desc_prepare", "pgi_match_descriptors_batch", "pgi_build_correspondences"]
+           "pgi_desc_prepare", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch"]
 
 _lib = None
 
@@ -64,6 +64,12 @@ class DescView(C.Structure):
 class KeypointView(C.Structure):
     """pgi_keypoint_view (include/pgi.h)."""
     _fields_ = [("d_xy", C.c_void_p), ("n", C.c_uint32), ("reserved", C.c_uint32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+class FeatureView(C.Structure):
+    """pgi_feature_view (include/pgi.h)."""
+    _fields_ = [("d_xy", C.c_void_p), ("d_desc", C.c_void_p), ("n", C.c_uint32), ("reserved", C.c_uint32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
 
 
@@ -95,6 +101,8 @@ def load():
     lib.pgi_build_correspondences.argtypes = [C.c_void_p, C.POINTER(KeypointView), C.POINTER(KeypointView), C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pgi_guided_match_batch.argtypes = [C.c_void_p, C.POINTER(FeatureView), C.POINTER(FeatureView), C.c_uint32, C.c_void_p,
+                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]

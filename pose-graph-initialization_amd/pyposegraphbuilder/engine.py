@@ -231,6 +231,37 @@ class Engine:
             _ptr(b["thr"])))
         return b
 
+    def upload_features(self, xy, desc, f, w, h):
+        """Keypoints (n x 2 px) + row-major descriptors (n x 128) of one image, for guided matching."""
+        kp = self.upload_keypoints(xy, f, w, h)
+        kp["desc"] = torch.as_tensor(np.ascontiguousarray(desc, np.float32).reshape(-1, 128)).to(self.device)
+        return kp
+
+    def guided_match_batch(self, features, pairs, poses_Rt, max_n=100, raw=False):
+        """HashingBasedMatcherWithPose::match + the top-N cut of guidedMatching (matcher.h:199-405,
+        pose_graph_builder.h:715-783) for every (src, dst) pair with pose (R, t) = poses_Rt[p] (12 doubles)."""
+        P = len(pairs)
+        va, vb = (L.FeatureView * max(P, 1))(), (L.FeatureView * max(P, 1))()
+        for p, (s, d) in enumerate(pairs):
+            for v, ft in ((va[p], features[s]), (vb[p], features[d])):
+                v.d_xy = ft["xy"].data_ptr() if ft["n"] else None
+                v.d_desc = ft["desc"].data_ptr() if ft["n"] else None
+                v.n, v.fx, v.fy, v.cx, v.cy = ft["n"], ft["fx"], ft["fy"], ft["cx"], ft["cy"]
+        stride = max_n if max_n else max([features[s]["n"] for s, _ in pairs] + [1])
+        pose = np.ascontiguousarray(poses_Rt, np.float64).reshape(max(P, 0), 12)
+        src = torch.empty((max(P, 1), stride), dtype=torch.int32, device=self.device)
+        dst = torch.empty_like(src)
+        ratio = torch.empty((max(P, 1), stride), dtype=torch.float64, device=self.device)
+        counts = torch.zeros(max(P, 1), dtype=torch.int32, device=self.device)
+        self._bind_stream()
+        L.check(self._lib.pgi_guided_match_batch(self._ctx, va, vb, P, pose.ctypes.data_as(C.c_void_p), int(max_n), stride,
+                                                 _ptr(src), _ptr(dst), _ptr(ratio), _ptr(counts)))
+        if raw:
+            return src, dst, ratio, counts
+        c = counts.cpu().numpy()
+        s_h, d_h, r_h = src.cpu().numpy(), dst.cpu().numpy(), ratio.cpu().numpy()
+        return [(s_h[p, :c[p]].astype(np.uint32), d_h[p, :c[p]].astype(np.uint32), r_h[p, :c[p]]) for p in range(P)]
+
     # ---- single-pair drop-in (host pointers) --------------------------------------------------
     def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
         """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""

@@ -259,3 +259,19 @@ def match_descriptors(A, B):
     lib().pgo_match_descriptors.restype = C.c_uint32
     m = lib().pgo_match_descriptors(_p(A), C.c_uint32(k1), _p(B), C.c_uint32(k2), C.c_uint32(d), _p(oi), _p(oj), _p(orr))
     return oi[:m], oj[:m], orr[:m]
+
+
+def fundamental_from_essential(E, k_src, k_dst):
+    F = np.zeros(9)
+    lib().pgo_fundamental_from_essential(_p(f64(E).ravel()), _p(f64(k_src)), _p(f64(k_dst)), _p(F))
+    return F
+
+
+def guided_match(F, kp1, kp2, d1, d2):
+    kp1, kp2, d1, d2 = f32(kp1), f32(kp2), f32(d1), f32(d2)
+    n1, n2 = len(kp1), len(kp2)
+    oi, oj, orr = np.zeros(max(n1, 1), np.uint32), np.zeros(max(n1, 1), np.uint32), np.zeros(max(n1, 1))
+    lib().pgo_guided_match.restype = C.c_uint32
+    m = lib().pgo_guided_match(_p(f64(F).ravel()), _p(kp1), C.c_uint32(n1), _p(kp2), C.c_uint32(n2), _p(d1), _p(d2),
+                               C.c_uint32(d1.shape[1] if n1 else 128), _p(oi), _p(oj), _p(orr))
+    return oi[:m], oj[:m], orr[:m]

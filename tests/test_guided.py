@@ -1,0 +1,99 @@
+"""Guided matching with a known pose (matcher.h:199-405, pose_graph_builder.h:715-783).
+
+CPU: the oracle's fundamental matrix against numpy and its candidate gate against an independent restatement.
+GPU: pgi_guided_match_batch through the C ABI == the oracle, index for index and ratio bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pyposegraphbuilder import synthetic as S
+
+
+def scene(seed, n_points=3000, n_clutter=3000, desc_noise=0.012):
+    rng = np.random.default_rng(seed)
+    views, poses, cam = S.make_feature_views(rng, n_views=3, n_points=n_points, n_clutter=n_clutter, desc_noise=desc_noise)
+    return views, poses, cam
+
+
+def rel_pose(poses, s, d):
+    R = poses[d][0] @ poses[s][0].T
+    return R, poses[d][1] - R @ poses[s][1]
+
+
+def oracle_matches(views, poses, cam, s, d, max_n):
+    R, t = rel_pose(poses, s, d)
+    E = np.zeros(9)
+    O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+    k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+    F = O.fundamental_from_essential(E, k, k)
+    oi, oj, orr = O.guided_match(F, views[s]["xy"], views[d]["xy"], views[s]["desc"], views[d]["desc"])
+    if max_n and len(oi) > max_n:                       # pose_graph_builder.h:759-772: smallest (ratio, position) first
+        order = np.lexsort((np.arange(len(oi)), orr))[:max_n]
+        oi, oj, orr = oi[order], oj[order], orr[order]
+    return oi, oj, orr, F
+
+
+def test_oracle_fundamental_and_gate():
+    views, poses, cam = scene(31, 1500, 1500)
+    oi, oj, orr, F = oracle_matches(views, poses, cam, 0, 1, 0)
+    k = np.array([[cam[0], 0, cam[1] / 2], [0, cam[0], cam[2] / 2], [0, 0, 1.0]])
+    R, t = rel_pose(poses, 0, 1)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    assert np.allclose(F.reshape(3, 3), np.linalg.inv(k).T @ (tx @ R) @ np.linalg.inv(k), rtol=1e-12, atol=1e-18)
+    assert len(oi) > 100
+    # every match obeys the epipolar gate (independent float64 evaluation) and the planted correspondences dominate
+    x1 = np.c_[views[0]["xy"][oi].astype(float), np.ones(len(oi))]
+    x2 = np.c_[views[1]["xy"][oj].astype(float), np.ones(len(oi))]
+    Fm = F.reshape(3, 3)
+    l2, l1 = x1 @ Fm.T, x2 @ Fm
+    r = np.einsum("ij,ij->i", x2, l2)
+    d = r * r * ((l1[:, 0] ** 2 + l1[:, 1] ** 2) + (l2[:, 0] ** 2 + l2[:, 1] ** 2)) / ((l1[:, 0] ** 2 + l1[:, 1] ** 2) * (l2[:, 0] ** 2 + l2[:, 1] ** 2))
+    assert np.all(d < 0.75 ** 2 * (1 + 1e-9))
+    pid0, pid1 = views[0]["point_id"][oi], views[1]["point_id"][oj]
+    assert (pid0 == pid1).mean() > 0.98
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pyposegraphbuilder import Engine
+    e = Engine()
+    yield e
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_n", [0, 100])
+def test_gpu_guided_match_bit_exact(eng, max_n):
+    views, poses, cam = scene(32)
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+    pairs = [(0, 1), (1, 0), (0, 2), (2, 1)]
+    rt = np.array([np.r_[rel_pose(poses, s, d)[0].ravel(), rel_pose(poses, s, d)[1]] for s, d in pairs])
+    got = eng.guided_match_batch(feats, pairs, rt, max_n=max_n)
+    for (s, d), (gi, gj, gr) in zip(pairs, got):
+        oi, oj, orr, _ = oracle_matches(views, poses, cam, s, d, max_n)
+        assert len(oi) > (50 if max_n else 300)
+        assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gr, orr), (s, d)
+
+
+@pytest.mark.gpu
+def test_gpu_guided_match_degenerate_inputs(eng):
+    """Empty images, a zero pose (F = 0: every distance is NaN, every destination point becomes a candidate and the
+    per-thread queues overflow repeatedly), and a pure-rotation pose (E = 0)."""
+    views, poses, cam = scene(33, 300, 300)
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+    empty = eng.upload_features(np.zeros((0, 2), np.float32), np.zeros((0, 128), np.float32), *cam)
+    feats.append(empty)
+    pairs = [(0, 3), (3, 0), (0, 1), (1, 2)]
+    rt = np.zeros((4, 12))
+    rt[3, :9] = np.eye(3).ravel()
+    got = eng.guided_match_batch(feats, pairs, rt, max_n=0)
+    assert len(got[0][0]) == 0 and len(got[1][0]) == 0
+    for p in (2, 3):
+        s, d = pairs[p]
+        R, t = rt[p, :9].reshape(3, 3), rt[p, 9:]
+        E = np.zeros(9)
+        O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+        k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+        oi, oj, orr = O.guided_match(O.fundamental_from_essential(E, k, k), views[s]["xy"], views[d]["xy"],
+                                     views[s]["desc"], views[d]["desc"])
+        assert np.array_equal(got[p][0], oi) and np.array_equal(got[p][1], oj) and np.array_equal(got[p][2], orr)
