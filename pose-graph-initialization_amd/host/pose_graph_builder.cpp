@@ -1,6 +1,7 @@
 // pose_graph_builder.cpp -- implementation of the C++ host layer (links against libpgi.so).
 // HIP is used here for device buffers and copies only; every computation is a C-ABI call.
 #include "graph_traversal.hpp"
+#include "tracklets.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -202,6 +203,255 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         if (wave.size() == waveSize) flush();
     }
     flush();
+    return st;
+}
+
+PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeatures>& views,
+                                                                          std::vector<CandidatePair>& cand,
+                                                                          PoseGraph& poseGraph_, size_t waveSize,
+                                                                          const SimilarityTable* similarityTable) {
+    FeatureRunStatistics st;
+    pgi_ctx* ctx = engine->get();
+    // features resident in HBM for the whole run: keypoints, row-major descriptors (guided matching) and the
+    // transposed copy + norms (brute-force matching)
+    const size_t V = views.size();
+    std::vector<std::unique_ptr<DevBuf>> dxy(V), ddesc(V), ddt(V), dnorm(V);
+    std::vector<pgi_desc_view> descView(V);
+    std::vector<pgi_keypoint_view> kpView(V);
+    std::vector<pgi_feature_view> featView(V);
+    for (size_t v = 0; v < V; ++v) {
+        const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
+        if (views[v].descriptors.size() != (size_t)n * PGI_DESC_DIM) throw PgiError("processFeatures: descriptors must be n x 128");
+        dxy[v].reset(new DevBuf((size_t)n * 8));
+        ddesc[v].reset(new DevBuf((size_t)n * PGI_DESC_DIM * 4));
+        ddt[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 4));
+        dnorm[v].reset(new DevBuf((size_t)n_pad * 4));
+        h2d(dxy[v]->p, views[v].keypoints.data(), (size_t)n * 8);
+        h2d(ddesc[v]->p, views[v].descriptors.data(), (size_t)n * PGI_DESC_DIM * 4);
+        Engine::check(pgi_desc_prepare(ctx, ddesc[v]->as<float>(), n, ddt[v]->as<float>(), dnorm[v]->as<float>()));
+        const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
+        descView[v] = pgi_desc_view{ddt[v]->as<float>(), dnorm[v]->as<float>(), n, n_pad};
+        kpView[v] = pgi_keypoint_view{dxy[v]->as<float>(), n, 0, f, f, cx, cy};
+        featView[v] = pgi_feature_view{dxy[v]->as<float>(), ddesc[v]->as<float>(), n, 0, f, f, cx, cy};
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const CandidatePair& a, const CandidatePair& b) {
+        if (a.similarity != b.similarity) return a.similarity > b.similarity;
+        return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);
+    });
+    VisibilityTable visibilityTable(V);  // :366-367
+    for (const EdgeId& id : poseGraph_.getEdgeIds()) visibilityTable.addLink(id.first, id.second);
+    Tracklets tracks(V);                 // :388
+    const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
+    uint64_t seed = 0;
+    typedef std::vector<Tracklets::Match> Matches;
+
+    auto processWave = [&](const std::vector<CandidatePair>& wave) {
+        const size_t P = wave.size();
+        if (!P) return;
+        // (1) quick matching from tracklets for pairs the graph already connects (:493-518)
+        std::vector<Matches> matches(P);
+        std::vector<char> quick(P, 0), visible(P, 0);
+        for (size_t i = 0; i < P; ++i) {
+            visible[i] = visibilityTable.hasLink(wave[i].src, wave[i].dst);
+            if (kUseEpipolarHashing && visible[i]) {
+                tracks.getCorrespondences(matches[i], wave[i].src, wave[i].dst, kMaximumTrackletNumber);
+                if (matches[i].size() < kMinimumInlierNumber) matches[i].clear();
+                else { quick[i] = 1; ++st.quickMatchingRuns; }
+            }
+        }
+        // batch order: descriptor-matched pairs first (the matcher writes rows 0..Pn-1), tracklet pairs after them
+        std::vector<size_t> order;
+        for (size_t i = 0; i < P; ++i) if (!quick[i]) order.push_back(i);
+        const size_t Pn = order.size();
+        for (size_t i = 0; i < P; ++i) if (quick[i]) order.push_back(i);
+        uint32_t mm = 1;
+        for (size_t k = 0; k < P; ++k) {
+            const size_t i = order[k];
+            mm = std::max(mm, quick[i] ? (uint32_t)matches[i].size() : (uint32_t)views[wave[i].src].size());
+        }
+        DevBuf dsrc(P * (size_t)mm * 4), ddst(P * (size_t)mm * 4), dratio(P * (size_t)mm * 8), dcnt(P * 4);
+        std::vector<uint32_t> hsrc(P * (size_t)mm), hdst(P * (size_t)mm), hcnt(P, 0);
+        // (2) descriptor matching for the others, one launch sequence (:521-546)
+        if (Pn) {
+            std::vector<pgi_desc_view> a(Pn), b(Pn);
+            for (size_t k = 0; k < Pn; ++k) { a[k] = descView[wave[order[k]].src]; b[k] = descView[wave[order[k]].dst]; }
+            Engine::check(pgi_match_descriptors_batch(ctx, a.data(), b.data(), (uint32_t)Pn, mm, dsrc.as<uint32_t>(), ddst.as<uint32_t>(),
+                                                      dratio.as<double>(), dcnt.as<uint32_t>()));
+            Engine::check(pgi_synchronize(ctx));
+            d2h(hcnt.data(), dcnt.p, Pn * 4);
+            d2h(hsrc.data(), dsrc.p, Pn * (size_t)mm * 4);
+            d2h(hdst.data(), ddst.p, Pn * (size_t)mm * 4);
+            st.matchingRuns += Pn;
+            for (size_t k = 0; k < Pn; ++k) {
+                Matches& m = matches[order[k]];
+                m.resize(hcnt[k]);
+                for (uint32_t q = 0; q < hcnt[k]; ++q) m[q] = Tracklets::Match(hsrc[k * (size_t)mm + q], hdst[k * (size_t)mm + q], 0.0);
+            }
+        }
+        for (size_t k = Pn; k < P; ++k) {  // tracklet matches join the same device layout
+            const Matches& m = matches[order[k]];
+            hcnt[k] = (uint32_t)m.size();
+            for (size_t q = 0; q < m.size(); ++q) {
+                hsrc[k * (size_t)mm + q] = (uint32_t)std::get<0>(m[q]);
+                hdst[k * (size_t)mm + q] = (uint32_t)std::get<1>(m[q]);
+            }
+        }
+        std::vector<char> skipped(P, 0);
+        for (size_t k = 0; k < P; ++k)
+            if (hcnt[k] < kMinimumPointNumber) { skipped[k] = 1; hcnt[k] = 0; ++st.tooFewMatches; }  // :550-551 `continue`
+        if (P > Pn) {
+            h2d((char*)dsrc.p + Pn * (size_t)mm * 4, hsrc.data() + Pn * (size_t)mm, (P - Pn) * (size_t)mm * 4);
+            h2d((char*)ddst.p + Pn * (size_t)mm * 4, hdst.data() + Pn * (size_t)mm, (P - Pn) * (size_t)mm * 4);
+        }
+        h2d(dcnt.p, hcnt.data(), P * 4);
+        // (3) createCorrespondenceMatrix on the device (:553-565)
+        std::vector<pgi_keypoint_view> ka(P), kb(P);
+        for (size_t k = 0; k < P; ++k) { ka[k] = kpView[wave[order[k]].src]; kb[k] = kpView[wave[order[k]].dst]; }
+        const size_t cap = P * (size_t)mm;
+        DevBuf dx1(cap * 4), dy1(cap * 4), dx2(cap * 4), dy2(cap * 4), doff((P + 1) * 8), dthr(P * 8), dguess(P * 96), dhas(P),
+            dedges(P * sizeof(pgi_edge)), dmasks(cap);
+        Engine::check(pgi_build_correspondences(ctx, ka.data(), kb.data(), (uint32_t)P, mm, dsrc.as<uint32_t>(), ddst.as<uint32_t>(),
+                                                dcnt.as<uint32_t>(), 0, kInlierOutlierThreshold, 0, dx1.as<float>(), dy1.as<float>(),
+                                                dx2.as<float>(), dy2.as<float>(), doff.as<uint64_t>(), dthr.as<double>()));
+        pgi_batch b{};
+        b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
+        b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
+        b.n_pairs = (uint32_t)P; b.max_corr = mm; b.pair_id_base = 0; b.seed = seed++;
+        // (4) A* pose guesses on the graph committed by earlier waves (:568-599), screened in one launch (:798-811)
+        std::vector<double> guess(12 * P, 0.0);
+        std::vector<uint8_t> has(P, 0);
+        bool anyGuess = false;
+        if (pathFinding) {
+            ImageSimilarityHeuristics heuristics(*similarityTable);
+            AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
+                                                                kMaximumSearchDepth);
+            for (size_t k = 0; k < P; ++k) {
+                const size_t i = order[k];
+                if (!visible[i] || skipped[k]) continue;
+                std::vector<ViewId> path;
+                std::vector<SE3d> poses;
+                size_t touched = 0, found = 0;
+                bool exists = false;
+                traversal.getPath(wave[i].src, wave[i].dst, path, poses, touched, found, exists);
+                ++st.pathsSearched;
+                st.touchedNodes += touched;
+                st.pathsFound += found;
+                if (poses.empty()) continue;
+                for (int c = 0; c < 9; ++c) guess[12 * k + c] = poses.back().R[c];
+                for (int c = 0; c < 3; ++c) guess[12 * k + 9 + c] = poses.back().t[c];
+                has[k] = 1;
+                anyGuess = true;
+            }
+        }
+        if (anyGuess) {
+            std::vector<double> thr(P), Eg(9 * P, 0.0), tau2(P, 0.0);
+            Engine::check(pgi_synchronize(ctx));
+            d2h(thr.data(), dthr.p, P * 8);
+            for (size_t k = 0; k < P; ++k) {
+                if (!has[k]) { Eg[9 * k] = 1.0; continue; }
+                SE3d g;
+                for (int c = 0; c < 9; ++c) g.R[c] = guess[12 * k + c];
+                for (int c = 0; c < 3; ++c) g.t[c] = guess[12 * k + 9 + c];
+                const Matrix3d E = pose::getEssentialMatrixFromRelativePose(g);
+                for (int c = 0; c < 9; ++c) Eg[9 * k + c] = E[c];
+                tau2[k] = (1.5 * thr[k]) * (1.5 * thr[k]);
+            }
+            DevBuf dE(P * 72), dtau(P * 8), dscore(P * 4);
+            h2d(dE.p, Eg.data(), P * 72);
+            h2d(dtau.p, tau2.data(), P * 8);
+            Engine::check(pgi_score_pose_batch(ctx, &b, dE.as<double>(), dtau.as<double>(), dscore.as<uint32_t>(), nullptr));
+            Engine::check(pgi_synchronize(ctx));
+            std::vector<uint32_t> cnt(P);
+            d2h(cnt.data(), dscore.p, P * 4);
+            for (size_t k = 0; k < P; ++k)
+                if (has[k] && cnt[k] < 5) has[k] = 0;
+            h2d(dguess.p, guess.data(), P * 96);
+            h2d(dhas.p, has.data(), P);
+            b.d_guess_Rt = dguess.as<double>();
+            b.d_has_guess = dhas.as<uint8_t>();
+        }
+        // (5) estimatePose for the whole wave (:616-627)
+        Engine::check(pgi_estimate_pose_batch(ctx, &b, dedges.as<pgi_edge>(), dmasks.as<uint8_t>()));
+        Engine::check(pgi_synchronize(ctx));
+        std::vector<pgi_edge> edges(P);
+        std::vector<uint64_t> off(P + 1);
+        d2h(edges.data(), dedges.p, P * sizeof(pgi_edge));
+        d2h(off.data(), doff.p, (P + 1) * 8);
+        std::vector<uint8_t> masks((size_t)off[P]);
+        d2h(masks.data(), dmasks.p, masks.size());
+        // (6) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
+        std::vector<size_t> guidedOf;
+        std::vector<pgi_feature_view> ga, gb;
+        std::vector<double> gpose;
+        for (size_t k = Pn; k < P; ++k) {
+            if (skipped[k] || edges[k].status != PGI_EDGE_OK) continue;
+            guidedOf.push_back(k);
+            ga.push_back(featView[wave[order[k]].src]);
+            gb.push_back(featView[wave[order[k]].dst]);
+            for (int c = 0; c < 9; ++c) gpose.push_back(edges[k].R[c]);
+            for (int c = 0; c < 3; ++c) gpose.push_back(edges[k].t[c]);
+        }
+        const uint32_t gstride = (uint32_t)std::max<size_t>(1, kMaximumPointNumberForEpipolarHashing);
+        std::vector<uint32_t> gsrc, gdst, gcnt;
+        if (!guidedOf.empty()) {
+            const size_t G = guidedOf.size();
+            DevBuf ds(G * (size_t)gstride * 4), dd(G * (size_t)gstride * 4), dr(G * (size_t)gstride * 8), dc(G * 4);
+            Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), gstride, gstride, ds.as<uint32_t>(),
+                                                 dd.as<uint32_t>(), dr.as<double>(), dc.as<uint32_t>()));
+            Engine::check(pgi_synchronize(ctx));
+            gsrc.resize(G * (size_t)gstride); gdst.resize(G * (size_t)gstride); gcnt.resize(G);
+            d2h(gsrc.data(), ds.p, gsrc.size() * 4);
+            d2h(gdst.data(), dd.p, gdst.size() * 4);
+            d2h(gcnt.data(), dc.p, G * 4);
+            st.guidedMatchingRuns += G;
+        }
+        // (7) commit in wave order: edge (:645-654), visibility (:692), tracklets (:677-681, :702-709)
+        std::vector<size_t> slotOf(P);
+        for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
+        size_t g = 0;
+        std::vector<size_t> guidedSlot(P, (size_t)-1);
+        for (size_t q = 0; q < guidedOf.size(); ++q) guidedSlot[guidedOf[q]] = q;
+        (void)g;
+        for (size_t i = 0; i < P; ++i) {
+            const size_t k = slotOf[i];
+            ++st.pairsProcessed;
+            if (skipped[k]) continue;
+            st.hypotheses += edges[k].iters;
+            st.posesFromGuess += edges[k].used_guess;
+            if (edges[k].status != PGI_EDGE_OK) continue;  // :641-642
+            SE3d T;
+            for (int c = 0; c < 9; ++c) T.R[c] = edges[k].R[c];
+            for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
+            poseGraph_.addVertex(wave[i].src);
+            poseGraph_.addVertex(wave[i].dst);
+            poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matches[i].size());
+            ++st.edgesAdded;
+            visibilityTable.addLink(wave[i].src, wave[i].dst);
+            if (!kUseEpipolarHashing) continue;
+            if (quick[i]) {
+                const size_t q = guidedSlot[k];
+                Matches extra(gcnt[q]);
+                for (uint32_t r = 0; r < gcnt[q]; ++r) extra[r] = Tracklets::Match(gsrc[q * (size_t)gstride + r], gdst[q * (size_t)gstride + r], 0.0);
+                tracks.add(wave[i].src, wave[i].dst, extra, std::vector<uchar>(extra.size(), 1));
+                st.guidedMatchesAdded += extra.size();
+            } else {
+                const std::vector<uchar> mask(masks.begin() + (size_t)off[k], masks.begin() + (size_t)off[k + 1]);
+                tracks.add(wave[i].src, wave[i].dst, matches[i], mask);
+            }
+        }
+        ++st.waves;
+    };
+
+    std::vector<CandidatePair> wave;
+    for (const CandidatePair& cp : cand) {
+        if (cp.similarity < kSimilarityThreshold) break;
+        if (cp.src >= V || cp.dst >= V) throw PgiError("processFeatures: view index out of range");
+        if (poseGraph_.hasEdge(cp.src, cp.dst) || poseGraph_.hasEdge(cp.dst, cp.src)) continue;  // :426-431
+        wave.push_back(cp);
+        if (wave.size() == waveSize) { processWave(wave); wave.clear(); }
+    }
+    processWave(wave);
+    st.trackNumber = tracks.trackNumber();
     return st;
 }
 

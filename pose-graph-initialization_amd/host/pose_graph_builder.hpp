@@ -389,6 +389,31 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     RunStatistics run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096,
                       const class SimilarityTable* similarityTable = nullptr);
 
+    // ---- the loop body of processImages on in-memory features (pose_graph_builder.h:391-709 minus file I/O) ----
+    // What loadFeatures returns for one image (:463-482) plus its pinhole camera K = [f 0 w/2; 0 f h/2; 0 0 1] (:286).
+    struct ViewFeatures {
+        std::vector<float> keypoints;    // n x 2 pixel coordinates (cv::KeyPoint::pt)
+        std::vector<float> descriptors;  // n x 128 RootSIFT, row-major
+        double focalLength = 1.0, width = 0.0, height = 0.0;
+        size_t size() const { return keypoints.size() / 2; }
+    };
+    struct CandidatePair {
+        ViewId src, dst;
+        double similarity;
+    };
+    struct FeatureRunStatistics : RunStatistics {  // the "[Matching]", "[Quick matching]", "[Epipolar Hashing]" keys
+        size_t matchingRuns = 0, quickMatchingRuns = 0, guidedMatchingRuns = 0, guidedMatchesAdded = 0, trackNumber = 0,
+               tooFewMatches = 0;
+    };
+    // Per wave of candidate pairs (descending similarity): tracklet correspondences for pairs the graph already
+    // connects (:493-518), descriptor matching for the rest (:521-546), createCorrespondenceMatrix (:553-565), A*
+    // pose guesses (:568-599), estimatePose (:616-627), edge + visibility update (:645-654, :692), guided matching
+    // and tracklet update (:657-709).  Matching, correspondence building, guess screening, pose estimation and guided
+    // matching are one device launch sequence per wave; tracklets, A* and the graph stay on the host.
+    FeatureRunStatistics processFeatures(const std::vector<ViewFeatures>& views, std::vector<CandidatePair>& candidatePairs,
+                                         PoseGraph& poseGraph_, size_t waveSize = 1024,
+                                         const class SimilarityTable* similarityTable = nullptr);
+
     Engine& getEngine() { return *engine; }
 
    protected:

@@ -4,6 +4,7 @@
 #include <fstream>
 
 #include "graph_traversal.hpp"
+#include "tracklets.hpp"
 #include "utils.hpp"
 
 using namespace reconstruction;
@@ -36,8 +37,44 @@ static int formats(char** argv) {
     return 0;
 }
 
+// mode "tracklets": <commands.txt> <out.txt>; commands: "add src dst m  p1 p2 keep ..." | "get src dst max"
+static int tracklets(char** argv) {
+    std::FILE* in = std::fopen(argv[2], "r");
+    std::FILE* out = std::fopen(argv[3], "w");
+    if (!in || !out) return 3;
+    Tracklets tr(64);
+    char cmd[8];
+    while (std::fscanf(in, "%7s", cmd) == 1) {
+        size_t a, b, m;
+        if (std::fscanf(in, "%zu %zu %zu", &a, &b, &m) != 3) return 4;
+        if (cmd[0] == 'a') {
+            std::vector<Tracklets::Match> matches(m);
+            std::vector<unsigned char> mask(m);
+            for (size_t k = 0; k < m; ++k) {
+                size_t p1, p2;
+                int keep;
+                if (std::fscanf(in, "%zu %zu %d", &p1, &p2, &keep) != 3) return 4;
+                matches[k] = Tracklets::Match(p1, p2, 0.0);
+                mask[k] = (unsigned char)keep;
+            }
+            tr.add(a, b, matches, mask);
+            std::fprintf(out, "tracks %zu\n", tr.trackNumber());
+        } else {
+            std::vector<Tracklets::Match> got;
+            tr.getCorrespondences(got, a, b, m);
+            std::fprintf(out, "get %zu", got.size());
+            for (auto& g : got) std::fprintf(out, " %zu %zu", std::get<0>(g), std::get<1>(g));
+            std::fprintf(out, "\n");
+        }
+    }
+    std::fclose(in);
+    std::fclose(out);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 7 && std::string(argv[1]) == "formats") return formats(argv);
+    if (argc >= 4 && std::string(argv[1]) == "tracklets") return tracklets(argv);
     if (argc < 3) return 2;
     std::ifstream in(argv[1], std::ios::binary);
     uint32_t V, E, Q;
