@@ -209,7 +209,8 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
 PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeatures>& views,
                                                                           std::vector<CandidatePair>& cand,
                                                                           PoseGraph& poseGraph_, size_t waveSize,
-                                                                          const SimilarityTable* similarityTable) {
+                                                                          const SimilarityTable* similarityTable,
+                                                                          const MatchLookup* cachedMatches) {
     FeatureRunStatistics st;
     pgi_ctx* ctx = engine->get();
     // features resident in HBM for the whole run: keypoints, row-major descriptors (guided matching) and the
@@ -250,24 +251,28 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         if (!P) return;
         // (1) quick matching from tracklets for pairs the graph already connects (:493-518)
         std::vector<Matches> matches(P);
-        std::vector<char> quick(P, 0), visible(P, 0);
+        std::vector<char> quick(P, 0), visible(P, 0), fromHost(P, 0);
         for (size_t i = 0; i < P; ++i) {
             visible[i] = visibilityTable.hasLink(wave[i].src, wave[i].dst);
             if (kUseEpipolarHashing && visible[i]) {
                 tracks.getCorrespondences(matches[i], wave[i].src, wave[i].dst, kMaximumTrackletNumber);
                 if (matches[i].size() < kMinimumInlierNumber) matches[i].clear();
-                else { quick[i] = 1; ++st.quickMatchingRuns; }
+                else { quick[i] = fromHost[i] = 1; ++st.quickMatchingRuns; }
+            }
+            if (!quick[i] && cachedMatches && (*cachedMatches)(wave[i].src, wave[i].dst, matches[i])) {  // feature_utils.h:115-133
+                fromHost[i] = 1;
+                ++st.cachedMatchLoads;
             }
         }
-        // batch order: descriptor-matched pairs first (the matcher writes rows 0..Pn-1), tracklet pairs after them
+        // batch order: descriptor-matched pairs first (the matcher writes rows 0..Pn-1), host-provided matches after them
         std::vector<size_t> order;
-        for (size_t i = 0; i < P; ++i) if (!quick[i]) order.push_back(i);
+        for (size_t i = 0; i < P; ++i) if (!fromHost[i]) order.push_back(i);
         const size_t Pn = order.size();
-        for (size_t i = 0; i < P; ++i) if (quick[i]) order.push_back(i);
+        for (size_t i = 0; i < P; ++i) if (fromHost[i]) order.push_back(i);
         uint32_t mm = 1;
         for (size_t k = 0; k < P; ++k) {
             const size_t i = order[k];
-            mm = std::max(mm, quick[i] ? (uint32_t)matches[i].size() : (uint32_t)views[wave[i].src].size());
+            mm = std::max(mm, fromHost[i] ? (uint32_t)matches[i].size() : (uint32_t)views[wave[i].src].size());
         }
         DevBuf dsrc(P * (size_t)mm * 4), ddst(P * (size_t)mm * 4), dratio(P * (size_t)mm * 8), dcnt(P * 4);
         std::vector<uint32_t> hsrc(P * (size_t)mm), hdst(P * (size_t)mm), hcnt(P, 0);
@@ -384,7 +389,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         std::vector<pgi_feature_view> ga, gb;
         std::vector<double> gpose;
         for (size_t k = Pn; k < P; ++k) {
-            if (skipped[k] || edges[k].status != PGI_EDGE_OK) continue;
+            if (skipped[k] || edges[k].status != PGI_EDGE_OK || !quick[order[k]]) continue;
             guidedOf.push_back(k);
             ga.push_back(featView[wave[order[k]].src]);
             gb.push_back(featView[wave[order[k]].dst]);
@@ -408,10 +413,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         // (7) commit in wave order: edge (:645-654), visibility (:692), tracklets (:677-681, :702-709)
         std::vector<size_t> slotOf(P);
         for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
-        size_t g = 0;
         std::vector<size_t> guidedSlot(P, (size_t)-1);
         for (size_t q = 0; q < guidedOf.size(); ++q) guidedSlot[guidedOf[q]] = q;
-        (void)g;
         for (size_t i = 0; i < P; ++i) {
             const size_t k = slotOf[i];
             ++st.pairsProcessed;

@@ -19,6 +19,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -403,16 +404,20 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     };
     struct FeatureRunStatistics : RunStatistics {  // the "[Matching]", "[Quick matching]", "[Epipolar Hashing]" keys
         size_t matchingRuns = 0, quickMatchingRuns = 0, guidedMatchingRuns = 0, guidedMatchesAdded = 0, trackNumber = 0,
-               tooFewMatches = 0;
+               tooFewMatches = 0, cachedMatchLoads = 0;
     };
     // Per wave of candidate pairs (descending similarity): tracklet correspondences for pairs the graph already
     // connects (:493-518), descriptor matching for the rest (:521-546), createCorrespondenceMatrix (:553-565), A*
     // pose guesses (:568-599), estimatePose (:616-627), edge + visibility update (:645-654, :692), guided matching
     // and tracklet update (:657-709).  Matching, correspondence building, guess screening, pose estimation and guided
     // matching are one device launch sequence per wave; tracklets, A* and the graph stay on the host.
+    // cachedMatches (optional): the correspondences.h5 lookup of matchFeatures (feature_utils.h:113-133) -- returns
+    // true and fills the (src index, dst index, ratio) list when the pair's matches are already known.
+    typedef std::function<bool(ViewId, ViewId, std::vector<std::tuple<size_t, size_t, double>>&)> MatchLookup;
     FeatureRunStatistics processFeatures(const std::vector<ViewFeatures>& views, std::vector<CandidatePair>& candidatePairs,
                                          PoseGraph& poseGraph_, size_t waveSize = 1024,
-                                         const class SimilarityTable* similarityTable = nullptr);
+                                         const class SimilarityTable* similarityTable = nullptr,
+                                         const MatchLookup* cachedMatches = nullptr);
 
     Engine& getEngine() { return *engine; }
 

@@ -56,7 +56,7 @@ class Engine:
             x2=torch.from_numpy(np.ascontiguousarray(x2, np.float32)).to(dev),
             y2=torch.from_numpy(np.ascontiguousarray(y2, np.float32)).to(dev),
             offsets=torch.from_numpy(off.view(np.int64)).to(dev),
-            thr=torch.from_numpy(np.ascontiguousarray(np.broadcast_to(thr, (P,)), np.float64)).to(dev),
+            thr=torch.from_numpy(np.array(np.broadcast_to(thr, (P,)), np.float64)).to(dev),
             guesses=None, has_guess=None, n_pairs=P,
             max_corr=int(np.diff(off.astype(np.int64)).max()) if P else 0,
             seed=int(seed), pair_id_base=int(pair_id_base))

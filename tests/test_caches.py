@@ -1,0 +1,52 @@
+"""HDF5 caches of the reference (image_data.h5 / keypoints.h5 / correspondences.h5) and the workspace
+runner mirroring PoseGraphBuilder::run (pose_graph_builder.h:173-239).  Optional component: skipped where the HDF5 C
+library is absent (the driver is then not built)."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+import test_feature_pipeline as FP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_caches")
+needs_hdf5 = pytest.mark.skipif(not os.path.exists(EXE), reason="HDF5 C library not available: test_caches not built")
+
+
+@needs_hdf5
+def test_hdf5_datasets_round_trip(tmp_path):
+    r = subprocess.run([EXE, "roundtrip", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "roundtrip ok" in r.stdout, (r.returncode, r.stderr)
+    # the files are genuine HDF5 (signature) and hold what the reference's readers look up
+    for name in ("keypoints.h5", "image_data.h5", "correspondences.h5"):
+        assert open(tmp_path / name, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    blob = open(tmp_path / "keypoints.h5", "rb").read()
+    assert b"feat_img_a" in blob and b"desc_img_a" in blob and b"finished" in blob
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_workspace_run_equals_in_memory_run(tmp_path):
+    views, poses, cam, sim, pairs = FP.make_scene()
+    V = len(views)
+    scene = str(tmp_path / "scene.bin")
+    with open(scene, "wb") as f:
+        f.write(struct.pack("<III", V, len(pairs), FP.WAVE))
+        f.write(sim.astype("<f8").tobytes())
+        for v in views:
+            f.write(struct.pack("<Iddd", len(v["xy"]), *cam))
+            f.write(v["xy"].astype("<f4").tobytes())
+            f.write(v["desc"].astype("<f4").tobytes())
+    ws = tmp_path / "workspace"
+    ws.mkdir()
+    out = str(tmp_path / "out.txt")
+    r = subprocess.run([EXE, "workspace", scene, str(ws), out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    rows = dict((line.split()[0], line.split()[1:]) for line in open(out))
+    n = len(pairs)
+    assert rows["edges_a"][0] == rows["edges_a"][2] and rows["edges_a"][4] == "1"     # same edges, bit for bit
+    assert int(rows["edges_a"][0]) >= 0.95 * n
+    assert rows["stats_a"] == rows["stats_b"] and int(rows["stats_a"][0]) == n and int(rows["stats_a"][3]) > 0
+    # a cached two-row match list for the top pair is used instead of matching, is too short, and the pair yields no edge
+    assert rows["stats_c"][3] == "1" and int(rows["stats_c"][5]) >= 1 and rows["edge_with_cached_tiny_list"] == ["0"]
