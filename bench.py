@@ -202,6 +202,28 @@ def main():
         out["score_pose_k2"] = {"kernel_ms": round(ms, 4), "achieved_GBs": round(k2_bytes / (ms * 1e-3) / 1e9, 1),
                                 "frac_hbm": round(k2_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 "pair_scores_per_s": round(P / (ms * 1e-3), 1)}
+        # descriptor matching, the MFMA-bound step that feeds the path: 8 images x 8000 keypoints,
+        # all 56 ordered pairs; useful flop = 2*K*K*128 per pair against the f32-input MFMA peak
+        K, n_img = 8000, 8
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        imgs = []
+        for _ in range(n_img):
+            d = torch.randn((K, 128), generator=g).abs_()
+            imgs.append(eng.prepare_descriptors((d / d.norm(dim=1, keepdim=True)).numpy()))
+        sel = [(i, j) for i in range(n_img) for j in range(n_img) if i != j]
+        eng.match_descriptors_batch(imgs, sel, raw=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(3):
+            eng.match_descriptors_batch(imgs, sel, raw=True)
+        z.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(z) / 3
+        tf = 2.0 * K * K * 128 * len(sel) / (ms * 1e-3) / 1e12
+        out["match_descriptors"] = {"pairs": len(sel), "keypoints": K, "ms": round(ms, 3), "pairs_per_s": round(len(sel) / (ms * 1e-3), 1),
+                                    "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                                                 "frac": round(tf / 157.3, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
+        del imgs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),
