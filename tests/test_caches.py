@@ -23,6 +23,15 @@ def test_hdf5_datasets_round_trip(tmp_path):
         assert open(tmp_path / name, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
     blob = open(tmp_path / "keypoints.h5", "rb").read()
     assert b"feat_img_a" in blob and b"desc_img_a" in blob and b"finished" in blob
+    # an independent reader (the HDF5 command-line tools) sees the layout cv::hdf would have written
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        hdr = " ".join(subprocess.run([h5dump, "-H", str(tmp_path / "keypoints.h5")], capture_output=True, text=True).stdout.split())
+        assert 'ATTRIBUTE "finished" { DATATYPE H5T_STD_I32LE' in hdr
+        assert 'DATASET "desc_img_a" { DATATYPE H5T_IEEE_F32LE DATASPACE SIMPLE { ( 37, 128 )' in hdr
+        assert 'DATASET "feat_img_a" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 37, 4 )' in hdr
+        val = subprocess.run([h5dump, "-d", "img_a.jpg", str(tmp_path / "image_data.h5")], capture_output=True, text=True).stdout
+        assert "1234.5, 1600, 1200" in val
 
 
 @needs_hdf5
