@@ -120,11 +120,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(con
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+        // B operands run kAhead steps ahead of the matrix cores (ring of registers), so LDS latency never stalls an MFMA
+        constexpr int kAhead = 6;
+        float x0[kAhead], x1[kAhead];
+#pragma unroll
+        for (int s = 0; s < kAhead; ++s) { x0[s] = bcur[s * 128]; x1[s] = bcur[s * 128 + 64]; }
 #pragma unroll
         for (int s = 0; s < kD / 2; ++s) {
-            const float x0 = bcur[s * 128], x1 = bcur[s * 128 + 64];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x0[s % kAhead], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1[s % kAhead], acc[1], 0, 0, 0);
+            if (s + kAhead < kD / 2) { x0[s % kAhead] = bcur[(s + kAhead) * 128]; x1[s % kAhead] = bcur[(s + kAhead) * 128 + 64]; }
+        }
+        // pin the issue order the source states: kAhead reads up front, then {2 MFMA, 1 LDS read} per step
+        __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+        for (int s = 0; s < kD / 2; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (s + kAhead < kD / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         // branch-free epilogue: every update is a compare + selects
 #pragma unroll

@@ -1,0 +1,42 @@
+"""Guided-matching throughput (pgi_guided_match_batch): P pairs of K keypoints each, SIFT-sized."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+from pyposegraphbuilder import Engine, synthetic as S
+
+
+def main():
+    n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+    rng = np.random.default_rng(0)
+    views, poses, cam = S.make_feature_views(rng, n_views=6, n_points=n_points, n_clutter=8000 - int(0.75 * n_points), desc_noise=0.012)
+    eng = Engine()
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+    pairs = [(i, j) for i in range(6) for j in range(6) if i != j]
+    rt = []
+    for s, d in pairs:
+        R = poses[d][0] @ poses[s][0].T
+        rt.append(np.r_[R.ravel(), poses[d][1] - R @ poses[s][1]])
+    rt = np.array(rt)
+    K = np.mean([len(v["xy"]) for v in views])
+    for P in (1, len(pairs)):
+        out = eng.guided_match_batch(feats, pairs[:P], rt[:P], max_n=100, raw=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = eng.guided_match_batch(feats, pairs[:P], rt[:P], max_n=100, raw=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print("K~%d pairs=%d: %.3f ms  %.1f pairs/s  %.2f G gate tests/s  kept %s" %
+              (K, P, dt * 1e3, P / dt, P * K * K / dt / 1e9, out[3][:P].cpu().numpy()[:4]))
+    allm = eng.guided_match_batch(feats, pairs[:4], rt[:4], max_n=0)
+    print("matches before the top-100 cut:", [len(m[0]) for m in allm])
+
+
+if __name__ == "__main__":
+    main()
