@@ -154,6 +154,16 @@ def main():
     # compute side (the kernel is VALU / LDS-latency bound, not HBM bound): measured by PMC, not estimated
     if pmc:
         out["valu"] = pmc
+    # SURVEY 8d's compute figure: F_edge = T * (F_solve + M * N * 30) with F_solve = 1e4 flop, M = 4 real solutions,
+    # 30 flop per Sampson residual and T = the hypotheses actually drawn.  This is ALGORITHMIC work (every model
+    # scored on every row); the kernel avoids most of it (pre-verification, exact bail-out), so the figure says how
+    # fast the job's nominal arithmetic is retired, not how many flops execute.
+    T_mean = float(got["iters"].mean())
+    f_edge = T_mean * (1.0e4 + 4 * N * 30)
+    tfs = (P / (kern_ms * 1e-3)) * f_edge / 1e12
+    out["valu_algorithmic"] = {"flop_per_edge": round(f_edge), "achieved": round(tfs, 2), "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": round(tfs / 157.3, 4), "hypotheses_per_edge": round(T_mean, 1),
+                               "note": "SURVEY 8d formula; nominal work, not executed flops"}
 
     if rank == 0 and world == 1 and not args.no_extra:
         # secondary lines (not `value`): fixed budget of 256 hypotheses; the HBM-bound K2 score kernel
