@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 #include "pose_graph_builder.hpp"
 
@@ -82,6 +83,41 @@ int main(int argc, char** argv) {
             out.write((const char*)&s, 4); out.write((const char*)&dd, 4); out.write((const char*)&sc, 8);
             out.write((const char*)e.getValue().getRotation().data(), 72);
         }
+    }
+    // (4) re-entrancy: processImages calls the seam from kCoreNumber OpenMP threads (pose_graph_builder.h:391-392).
+    // Eight threads share one builder (one context: calls serialise), then two builders run side by side (two
+    // contexts, two streams); every result must equal the single-threaded one.
+    {
+        std::vector<SE3d> ref(P);
+        std::vector<size_t> refInl(P);
+        std::vector<std::vector<uchar>> refMask(P);
+        for (uint32_t i = 0; i < P; ++i)
+            builder.estimatePose(20, pairs[i].correspondences, pairs[i].normalizedThreshold, {}, ref[i], refMask[i], refInl[i], 42, i);
+        auto sweep = [&](PoseGraphBuilder& b, uint32_t first, uint32_t step, int* bad) {
+            for (uint32_t i = first; i < P; i += step) {
+                SE3d T;
+                std::vector<uchar> mask;
+                size_t ninl = 0;
+                b.estimatePose(20, pairs[i].correspondences, pairs[i].normalizedThreshold, {}, T, mask, ninl, 42, i);
+                if (ninl != refInl[i] || mask != refMask[i] || T.R != ref[i].R || T.t != ref[i].t) ++*bad;
+            }
+        };
+        int bad[8] = {0};
+        {
+            std::vector<std::thread> th;
+            for (uint32_t k = 0; k < 8; ++k) th.emplace_back(sweep, std::ref(builder), k, 8u, &bad[k]);
+            for (auto& t : th) t.join();
+        }
+        uint32_t sharedBad = 0;
+        for (int k = 0; k < 8; ++k) sharedBad += (uint32_t)bad[k];
+        PoseGraphBuilder b2(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.5, 0.4, "", "", "", "", true, true, true);
+        int badA = 0, badB = 0;
+        std::thread ta(sweep, std::ref(builder), 0u, 1u, &badA), tb(sweep, std::ref(b2), 0u, 1u, &badB);
+        ta.join();
+        tb.join();
+        const uint32_t twoBad = (uint32_t)(badA + badB);
+        out.write((const char*)&sharedBad, 4);
+        out.write((const char*)&twoBad, 4);
     }
     std::printf("host api ok: %u pairs\n", P);
     return 0;

@@ -87,4 +87,7 @@ def test_cpp_host_api(tmp_path):
         s, d, sc = take("<IId")
         R = np.frombuffer(buf, "<f8", 9, pos).reshape(3, 3); pos += 72
         assert d == s + 1 and 0.3 < sc < 0.7 and S.rot_err_deg(R, b["R"][s]) < 1.0
+    # (4) re-entrancy: eight threads on one builder, then two builders side by side -- no result differs
+    shared_bad, two_bad = take("<II")
+    assert shared_bad == 0 and two_bad == 0
     assert pos == len(buf)
