@@ -1,0 +1,48 @@
+"""Committed golden vectors for the matching specifications (tests/golden/golden_v2_matching.npz): the oracle must
+keep producing them (CPU), and the HIP kernels must reproduce them through the C ABI (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_matching as G  # noqa: E402  (input generator shared with the fixture script)
+
+GOLD = np.load(os.path.join(HERE, "golden", "golden_v2_matching.npz"))
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_oracle_reproduces_matching_goldens(k):
+    A, B, truth, views, poses, cam = G.inputs(int(GOLD["seeds"][k]))
+    oi, oj, orr = O.match_descriptors(A, B)
+    assert np.array_equal(oi, GOLD["m%d_i" % k]) and np.array_equal(oj, GOLD["m%d_j" % k]) and np.array_equal(orr, GOLD["m%d_ratio" % k])
+    # independent float64 selection: identical pair set away from razor-thin ratio margins
+    fragile = set(GOLD["m%d_np_fragile" % k].tolist())
+    got = {(i, j) for i, j in zip(oi.tolist(), oj.tolist()) if i not in fragile}
+    exp = {(i, j) for i, j in zip(GOLD["m%d_np_i" % k].tolist(), GOLD["m%d_np_j" % k].tolist()) if i not in fragile}
+    assert got == exp and len(got) > 100
+    gi, gj, gr = O.guided_match(GOLD["g%d_F" % k], views[0]["xy"], views[1]["xy"], views[0]["desc"], views[1]["desc"])
+    assert np.array_equal(gi, GOLD["g%d_i" % k]) and np.array_equal(gj, GOLD["g%d_j" % k]) and np.array_equal(gr, GOLD["g%d_ratio" % k])
+    assert (views[0]["point_id"][gi] == views[1]["point_id"][gj]).mean() > 0.97
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_matching_goldens():
+    from pyposegraphbuilder import Engine
+    eng = Engine()
+    try:
+        for k in range(3):
+            A, B, truth, views, poses, cam = G.inputs(int(GOLD["seeds"][k]))
+            gi, gj, gr = eng.match_descriptors_batch([eng.prepare_descriptors(A), eng.prepare_descriptors(B)], [(0, 1)])[0]
+            assert np.array_equal(gi, GOLD["m%d_i" % k]) and np.array_equal(gj, GOLD["m%d_j" % k]) and np.array_equal(gr, GOLD["m%d_ratio" % k])
+            feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+            R = poses[1][0] @ poses[0][0].T
+            t = poses[1][1] - R @ poses[0][1]
+            hi, hj, hr = eng.guided_match_batch(feats, [(0, 1)], np.r_[R.ravel(), t][None], max_n=0)[0]
+            assert np.array_equal(hi, GOLD["g%d_i" % k]) and np.array_equal(hj, GOLD["g%d_j" % k]) and np.array_equal(hr, GOLD["g%d_ratio" % k])
+    finally:
+        eng.close()
