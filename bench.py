@@ -48,6 +48,14 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-256 / score_pose lines")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched plainly with --gpus N: start the one-process-per-GPU job as a CHILD (never exec after HIP init) and
+        # pass its exit code on; the driver's own torch.distributed.run invocation takes the other branch
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 
