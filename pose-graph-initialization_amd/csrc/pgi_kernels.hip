@@ -419,7 +419,7 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     return ni;
 }
 
-template <bool LDS_PTS>
+template <bool LDS_PTS, bool GUESS>
 __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     uint32_t guess_ninl = 0;
 
     // ---- pose guess (pose_graph_builder.h:974-1029) ----
-    if (a.guess && a.has_guess && a.has_guess[pair]) {
+    if (GUESS && a.has_guess[pair]) {  // GUESS: the batch carries guesses (chosen at launch)
         const double* G = a.guess + 12 * (size_t)pair;
         const double R[9] = {G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7], G[8]};
         const double t[3] = {G[9], G[10], G[11]};
@@ -565,13 +565,17 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
         const uint32_t rs = prm.round_size ? prm.round_size : 32u;
         const uint32_t budget = prm.fixed_budget ? prm.fixed_budget : prm.max_iters;
         uint32_t hyps = 0;
-        const int g = lane >> 4, s = lane & 15;
         const uint32_t n_pass = (rs + 3u) / 4u;
         // best of the round this wavefront is working on (first maximum in hypothesis order)
         int wb_score = -1;  // its model is parked in sh->candE[w] (LDS), not in registers
         uint32_t wb_ninl = 0, wb_hyp = 0;
         // one pass = four hypotheses (one per 16-lane group): sample, solve, score
         auto do_pass = [&](uint32_t pass, uint32_t base_hyp, int floor_score, uint32_t n_bar) {
+            // Lane-derived LDS addresses are recomputed per pass from an opaque copy of the lane id: otherwise the
+            // compiler hoists dozens of them out of the round loop, keeps them live across the whole fit and spills.
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int g = ln >> 4, s = ln & 15;
             const uint32_t local = pass * 4 + g;
             const bool active = local < rs;
             const uint32_t hyp = base_hyp + (active ? local : 0u);
@@ -591,13 +595,13 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
             const bool valid = backend_group<false, 3, true>(
                 gs, s, g * 16, [&](int i) { return rows.get(idx[i]); }, E32, nullptr, prof);
             wave_sync();  // every group is done with region A: the queue may overlay it
-            const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], lane);
+            const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], ln);
             wave_sync();
             prof.mark<9>();
             int bidx = -1;
-            score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, lane, floor_score, n_bar, wb_score,
+            score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, ln, floor_score, n_bar, wb_score,
                                  wb_ninl, wb_hyp, bidx);
-            if (bidx >= 0 && lane < 9) sh->candE[w][lane] = queue[9 * bidx + lane];
+            if (bidx >= 0 && ln < 9) sh->candE[w][ln] = queue[9 * bidx + ln];
             wave_sync();
             prof.mark<10>();
         };
@@ -676,8 +680,10 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                     float bE0[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
+                    int td = tid;
+                    asm volatile("" : "+v"(td));
                     ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ,
-                                                              wscr_all + W_DOUBLES, sh, tid);
+                                                              wscr_all + W_DOUBLES, sh, td);
                 }
                 if (w == 0) {  // n-point refits while they improve (only wave 0 touches the best from here to A)
                     for (uint32_t it = 0; it < prm.lo_iters; ++it) {
@@ -689,7 +695,9 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                         int r_score;
                         uint32_t r_ninl;
                         float rE[9];
-                        const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, lane, cur_best,
+                        int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
+                        asm volatile("" : "+v"(ln));
+                        const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best,
                                                                  cur_ninl, r_score, r_ninl, rE, prof, it == 0 ? ni_first : -1);
                         if (ni < 5) break;
                         if (lane == 0) sh->lo_runs += 1;
@@ -1176,6 +1184,7 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     a.pair_count = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t fixed = k1_fixed_lds();
+    const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
     auto rows_cap = [&](int wgs_per_cu) {  // largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
         const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
         return budget > fixed ? (uint32_t)(((budget - fixed) / 16) & ~(size_t)63) : 0u;
@@ -1184,14 +1193,18 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + fixed;
-        hipLaunchKernelGGL(estimate_pose_kernel<true>, dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<true, true>), dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<true, false>), dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        hipLaunchKernelGGL(estimate_pose_kernel<false>, dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<false, true>), dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<false, false>), dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
     };
     if (!ctx->lds_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ctx->max_lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     ctx->max_lds));
         ctx->lds_attr_set = true;
     }
