@@ -153,7 +153,7 @@ def main():
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "estimate_pose_kernel", "kernel_ms": round(kern_ms, 3),
                      "bytes_per_edge": algorithmic_bytes_per_edge(N),
-                     "note": "K1 stages rows once into LDS: VALU / LDS-latency bound by design (SURVEY 8d), see 'valu'; traffic above algorithmic bytes = register-spill scratch"},
+                     "note": "K1 stages rows once into LDS: VALU / LDS-latency bound by design (SURVEY 8d), see 'valu'"},
         "quality": {"rot_err_auc_at_5deg": round(auc5, 4), "edges_ok": int(ok.sum()),
                     "median_rot_err_deg": round(float(np.median(errs)), 4), "mean_hypotheses": float(got["iters"].mean()),
                     "mean_lo_refits": float(got["lo_runs"].mean())},
