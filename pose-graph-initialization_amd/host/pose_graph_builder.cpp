@@ -246,9 +246,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     uint64_t seed = 0;
     typedef std::vector<Tracklets::Match> Matches;
 
+    typedef std::chrono::steady_clock Clock;
+    auto since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
     auto processWave = [&](const std::vector<CandidatePair>& wave) {
         const size_t P = wave.size();
         if (!P) return;
+        Clock::time_point tick = Clock::now();
         // (1) quick matching from tracklets for pairs the graph already connects (:493-518)
         std::vector<Matches> matches(P);
         std::vector<char> quick(P, 0), visible(P, 0), fromHost(P, 0);
@@ -264,6 +267,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 ++st.cachedMatchLoads;
             }
         }
+        st.secQuickMatching += since(tick); tick = Clock::now();
         // batch order: descriptor-matched pairs first (the matcher writes rows 0..Pn-1), host-provided matches after them
         std::vector<size_t> order;
         for (size_t i = 0; i < P; ++i) if (!fromHost[i]) order.push_back(i);
@@ -293,6 +297,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 for (uint32_t q = 0; q < hcnt[k]; ++q) m[q] = Tracklets::Match(hsrc[k * (size_t)mm + q], hdst[k * (size_t)mm + q], 0.0);
             }
         }
+        st.secMatching += since(tick); tick = Clock::now();
         for (size_t k = Pn; k < P; ++k) {  // tracklet matches join the same device layout
             const Matches& m = matches[order[k]];
             hcnt[k] = (uint32_t)m.size();
@@ -322,6 +327,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
         b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
         b.n_pairs = (uint32_t)P; b.max_corr = mm; b.pair_id_base = 0; b.seed = seed++;
+        Engine::check(pgi_synchronize(ctx));
+        st.secCorrespondences += since(tick); tick = Clock::now();
         // (4) A* pose guesses on the graph committed by earlier waves (:568-599), screened in one launch (:798-811)
         std::vector<double> guess(12 * P, 0.0);
         std::vector<uint8_t> has(P, 0);
@@ -348,6 +355,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 anyGuess = true;
             }
         }
+        st.secAStar += since(tick); tick = Clock::now();
         if (anyGuess) {
             std::vector<double> thr(P), Eg(9 * P, 0.0), tau2(P, 0.0);
             Engine::check(pgi_synchronize(ctx));
@@ -384,6 +392,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         d2h(off.data(), doff.p, (P + 1) * 8);
         std::vector<uint8_t> masks((size_t)off[P]);
         d2h(masks.data(), dmasks.p, masks.size());
+        st.secPoseEstimation += since(tick); tick = Clock::now();
         // (6) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
         std::vector<size_t> guidedOf;
         std::vector<pgi_feature_view> ga, gb;
@@ -410,6 +419,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             d2h(gcnt.data(), dc.p, G * 4);
             st.guidedMatchingRuns += G;
         }
+        st.secGuidedMatching += since(tick); tick = Clock::now();
         // (7) commit in wave order: edge (:645-654), visibility (:692), tracklets (:677-681, :702-709)
         std::vector<size_t> slotOf(P);
         for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
@@ -442,6 +452,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 tracks.add(wave[i].src, wave[i].dst, matches[i], mask);
             }
         }
+        st.secTrackUpdate += since(tick);
         ++st.waves;
     };
 

@@ -18,6 +18,7 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -405,6 +406,10 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     struct FeatureRunStatistics : RunStatistics {  // the "[Matching]", "[Quick matching]", "[Epipolar Hashing]" keys
         size_t matchingRuns = 0, quickMatchingRuns = 0, guidedMatchingRuns = 0, guidedMatchesAdded = 0, trackNumber = 0,
                tooFewMatches = 0, cachedMatchLoads = 0;
+        // wall-clock seconds per stage (RunningStatistics' "[Matching]", "[Quick matching]", "[A*]", "[Pose estimation]",
+        // "[Epipolar Hashing]" timers of the reference)
+        double secQuickMatching = 0, secMatching = 0, secCorrespondences = 0, secAStar = 0, secPoseEstimation = 0,
+               secGuidedMatching = 0, secTrackUpdate = 0;
     };
     // Per wave of candidate pairs (descending similarity): tracklet correspondences for pairs the graph already
     // connects (:493-518), descriptor matching for the rest (:521-546), createCorrespondenceMatrix (:553-565), A*

@@ -40,9 +40,15 @@ public:
         if (it == tmpViewToTracks.end()) return;
         const auto jt = tmpViewToTracks.find(viewIdDestination_);
         if (jt == tmpViewToTracks.end()) return;
-        std::unordered_set<size_t> ofSource(it->second.begin(), it->second.end());
+        // membership of a track in the source view's list: a per-thread stamp array instead of the reference's
+        // unordered_set (same answers; the lists reach 10^5 entries and this lookup dominated the host time)
+        static thread_local std::vector<unsigned> stamp;
+        static thread_local unsigned epoch = 0;
+        if (stamp.size() < tmpTracks.size()) stamp.resize(tmpTracks.size(), 0u);
+        if (++epoch == 0u) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1u; }
+        for (const size_t trackIdx : it->second) stamp[trackIdx] = epoch;
         for (const size_t trackIdx : jt->second) {
-            if (!ofSource.count(trackIdx)) continue;
+            if (stamp[trackIdx] != epoch) continue;
             Match m(0, 0, 0.0);
             int found = 0;
             for (const Pair& p : tmpTracks[trackIdx]) {
@@ -59,16 +65,24 @@ public:
     void add(const size_t& imageIdxSource_, const size_t& imageIdxDestination_, const std::vector<Match>& matches_,
              const std::vector<unsigned char>& inlierMask_) {
         std::unique_lock<std::shared_mutex> lock(readerWriterLock);
+        // (unordered_map never invalidates references to its elements; a view's list is created on first use, as
+        // operator[] does in the reference)
+        std::vector<size_t>* viewTracksSource = nullptr;
+        std::vector<size_t>* viewTracksDestination = nullptr;
+        auto ofSource = [&]() -> std::vector<size_t>& {
+            if (!viewTracksSource) viewTracksSource = &tmpViewToTracks[imageIdxSource_];
+            return *viewTracksSource;
+        };
+        auto ofDestination = [&]() -> std::vector<size_t>& {
+            if (!viewTracksDestination) viewTracksDestination = &tmpViewToTracks[imageIdxDestination_];
+            return *viewTracksDestination;
+        };
         for (size_t k = 0; k < matches_.size(); ++k) {
             if (!inlierMask_[k]) continue;
             const Pair pairSource(imageIdxSource_, std::get<0>(matches_[k]));
             const Pair pairDestination(imageIdxDestination_, std::get<1>(matches_[k]));
-            size_t& idS = pointPairs[pairSource];
-            if (idS == 0) idS = pointPairNumber++;
-            const size_t idSource = idS;  // (the reference holds references; std::map never invalidates them either)
-            size_t& idD = pointPairs[pairDestination];
-            if (idD == 0) idD = pointPairNumber++;
-            const size_t idDestination = idD;
+            const size_t idSource = idOf(pairSource), idDestination = idOf(pairDestination);
+            if (tmpPairToTracks.size() < pointPairNumber) tmpPairToTracks.resize(pointPairNumber);  // before taking references
             std::vector<size_t>& tracksSource = tmpPairToTracks[idSource];
             std::vector<size_t>& tracksDestination = tmpPairToTracks[idDestination];
             const size_t trackNumDestination = tracksDestination.size();
@@ -77,7 +91,7 @@ public:
                 const size_t trackIdx = tracksSource[q];
                 std::vector<Pair>& track = tmpTracks[trackIdx];
                 if (std::find(track.begin(), track.end(), pairDestination) != track.end()) continue;
-                tmpViewToTracks[imageIdxDestination_].emplace_back(trackIdx);
+                ofDestination().emplace_back(trackIdx);
                 track.emplace_back(pairDestination);
                 tracksDestination.emplace_back(trackIdx);
                 added = true;
@@ -86,7 +100,7 @@ public:
                 const size_t trackIdx = tracksDestination[q];
                 std::vector<Pair>& track = tmpTracks[trackIdx];
                 if (std::find(track.begin(), track.end(), pairSource) != track.end()) continue;
-                tmpViewToTracks[imageIdxSource_].emplace_back(trackIdx);
+                ofSource().emplace_back(trackIdx);
                 track.emplace_back(pairSource);
                 tracksSource.emplace_back(trackIdx);
                 added = true;
@@ -94,8 +108,8 @@ public:
             if (!added) {
                 const size_t idx = tmpTracks.size();
                 tmpTracks.emplace_back(std::vector<Pair>{pairSource, pairDestination});
-                tmpViewToTracks[imageIdxSource_].emplace_back(idx);
-                tmpViewToTracks[imageIdxDestination_].emplace_back(idx);
+                ofSource().emplace_back(idx);
+                ofDestination().emplace_back(idx);
                 tracksSource.emplace_back(idx);
                 tracksDestination.emplace_back(idx);
             }
@@ -106,12 +120,18 @@ public:
     const std::vector<std::vector<Pair>>& tracks() const { return tmpTracks; }
 
 private:
+    // point_track.h:651-657: id 0 doubles as "not seen yet", so the first point ever is re-registered on every visit
+    size_t idOf(const Pair& p) {
+        size_t& id = pointPairs[(static_cast<unsigned long long>(p.first) << 32) ^ static_cast<unsigned long long>(p.second)];
+        if (id == 0) id = pointPairNumber++;
+        return id;
+    }
     mutable std::shared_mutex readerWriterLock;
     size_t pointPairNumber;
-    std::map<Pair, size_t> pointPairs;                           // (view, point) -> id
+    std::unordered_map<unsigned long long, size_t> pointPairs;   // (view, point) -> id
     std::vector<std::vector<Pair>> tmpTracks;                    // track -> its (view, point) members
     std::unordered_map<size_t, std::vector<size_t>> tmpViewToTracks;  // view -> tracks touching it (with repeats)
-    std::map<size_t, std::vector<size_t>> tmpPairToTracks;       // id -> tracks containing that point
+    std::vector<std::vector<size_t>> tmpPairToTracks;            // id -> tracks containing that point (ids are dense)
 };
 
 }  // namespace reconstruction

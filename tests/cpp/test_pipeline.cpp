@@ -1,6 +1,7 @@
 // Feature-level pipeline on the GPU: reads views (keypoints, descriptors, camera), candidate pairs and a similarity
 // matrix written by tests/test_feature_pipeline.py, runs PoseGraphBuilder::processFeatures in three configurations
 // (plain; + path finding; + path finding + epipolar hashing/tracklets) and writes statistics + edges.
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 
@@ -45,7 +46,15 @@ int main(int argc, char** argv) {
         PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.75, "", "", "", "", usePath, true, useHashing);
         PoseGraph graph;
         auto cand = pairs;
+        const auto t0 = std::chrono::steady_clock::now();
         const auto st = builder.processFeatures(views, cand, graph, wave, &sim);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("mode %d: %zu pairs -> %zu edges in %.3f s (%.1f pairs/s; %zu matched, %zu quick, %zu guided runs)\n", mode,
+                    (size_t)st.pairsProcessed, (size_t)st.edgesAdded, sec, st.pairsProcessed / sec, (size_t)st.matchingRuns,
+                    (size_t)st.quickMatchingRuns, (size_t)st.guidedMatchingRuns);
+        std::printf("        seconds: quick matching %.3f, matching %.3f, correspondences %.3f, A* %.3f, pose estimation %.3f, guided %.3f, "
+                    "commit + tracklets %.3f\n", st.secQuickMatching, st.secMatching, st.secCorrespondences, st.secAStar,
+                    st.secPoseEstimation, st.secGuidedMatching, st.secTrackUpdate);
         const uint64_t v[16] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes, st.posesFromGuess,
                                 st.hypotheses, st.waves, graph.numEdges(), st.matchingRuns, st.quickMatchingRuns, st.guidedMatchingRuns,
                                 st.guidedMatchesAdded, st.trackNumber, st.tooFewMatches, 0};
