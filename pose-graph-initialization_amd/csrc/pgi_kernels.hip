@@ -1132,6 +1132,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     c->max_lds = lds > 0 ? lds : 65536;
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
+    if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
     return c;
 }
 

@@ -9,6 +9,7 @@
 //   desc_top2_kernel      per (128-row block, column split): distances tile by tile, running row top-2 in
 //                         registers, column best through 64-bit atomicMin on (d2 bits, row)
 //   match_select_kernel   per pair: merge the splits, ratio + mutual test, bitonic sort by (ratio, row)
+#include <algorithm>
 #include <cfloat>
 #include <vector>
 #include "pgi_internal.hpp"
@@ -30,6 +31,13 @@ struct MatchPair {
     uint64_t row_off;  // RowBest index of (split 0, row 0) of this pair
     uint64_t col_off;  // column-best index of column 0 of this pair
 };
+
+// DS operations of one wavefront execute in order; this only keeps the compiler from moving LDS accesses across it
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // C/D layout of the 32x32 MFMA: register r of lane (c = lane & 31, h = lane >> 5) holds C[row][c]
 __device__ __forceinline__ uint32_t mfma_row(int r, uint32_t h) { return (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h; }
@@ -255,6 +263,300 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
     if (tid == 0) out_count[blockIdx.x] = count;
 }
 // ---------------------------------------------------------------------------------------------------------------
+// Screened matching: the same exact result, most of the arithmetic at the f16 matrix-core rate (16x the f32 one).
+//
+//   desc_screen_kernel   s~_ij from v_mfma_f32_32x32x16_f16 on f16-rounded descriptors.  |d~2 - d2| <= eps_i for
+//                        every column (eps_i from the rounding analysis below), so the columns that can be among a
+//                        row's two nearest are those with d~2 <= T + 2 eps_i, T = the second smallest d~2 of the row.
+//                        Every lane keeps its two best columns and the VALUE of its third best: if no lane's third
+//                        best is inside the window, the stored columns provably contain the exact top-2 (certificate);
+//                        otherwise the row is flagged.
+//   desc_verify_kernel   exact f32 chain (the specification) for the stored candidates only -> RowBest; flagged rows
+//                        go to a list.
+//   desc_exact_rows_kernel  flagged rows: full exact scan, one wavefront per row.
+// The column-wise nearest neighbour is the row problem with the images swapped (identical bits: products and the
+// norm sum commute), so the pipeline runs twice and feeds the unchanged selection kernel.
+//
+// eps: f16 rounding has unit roundoff u = 2^-11 (absolute 2^-25 in the subnormal range), so |sum a~b~ - sum ab| <=
+// (2u + u^2) sum|a_k b_k| + 2^-25 sqrt(128) (|a| + |b|) <= (2u + u^2) sqrt(na nb) + 3.4e-7 (|a| + |b|); both f32
+// accumulations add at most 128 * 2^-24 sqrt(na nb) each and the norms carry 2^-17 relative error: kEpsS = 2^-10 + 2^-15
+// covers the relative part with margin; d2 = na + nb - 2s doubles everything and adds a few ulps of na + nb.  f16
+// overflows above 65504: |x_k| <= sqrt(norm), so rows or images with a squared norm above 3e9 are simply flagged.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kEpsS = 0.0009765625f + 0.000030517578125f;  // 2^-10 + 2^-15
+constexpr int kCand = 8;  // stored candidates per row and column split
+
+struct ScreenPair {
+    const unsigned short *abf, *bbf;  // row-major f16, n_pad x 128
+    const float *arm, *brm;           // row-major f32,  n_pad x 128
+    const float *at, *bt;             // transposed f32, 128 x n_pad (exact fallback)
+    const float *na, *nb;
+    uint32_t n_a, n_a_pad, n_b, n_b_pad;
+    uint64_t row_off;                 // first row slot of this pair (ScreenRow / RowBest / keys)
+};
+struct ScreenRow {
+    uint32_t count, flagged;
+    uint32_t j[kCand];
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPair* __restrict__ pairs, ScreenRow* __restrict__ out,
+                                                                uint32_t splits, uint32_t wgs_per_pair, uint64_t split_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned short bt[2][kTileJ * kD];  // 2 x 16 KB, MFMA operand order
+    __shared__ float s_nbmax[NW];
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, qq = nwg >> 3, rr = nwg & 7u;
+    const uint32_t wgid = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const ScreenPair P = pairs[wgid / wgs_per_pair];
+    const uint32_t x = wgid % wgs_per_pair, rb = x / splits, split = x % splits;
+    constexpr uint32_t kRows = NW * 32u;
+    if (rb * kRows >= P.n_a_pad) return;
+    const uint32_t tiles = P.n_b_pad / kTileJ;
+    const uint32_t t0 = (uint32_t)((uint64_t)tiles * split / splits), t1 = (uint32_t)((uint64_t)tiles * (split + 1) / splits);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
+    const uint32_t row_base = rb * kRows + w * 32u;
+
+    // largest column norm (for eps): every wavefront scans the norm array once
+    float nbmax = 0.0f;
+    for (uint32_t j = tid; j < P.n_b_pad; j += NW * 64u) nbmax = fmaxf(nbmax, P.nb[j]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nbmax = fmaxf(nbmax, __shfl_xor(nbmax, m));
+    if (lane == 0) s_nbmax[w] = nbmax;
+    // A fragments: lane (c, h) holds A[row_base + c][16 ks + 8 h .. +7] for the eight k-steps
+    f16x8 a[kD / 16];
+#pragma unroll
+    for (int ks = 0; ks < kD / 16; ++ks)
+        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + (size_t)(row_base + c) * kD + 16 * ks + 8 * (int)h);
+    float nar[16], b1[16], b2[16], b3[16];
+    uint32_t j1[16], j2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        nar[r] = P.na[row_base + mfma_row(r, h)];
+        b1[r] = INFINITY; b2[r] = INFINITY; b3[r] = INFINITY; j1[r] = 0u; j2[r] = 0u;
+    }
+    // chunk cg = (ks, h') of 64 columns x 16 bytes: LDS element ((cg * 64 + jj) * 8), global B[j0 + jj][16 ks + 8 h' ..]
+    auto stage = [&](uint32_t tile, uint32_t buf) {
+#pragma unroll
+        for (int q = 0; q < 16 / NW; ++q) {
+            const uint32_t cg = (uint32_t)q * NW + w;
+            const unsigned short* src = P.bbf + (size_t)(tile * kTileJ + lane) * kD + 8u * cg;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&bt[buf][cg * 512u]), 16, 0, 0);
+        }
+    };
+    if (t0 < t1) stage(t0, 0u);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint32_t cur = (tile - t0) & 1u;
+        __syncthreads();
+        if (tile + 1 < t1) stage(tile + 1, cur ^ 1u);
+        float nbj[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) nbj[sub] = P.nb[tile * kTileJ + 32u * sub + c];
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < kD / 16; ++ks) {
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(&bt[cur][((2 * ks + (int)h) * 64 + (int)c) * 8]);
+            const f16x8 x1 = *reinterpret_cast<const f16x8*>(&bt[cur][((2 * ks + (int)h) * 64 + 32 + (int)c) * 8]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], x1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t j = tile * kTileJ + 32u * sub + c;
+            const bool jvalid = j < P.n_b;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float d = fmaf(-2.0f, acc[sub][r], nar[r] + nbj[sub]);
+                d = jvalid ? d : INFINITY;  // (no clamp at 0: the window only needs |d~ - d| <= eps, and max(0, .) is 1-Lipschitz)
+                // keep the lane's best two columns and the value of its third: medians and selects, no branches
+                const bool lt1 = d < b1[r], lt2 = d < b2[r];
+                b3[r] = fminf(b3[r], fmaxf(b2[r], d));
+                const float nb2 = lt1 ? b1[r] : (lt2 ? d : b2[r]);
+                const uint32_t nj2 = lt1 ? j1[r] : (lt2 ? j : j2[r]);
+                b2[r] = nb2; j2[r] = nj2;
+                b1[r] = lt1 ? d : b1[r];
+                j1[r] = lt1 ? j : j1[r];
+            }
+        }
+    }
+    __syncthreads();
+    float nbm = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) nbm = fmaxf(nbm, s_nbmax[ww]);
+    // per row: T = second smallest approximate distance over the 32 lanes of the row, window T + 2 eps
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float x1 = b1[r], x2 = b2[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const float o1 = __shfl_xor(x1, m), o2 = __shfl_xor(x2, m);
+            const float n2 = fminf(fmaxf(x1, o1), fminf(x2, o2));
+            x1 = fminf(x1, o1);
+            x2 = n2;
+        }
+        const float eps = 2.0f * (kEpsS * sqrtf(nar[r] * nbm) + 3.4e-7f * (sqrtf(nar[r]) + sqrtf(nbm))) + 2.4e-7f * (nar[r] + nbm);
+        const float win = x2 + 2.0f * eps;  // +inf when the split has fewer than two valid columns: everything is kept
+        const bool safe = nar[r] <= 3.0e9f && nbm <= 3.0e9f;  // f16 range; also false for NaN norms
+        const bool k1 = b1[r] <= win && b1[r] < INFINITY, k2 = b2[r] <= win && b2[r] < INFINITY;
+        const bool miss = (b3[r] <= win && b3[r] < INFINITY) || !safe;  // a third column of this lane could matter: not stored
+        const unsigned long long m1 = __ballot(k1), m2 = __ballot(k2), mm = __ballot(miss);
+        const uint32_t h1 = (uint32_t)(m1 >> (32u * h)), h2 = (uint32_t)(m2 >> (32u * h)), hm = (uint32_t)(mm >> (32u * h));
+        const uint32_t n1 = __popc(h1), total = n1 + __popc(h2);
+        const uint32_t row = row_base + mfma_row(r, h);
+        ScreenRow* o = out + (size_t)split * split_stride + P.row_off + row;
+        const uint32_t below = (1u << c) - 1u;
+        if (total <= (uint32_t)kCand) {
+            if (k1) o->j[__popc(h1 & below)] = j1[r];
+            if (k2) o->j[n1 + __popc(h2 & below)] = j2[r];
+        }
+        if (c == 0u) {
+            o->count = total <= (uint32_t)kCand ? total : 0u;
+            o->flagged = (hm != 0u || total > (uint32_t)kCand) ? 1u : 0u;
+        }
+    }
+}
+
+// exact f32 chain d2 of row i of A against row j of B (both row-major): the specification's arithmetic
+__device__ __forceinline__ float exact_d2(const float* __restrict__ ai, const float* __restrict__ bj, float na, float nb) {
+    float s = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < kD; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(ai + k), y = *reinterpret_cast<const float4*>(bj + k);
+        s = fmaf(x.x, y.x, s);
+        s = fmaf(x.y, y.y, s);
+        s = fmaf(x.z, y.z, s);
+        s = fmaf(x.w, y.w, s);
+    }
+    const float d2 = (na + nb) - 2.0f * s;
+    return d2 > 0.0f ? d2 : 0.0f;
+}
+
+// one thread per row: exact distances of the screened candidates -> (b1, j1, b2); flagged rows are queued.
+// as_keys = 1 writes the column-best key (d2 bits, row index) of the swapped problem instead of a RowBest.
+__global__ __launch_bounds__(256) void desc_verify_kernel(const ScreenPair* __restrict__ pairs, const ScreenRow* __restrict__ scr,
+                                                         uint32_t splits, uint64_t split_stride, uint32_t max_rows, RowBest* __restrict__ rowbest,
+                                                         unsigned long long* __restrict__ keys, uint32_t as_keys,
+                                                         uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+    const ScreenPair P = pairs[blockIdx.y];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P.n_a || i >= max_rows) return;
+    bool flagged = false;
+    float b1 = INFINITY, b2 = INFINITY;
+    uint32_t j1 = 0u, seen = 0u;
+    const float* ai = P.arm + (size_t)i * kD;
+    const float nai = P.na[i];
+    for (uint32_t s = 0; s < splits; ++s) {
+        const ScreenRow* r = scr + (size_t)s * split_stride + P.row_off + i;
+        flagged |= r->flagged != 0u;
+        const uint32_t cnt = r->count;
+        for (uint32_t q = 0; q < cnt; ++q) {
+            const uint32_t j = r->j[q];
+            const float d2 = exact_d2(ai, P.brm + (size_t)j * kD, nai, P.nb[j]);
+            if (d2 < b1 || (d2 == b1 && j < j1)) { b2 = b1; b1 = d2; j1 = j; }
+            else if (d2 < b2) { b2 = d2; }
+            ++seen;
+        }
+    }
+    if (P.n_b >= 2u && seen < 2u) flagged = true;
+    if (flagged) {  // queue the row in its pair's list (capacity n_a_pad)
+        const uint32_t slot = atomicAdd(fb_count + blockIdx.y, 1u);
+        fb_list[P.row_off + slot] = i;
+        return;
+    }
+    if (as_keys) keys[P.row_off + i] = ((unsigned long long)__float_as_uint(b1) << 32) | j1;
+    else { RowBest rb; rb.b1 = b1; rb.b2 = b2; rb.j1 = j1; rb.pad = 0u; rowbest[P.row_off + i] = rb; }
+}
+
+// flagged rows: the full exact scan.  A workgroup takes four queued rows of one pair at a time; its 256 threads own the
+// columns j = tid, tid + 256, ..., so every B value loaded feeds four chains and B is streamed once per four rows.
+__global__ __launch_bounds__(256) void desc_exact_rows_kernel(const ScreenPair* __restrict__ pairs, const uint32_t* __restrict__ fb_list,
+                                                             const uint32_t* __restrict__ fb_count, RowBest* __restrict__ rowbest,
+                                                             unsigned long long* __restrict__ keys, uint32_t as_keys) {
+    __shared__ float arow[4][kD];
+    __shared__ float mb1[4][4], mb2[4][4];
+    __shared__ uint32_t mj1[4][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const ScreenPair P = pairs[blockIdx.y];
+    const uint32_t total = fb_count[blockIdx.y];
+    for (uint32_t e = blockIdx.x * 4u; e < total; e += gridDim.x * 4u) {
+        uint32_t row[4];
+        float nai[4], b1[4], b2[4];
+        uint32_t j1[4];
+        __syncthreads();  // the previous group's readers of arow / mb* are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            row[q] = fb_list[P.row_off + (e + q < total ? e + q : e)];  // a short tail repeats the first row
+            nai[q] = P.na[row[q]];
+            b1[q] = INFINITY; b2[q] = INFINITY; j1[q] = 0u;
+            if (tid < (uint32_t)kD) arow[q][tid] = P.arm[(size_t)row[q] * kD + tid];
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < P.n_b; j += 256u) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < kD; ++k) {
+                const float bv = P.bt[(size_t)k * P.n_b_pad + j];
+                s0 = fmaf(arow[0][k], bv, s0);
+                s1 = fmaf(arow[1][k], bv, s1);
+                s2 = fmaf(arow[2][k], bv, s2);
+                s3 = fmaf(arow[3][k], bv, s3);
+            }
+            const float nbj = P.nb[j];
+            const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float d2 = (nai[q] + nbj) - 2.0f * sv[q];
+                d2 = d2 > 0.0f ? d2 : 0.0f;
+                if (d2 < b1[q]) { b2[q] = b1[q]; b1[q] = d2; j1[q] = j; }
+                else if (d2 < b2[q]) { b2[q] = d2; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x1 = b1[q], x2 = b2[q];
+            uint32_t xj = j1[q];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const float o1 = __shfl_xor(x1, m), o2 = __shfl_xor(x2, m);
+                const uint32_t oj = (uint32_t)__shfl_xor((int)xj, m);
+                const bool take = o1 < x1 || (o1 == x1 && oj < xj);
+                const float n2 = fminf(fmaxf(x1, o1), fminf(x2, o2));
+                if (take) { x1 = o1; xj = oj; }
+                x2 = n2;
+            }
+            if (lane == 0) { mb1[q][w] = x1; mb2[q][w] = x2; mj1[q][w] = xj; }
+        }
+        __syncthreads();
+        if (tid < 4u && e + tid < total) {
+            float x1 = mb1[tid][0], x2 = mb2[tid][0];
+            uint32_t xj = mj1[tid][0];
+            for (int ww = 1; ww < 4; ++ww) {
+                const float o1 = mb1[tid][ww], o2 = mb2[tid][ww];
+                const uint32_t oj = mj1[tid][ww];
+                const bool take = o1 < x1 || (o1 == x1 && oj < xj);
+                const float n2 = fminf(fmaxf(x1, o1), fminf(x2, o2));
+                if (take) { x1 = o1; xj = oj; }
+                x2 = n2;
+            }
+            const uint32_t r = fb_list[P.row_off + e + tid];
+            if (as_keys) keys[P.row_off + r] = ((unsigned long long)__float_as_uint(x1) << 32) | xj;
+            else { RowBest rb; rb.b1 = x1; rb.b2 = x2; rb.j1 = xj; rb.pad = 0u; rowbest[P.row_off + r] = rb; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void desc_round_f16_kernel(const float* __restrict__ desc, uint32_t n, uint32_t n_pad,
+                                                             float* __restrict__ rm, unsigned short* __restrict__ bf) {
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (size_t)n_pad * kD) return;
+    const float v = idx < (size_t)n * kD ? desc[idx] : 0.0f;
+    rm[idx] = v;
+    const _Float16 hv = (_Float16)v;  // v_cvt_f16_f32: round to nearest even, gradual underflow
+    bf[idx] = __builtin_bit_cast(unsigned short, hv);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // guided matching with a known pose (matcher.h:199-405)
 struct GuidedPair {
     const float *kp1, *kp2, *d1, *d2;
@@ -476,6 +778,104 @@ int pgi_desc_prepare(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_des
     return PGI_SUCCESS;
 }
 
+int pgi_desc_prepare_screen(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_desc_rm, uint16_t* d_desc_f16) {
+    if (!ctx || !d_desc_rm || !d_desc_f16 || (n && !d_desc)) return pgi::fail(PGI_ERR_INVALID, "pgi_desc_prepare_screen: null argument");
+    if (n > PGI_DESC_MAX) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_desc_prepare_screen: more than PGI_DESC_MAX keypoints");
+    const uint32_t n_pad = pgi_desc_padded(n);
+    if (n_pad == 0) return PGI_SUCCESS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t elems = (size_t)n_pad * kD;
+    hipLaunchKernelGGL(desc_round_f16_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, ctx->stream, d_desc, n, n_pad, d_desc_rm,
+                       d_desc_f16);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+// screened path of pgi_match_descriptors_batch (views validated by the caller, ctx locked)
+static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst, uint32_t n_pairs, uint32_t max_matches,
+                          uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
+    constexpr uint32_t NWS = 4, kRowsWg = NWS * 32u;
+    std::vector<MatchPair> hp(n_pairs);
+    std::vector<ScreenPair> fwd(n_pairs), bwd(n_pairs);
+    uint64_t rows_total = 0, cols_total = 0, rb_f = 0, rb_b = 0;
+    uint32_t max_rb_f = 0, max_rb_b = 0, min_tiles_f = ~0u, min_tiles_b = ~0u, max_na = 0, max_nb = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const pgi_desc_view &a = h_src[p], &b = h_dst[p];
+        hp[p] = MatchPair{a.d_desc_t, a.d_norm, b.d_desc_t, b.d_norm, a.n, a.n_pad, b.n, b.n_pad, rows_total, cols_total};
+        fwd[p] = ScreenPair{a.d_desc_f16, b.d_desc_f16, a.d_desc_rm, b.d_desc_rm, a.d_desc_t, b.d_desc_t, a.d_norm, b.d_norm,
+                            a.n, a.n_pad, b.n, b.n_pad, rows_total};
+        bwd[p] = ScreenPair{b.d_desc_f16, a.d_desc_f16, b.d_desc_rm, a.d_desc_rm, b.d_desc_t, a.d_desc_t, b.d_norm, a.d_norm,
+                            b.n, b.n_pad, a.n, a.n_pad, cols_total};
+        if (a.n && b.n) {
+            rb_f += a.n_pad / kRowsWg; rb_b += b.n_pad / kRowsWg;
+            max_rb_f = std::max(max_rb_f, a.n_pad / kRowsWg); max_rb_b = std::max(max_rb_b, b.n_pad / kRowsWg);
+            min_tiles_f = std::min(min_tiles_f, b.n_pad / (uint32_t)kTileJ); min_tiles_b = std::min(min_tiles_b, a.n_pad / (uint32_t)kTileJ);
+        }
+        max_na = std::max(max_na, a.n); max_nb = std::max(max_nb, b.n);
+        rows_total += a.n_pad; cols_total += b.n_pad;
+    }
+    auto pick_splits = [](uint64_t row_blocks, uint32_t min_tiles) {
+        uint32_t s = 1;
+        if (row_blocks > 0 && row_blocks < 1024) s = (uint32_t)((1024 + row_blocks - 1) / row_blocks);
+        if (s > 8) s = 8;
+        if (min_tiles != ~0u && s > min_tiles) s = min_tiles;
+        return s < 1 ? 1u : s;
+    };
+    const uint32_t sf = pick_splits(rb_f, min_tiles_f), sb = pick_splits(rb_b, min_tiles_b);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_hp = 0, o_fwd = o_hp + up(n_pairs * sizeof(MatchPair)), o_bwd = o_fwd + up(n_pairs * sizeof(ScreenPair)),
+                 o_sf = o_bwd + up(n_pairs * sizeof(ScreenPair)), o_sb = o_sf + up((size_t)rows_total * sf * sizeof(ScreenRow)),
+                 o_rows = o_sb + up((size_t)cols_total * sb * sizeof(ScreenRow)), o_keys = o_rows + up((size_t)rows_total * sizeof(RowBest)),
+                 o_fb = o_keys + up((size_t)cols_total * 8), o_cnt = o_fb + up((size_t)(rows_total + cols_total) * sizeof(uint32_t)),
+                 bytes = o_cnt + up((size_t)2 * n_pairs * sizeof(uint32_t)) + 256;
+    if (bytes > ctx->match_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
+        ctx->d_match_ws = nullptr;
+        ctx->match_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
+        ctx->match_ws_bytes = bytes;
+    }
+    char* ws = (char*)ctx->d_match_ws;
+    MatchPair* d_hp = (MatchPair*)(ws + o_hp);
+    ScreenPair *d_fwd = (ScreenPair*)(ws + o_fwd), *d_bwd = (ScreenPair*)(ws + o_bwd);
+    ScreenRow *d_sf = (ScreenRow*)(ws + o_sf), *d_sb = (ScreenRow*)(ws + o_sb);
+    RowBest* d_rows = (RowBest*)(ws + o_rows);
+    unsigned long long* d_keys = (unsigned long long*)(ws + o_keys);
+    uint32_t* d_fb = (uint32_t*)(ws + o_fb);
+    uint32_t* d_cnt = (uint32_t*)(ws + o_cnt);
+    ctx->d_match_cnt = d_cnt;
+    ctx->match_cnt_pairs = n_pairs;
+    HIP_TRY(hipMemcpyAsync(d_hp, hp.data(), n_pairs * sizeof(MatchPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_fwd, fwd.data(), n_pairs * sizeof(ScreenPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_bwd, bwd.data(), n_pairs * sizeof(ScreenPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors are local buffers
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)2 * n_pairs * sizeof(uint32_t), ctx->stream));
+    if (cols_total) HIP_TRY(hipMemsetAsync(d_keys, 0xFF, (size_t)cols_total * 8, ctx->stream));  // columns of empty pairs stay "no best"
+    auto direction = [&](const ScreenPair* d_pairs, ScreenRow* d_scr, uint32_t splits, uint32_t max_rb, uint64_t stride, uint32_t max_rows,
+                         uint32_t as_keys, uint32_t* fb, uint32_t* cnt) {
+        if (max_rb == 0) return;
+        const uint32_t per_pair = max_rb * splits;
+        hipLaunchKernelGGL(desc_screen_kernel<NWS>, dim3(per_pair * n_pairs), dim3(NWS * 64), 0, ctx->stream, d_pairs, d_scr, splits, per_pair,
+                           stride);
+        hipLaunchKernelGGL(desc_verify_kernel, dim3((max_rows + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_scr, splits, stride,
+                           max_rows, d_rows, d_keys, as_keys, fb, cnt);
+        hipLaunchKernelGGL(desc_exact_rows_kernel, dim3(n_pairs < 16 ? 64 : 16, n_pairs), dim3(256), 0, ctx->stream, d_pairs, fb, cnt, d_rows,
+                           d_keys, as_keys);
+    };
+    direction(d_fwd, d_sf, sf, max_rb_f, rows_total, max_na, 0u, d_fb, d_cnt);
+    direction(d_bwd, d_sb, sb, max_rb_b, cols_total, max_nb, 1u, d_fb + rows_total, d_cnt + n_pairs);
+    HIP_TRY(hipGetLastError());
+    uint32_t np = 2;
+    while (np < max_na) np <<= 1;
+    HIP_TRY(hipFuncSetAttribute((const void*)match_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipLaunchKernelGGL(match_select_kernel, dim3(n_pairs), dim3(1024), (size_t)np * sizeof(unsigned long long), ctx->stream, d_hp, d_rows,
+                       d_keys, 1u, max_matches, d_match_src, d_match_dst, d_ratio, d_counts);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
 int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst, uint32_t n_pairs,
                                 uint32_t max_matches, uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio,
                                 uint32_t* d_counts) {
@@ -505,6 +905,10 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
         rows_total += a.n_pad;
         cols_total += b.n_pad;
     }
+    bool screen = ctx->match_screen != 0;
+    for (uint32_t p = 0; p < n_pairs && screen; ++p)
+        screen = (!h_src[p].n || (h_src[p].d_desc_rm && h_src[p].d_desc_f16)) && (!h_dst[p].n || (h_dst[p].d_desc_rm && h_dst[p].d_desc_f16));
+    if (screen) return match_screened(ctx, h_src, h_dst, n_pairs, max_matches, d_match_src, d_match_dst, d_ratio, d_counts);
     // column splits: enough workgroups to cover the 256 CUs a few times over, never more splits than tiles
     uint32_t splits = 1;
     if (row_blocks > 0 && row_blocks < 1024) splits = (uint32_t)((1024 + row_blocks - 1) / row_blocks);
@@ -662,6 +1066,19 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     hipLaunchKernelGGL(guided_select_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_best, d_rat, d_ci, d_cj, d_cr, max_n,
                        out_stride, d_match_src, d_match_dst, d_ratio, d_counts);
     HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
+// diagnostics (tests, scripts): rows the last screened match had to re-scan exactly, summed over pairs; synchronises
+int pgi_internal_match_flagged(pgi_ctx* ctx, uint64_t* forward, uint64_t* backward) {
+    if (!ctx || !forward || !backward) return PGI_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    *forward = *backward = 0;
+    if (!ctx->d_match_cnt || !ctx->match_cnt_pairs) return PGI_SUCCESS;
+    std::vector<uint32_t> h((size_t)2 * ctx->match_cnt_pairs);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(h.data(), ctx->d_match_cnt, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t p = 0; p < ctx->match_cnt_pairs; ++p) { *forward += h[p]; *backward += h[ctx->match_cnt_pairs + p]; }
     return PGI_SUCCESS;
 }
 }  // extern "C"

@@ -216,7 +216,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     // features resident in HBM for the whole run: keypoints, row-major descriptors (guided matching) and the
     // transposed copy + norms (brute-force matching)
     const size_t V = views.size();
-    std::vector<std::unique_ptr<DevBuf>> dxy(V), ddesc(V), ddt(V), dnorm(V);
+    std::vector<std::unique_ptr<DevBuf>> dxy(V), ddesc(V), ddt(V), dnorm(V), drm(V), df16(V);
     std::vector<pgi_desc_view> descView(V);
     std::vector<pgi_keypoint_view> kpView(V);
     std::vector<pgi_feature_view> featView(V);
@@ -229,9 +229,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         dnorm[v].reset(new DevBuf((size_t)n_pad * 4));
         h2d(dxy[v]->p, views[v].keypoints.data(), (size_t)n * 8);
         h2d(ddesc[v]->p, views[v].descriptors.data(), (size_t)n * PGI_DESC_DIM * 4);
+        drm[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 4));
+        df16[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 2));
         Engine::check(pgi_desc_prepare(ctx, ddesc[v]->as<float>(), n, ddt[v]->as<float>(), dnorm[v]->as<float>()));
+        Engine::check(pgi_desc_prepare_screen(ctx, ddesc[v]->as<float>(), n, drm[v]->as<float>(), df16[v]->as<uint16_t>()));
         const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
-        descView[v] = pgi_desc_view{ddt[v]->as<float>(), dnorm[v]->as<float>(), n, n_pad};
+        descView[v] = pgi_desc_view{ddt[v]->as<float>(), dnorm[v]->as<float>(), n, n_pad, drm[v]->as<float>(), df16[v]->as<uint16_t>()};
         kpView[v] = pgi_keypoint_view{dxy[v]->as<float>(), n, 0, f, f, cx, cy};
         featView[v] = pgi_feature_view{dxy[v]->as<float>(), ddesc[v]->as<float>(), n, 0, f, f, cx, cy};
     }

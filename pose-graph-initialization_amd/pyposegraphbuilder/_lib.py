@@ -51,14 +51,15 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_set_stream", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch",
            "pgi_estimate_pose", "pgi_score_pose_batch", "pgi_score_pose_f64", "pgi_decompose_batch",
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
-           "pgi_desc_prepare", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch"]
+           "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch"]
 
 _lib = None
 
 
 class DescView(C.Structure):
     """pgi_desc_view (include/pgi.h)."""
-    _fields_ = [("d_desc_t", C.c_void_p), ("d_norm", C.c_void_p), ("n", C.c_uint32), ("n_pad", C.c_uint32)]
+    _fields_ = [("d_desc_t", C.c_void_p), ("d_norm", C.c_void_p), ("n", C.c_uint32), ("n_pad", C.c_uint32),
+                ("d_desc_rm", C.c_void_p), ("d_desc_f16", C.c_void_p)]
 
 
 class KeypointView(C.Structure):
@@ -96,6 +97,7 @@ def load():
     lib.pgi_desc_padded.restype = C.c_uint32
     lib.pgi_desc_padded.argtypes = [C.c_uint32]
     lib.pgi_desc_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.pgi_desc_prepare_screen.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.pgi_match_descriptors_batch.argtypes = [C.c_void_p, C.POINTER(DescView), C.POINTER(DescView), C.c_uint32, C.c_uint32,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_build_correspondences.argtypes = [C.c_void_p, C.POINTER(KeypointView), C.POINTER(KeypointView), C.c_uint32, C.c_uint32,

@@ -163,8 +163,9 @@ class Engine:
         return R, iters.value
 
     # ---- descriptor matching (feature_utils.h:135-202) ------------------------------------------
-    def prepare_descriptors(self, desc):
-        """n x 128 float32 (numpy or device tensor) -> prepared image (transposed copy + norms in HBM)."""
+    def prepare_descriptors(self, desc, screen=True):
+        """n x 128 float32 (numpy or device tensor) -> prepared image (transposed copy + norms in HBM; with screen=True
+        also the padded row-major copy and its half-precision rounding that enable the screened matcher)."""
         d = torch.as_tensor(np.ascontiguousarray(desc, np.float32) if isinstance(desc, np.ndarray) else desc,
                             dtype=torch.float32, device=self.device).contiguous()
         n = int(d.shape[0])
@@ -175,7 +176,12 @@ class Engine:
         nrm = torch.empty(max(n_pad, 1), dtype=torch.float32, device=self.device)
         self._bind_stream()
         L.check(self._lib.pgi_desc_prepare(self._ctx, _ptr(d) if n else None, n, _ptr(dt), _ptr(nrm)))
-        return {"t": dt, "norm": nrm, "n": n, "n_pad": n_pad}
+        im = {"t": dt, "norm": nrm, "n": n, "n_pad": n_pad, "rm": None, "f16": None}
+        if screen:
+            im["rm"] = torch.empty((max(n_pad, 1), 128), dtype=torch.float32, device=self.device)
+            im["f16"] = torch.empty((max(n_pad, 1), 128), dtype=torch.int16, device=self.device)
+            L.check(self._lib.pgi_desc_prepare_screen(self._ctx, _ptr(d) if n else None, n, _ptr(im["rm"]), _ptr(im["f16"])))
+        return im
 
     def match_descriptors_batch(self, images, pairs, max_matches=None, raw=False):
         """images: list of prepared images; pairs: [(src, dst)] -> per pair (src_idx, dst_idx, ratio) sorted by ratio.
@@ -187,6 +193,8 @@ class Engine:
         for p, (s, d) in enumerate(pairs):
             for v, im in ((va[p], images[s]), (vb[p], images[d])):
                 v.d_desc_t, v.d_norm, v.n, v.n_pad = im["t"].data_ptr(), im["norm"].data_ptr(), im["n"], im["n_pad"]
+                v.d_desc_rm = im["rm"].data_ptr() if im.get("rm") is not None else None
+                v.d_desc_f16 = im["f16"].data_ptr() if im.get("f16") is not None else None
         src = torch.empty((max(P, 1), max_matches), dtype=torch.int32, device=self.device)
         dst = torch.empty_like(src)
         ratio = torch.empty((max(P, 1), max_matches), dtype=torch.float64, device=self.device)
