@@ -148,3 +148,35 @@ def test_gpu_descriptors_to_pose_on_device(eng, quirk, top_k):
         for p, (s, d) in enumerate(pairs):
             R_rel = poses[d][0] @ poses[s][0].T
             assert e["status"][p] == 1 and S.rot_err_deg(e["R"][p].reshape(3, 3), R_rel) < 0.5
+
+
+@pytest.mark.gpu
+def test_gpu_screened_matcher_stress_inputs(eng):
+    """Inputs chosen to stress the f16 screen's certificate: clustered descriptors (dozens of columns inside the
+    error window), raw integer SIFT (norm ~512), signed entries, zero rows, and norms beyond the f16 range (rows are
+    then re-scanned exactly).  The result must stay bit-identical to the oracle in every case."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    base, _, _ = S.make_descriptors(rng, 40, 2, overlap=0.0)
+    clustered = (base[rng.integers(0, 40, 500)] + 2e-4 * rng.standard_normal((500, 128))).astype(np.float32)
+    clustered2 = (base[rng.integers(0, 40, 450)] + 2e-4 * rng.standard_normal((450, 128))).astype(np.float32)
+    raw_a = np.floor(np.abs(rng.standard_normal((400, 128))) * 60).clip(0, 255).astype(np.float32)
+    raw_b = raw_a[rng.permutation(400)] + rng.integers(-3, 4, (400, 128)).astype(np.float32)
+    raw_b = raw_b.clip(0, 255).astype(np.float32)
+    signed_a = rng.standard_normal((300, 128)).astype(np.float32)
+    signed_b = (signed_a[rng.permutation(300)] + 0.05 * rng.standard_normal((300, 128))).astype(np.float32)
+    signed_b[:20] = 0.0                                        # zero descriptors
+    huge_a = (signed_a * 3e4).astype(np.float32)                 # squared norms ~1e11: outside the f16 range
+    huge_b = (signed_b * 3e4).astype(np.float32)
+    sets = [clustered, clustered2, raw_a, raw_b, signed_a, signed_b, huge_a, huge_b]
+    pairs = [(0, 1), (1, 0), (2, 3), (3, 2), (4, 5), (5, 4), (6, 7), (7, 6), (0, 5)]
+    _check(eng, sets, pairs)
+    eng._lib.pgi_internal_match_flagged.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    f, b = C.c_uint64(0), C.c_uint64(0)
+    assert eng._lib.pgi_internal_match_flagged(eng._ctx, C.byref(f), C.byref(b)) == 0
+    assert f.value > 500 and b.value > 500                      # the clustered and out-of-range sets did take the exact path
+    # ordinary data: the fallback stays rare
+    A, B, _ = S.make_descriptors(rng, 3000, 3000, overlap=0.6)
+    eng.match_descriptors_batch([eng.prepare_descriptors(A), eng.prepare_descriptors(B)], [(0, 1)], raw=True)
+    eng._lib.pgi_internal_match_flagged(eng._ctx, C.byref(f), C.byref(b))
+    assert f.value + b.value < 0.03 * 6000, (f.value, b.value)
