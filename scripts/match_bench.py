@@ -45,7 +45,7 @@ def main():
             eng._lib.pgi_internal_match_flagged.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             eng._lib.pgi_internal_match_flagged(eng._ctx, C.byref(f), C.byref(b))
         print("   rows re-scanned exactly: %d forward, %d backward (of %d)" % (f.value, b.value, P * K))
-        print("K=%d pairs=%d: %.3f ms  %.1f pairs/s  %.1f TFLOP/s (%.1f%% of 157.3)  mean matches %.0f" %
+        print("K=%d pairs=%d: %.3f ms  %.1f pairs/s  %.1f f32-equivalent TFLOP/s (%.1f%% of 157.3; >100%% possible on the screened path)  mean matches %.0f" %
               (K, P, dt * 1e3, P / dt, flop / dt / 1e12, 100 * flop / dt / 157.3e12, out[3][:P].float().mean().item()))
     t0 = time.perf_counter()
     for _ in range(20):
