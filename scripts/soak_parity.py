@@ -46,6 +46,26 @@ for ci, kw in enumerate(cases):
         sys.exit(1)
     total += P
     eng.close()
+# big pairs: every occupancy class of the bucketed launch (LDS rows at 3 and 2 workgroups per CU, rows from L2)
+rng = np.random.default_rng(77)
+Pb = max(256, P // 20)
+sizes = rng.choice([2176, 2177, 3000, 3904, 3905, 6000, 9024, 9025, 12000], Pb)
+b = S.make_batch(np.arange(7000000, 7000000 + Pb), sizes, inlier_ratio=0.45, noise_px=0.4)
+guesses = np.zeros((Pb, 12)); has = (rng.random(Pb) < 0.25).astype(np.uint8)
+for i in np.nonzero(has)[0]:
+    guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
+eng = Engine()
+db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has, seed=99)
+e, m = eng.estimate_pose_batch(db)
+got, masks = eng.edges_to_numpy(e), m.cpu().numpy()
+exp, emask = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(), 99,
+                                   guesses=guesses, has_guess=has, threads=0)
+ok = np.array_equal(masks, emask) and all(np.array_equal(got[k], exp[k]) for k in ("status", "n_inl", "score", "iters", "E", "R", "t", "votes", "cand", "used_guess", "lo_runs"))
+print("big pairs (2176..12000 rows): %d pairs, %d rows: %s" % (Pb, len(masks), "IDENTICAL" if ok else "MISMATCH"))
+if not ok:
+    sys.exit(1)
+total += Pb
+eng.close()
 print("estimator soak ok: %d pairs identical in %.0f s" % (total, time.time() - t00))
 
 # ---- matchers: screened descriptor matcher and guided matcher vs the oracle ----
