@@ -834,6 +834,8 @@ static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_de
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
         ctx->d_match_ws = nullptr;
         ctx->match_ws_bytes = 0;
+        ctx->d_match_cnt = nullptr;  // diagnostics pointer into the old workspace
+        ctx->match_cnt_pairs = 0;
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
@@ -926,6 +928,8 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
         ctx->d_match_ws = nullptr;
         ctx->match_ws_bytes = 0;
+        ctx->d_match_cnt = nullptr;  // diagnostics pointer into the old workspace
+        ctx->match_cnt_pairs = 0;
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
@@ -982,6 +986,8 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
         ctx->d_match_ws = nullptr;
         ctx->match_ws_bytes = 0;
+        ctx->d_match_cnt = nullptr;  // diagnostics pointer into the old workspace
+        ctx->match_cnt_pairs = 0;
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
@@ -1047,6 +1053,8 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
         ctx->d_match_ws = nullptr;
         ctx->match_ws_bytes = 0;
+        ctx->d_match_cnt = nullptr;  // diagnostics pointer into the old workspace
+        ctx->match_cnt_pairs = 0;
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
