@@ -32,6 +32,14 @@ struct pgi_ctx {
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
     bool lds_attr_set = false;
+    // double-buffered device slots of pgi_estimate_pose_batch_host (own streams: copies overlap kernels)
+    struct HostSlot {
+        void* d = nullptr;
+        size_t bytes = 0;
+        uint32_t* d_bucket = nullptr;
+        size_t bucket_bytes = 0;
+        hipStream_t stream = nullptr;
+    } hslot[2];
     void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
     size_t match_ws_bytes = 0;
     uint32_t* d_match_cnt = nullptr;  // per-pair flagged-row counters of the last screened match (forward, then backward)

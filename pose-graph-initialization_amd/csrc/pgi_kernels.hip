@@ -1141,6 +1141,11 @@ void pgi_destroy(pgi_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
+        if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
+        if (ctx->hslot[k].stream) (void)hipStreamDestroy(ctx->hslot[k].stream);
+    }
     delete ctx;
 }
 
@@ -1170,7 +1175,9 @@ int pgi_internal_set_profile_buffer(pgi_ctx* ctx, unsigned long long* d_buf) {
     return PGI_SUCCESS;
 }
 
-int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
+// enqueues K1 for a device-resident batch on `stream`; `bucket` is the caller's scratch for the size-bucket lists
+static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks, hipStream_t stream, uint32_t** bucket,
+                           size_t* bucket_cap) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1194,13 +1201,13 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + fixed;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<true, true>), dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<true, false>), dim3(b->n_pairs), dim3(NT), lds, ctx->stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<true, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<true, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<false, true>), dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<false, false>), dim3(b->n_pairs), dim3(NT), fixed, ctx->stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<false, true>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<false, false>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
     };
     if (!ctx->lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1218,17 +1225,18 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
         if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // ragged: bucket by row count on the device, one launch per occupancy class
         const size_t need = ((size_t)4 * b->n_pairs + 8) * sizeof(uint32_t);
-        if (need > ctx->bucket_bytes) {
-            if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
-            ctx->d_bucket = nullptr;
-            ctx->bucket_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&ctx->d_bucket, need));
-            ctx->bucket_bytes = need;
+        if (need > *bucket_cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (*bucket) (void)hipFree(*bucket);
+            *bucket = nullptr;
+            *bucket_cap = 0;
+            HIP_TRY(hipMalloc((void**)bucket, need));
+            *bucket_cap = need;
         }
-        uint32_t* counts = ctx->d_bucket;
-        uint32_t* lists = ctx->d_bucket + 8;
-        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, ctx->stream, b->d_offsets,
+        uint32_t* counts = *bucket;
+        uint32_t* lists = *bucket + 8;
+        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, stream, b->d_offsets,
                            b->n_pairs, cap3, cap2, cap1, lists, counts);
         const uint32_t caps[3] = {cap3, cap2, cap1};
         for (int k = 0; k < 4; ++k) {
@@ -1241,6 +1249,109 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
 }
+
+int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
+    if (!ctx) return fail(PGI_ERR_INVALID, "null argument");
+    return launch_estimate(ctx, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
+}
+
+// Host buffers in, host buffers out: the batch is cut into chunks that travel through two device slots on two
+// streams, so the H2D copy of chunk c+1 and the D2H copy of chunk c-1 overlap the kernel of chunk c (PCIe-inclusive
+// throughput ~ max(copy, compute) instead of their sum).  Pair ids are global, so the result equals the one-launch one.
+int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h_y1, const float* h_x2, const float* h_y2,
+                                 const uint64_t* h_offsets, const double* h_thr, const double* h_guess_Rt,
+                                 const uint8_t* h_has_guess, uint32_t n_pairs, uint64_t pair_id_base, uint64_t seed,
+                                 pgi_edge* h_edges, uint8_t* h_masks) {
+    if (!ctx) return fail(PGI_ERR_INVALID, "null ctx");
+    if (n_pairs == 0) return PGI_SUCCESS;
+    if (!h_x1 || !h_y1 || !h_x2 || !h_y2 || !h_offsets || !h_thr || !h_edges || !h_masks)
+        return fail(PGI_ERR_INVALID, "null argument");
+    if ((h_guess_Rt == nullptr) != (h_has_guess == nullptr)) return fail(PGI_ERR_INVALID, "guesses and flags go together");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool guesses = h_guess_Rt != nullptr;
+    // chunks of ~2.5 M rows (at least 256 pairs): big enough to fill the chip, small enough to pipeline
+    const uint64_t rows_total = h_offsets[n_pairs] - h_offsets[0];
+    const uint64_t target = std::max<uint64_t>(2500000ull, rows_total / 64 + 1);
+    std::vector<uint32_t> cuts(1, 0u);
+    for (uint32_t p = 0; p < n_pairs;) {
+        uint32_t q = p;
+        const uint64_t r0 = h_offsets[p];
+        while (q < n_pairs && (q - p < 256u || h_offsets[q + 1] - r0 <= target)) ++q;
+        cuts.push_back(q);
+        p = q;
+    }
+    const size_t n_chunks = cuts.size() - 1;
+    struct Lay { size_t x1, y1, x2, y2, off, thr, guess, has, edges, masks, total; };
+    auto layout = [&](uint64_t rows, uint32_t pairs) {
+        auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+        Lay L;
+        size_t o = 0;
+        L.x1 = o; o += up(rows * 4); L.y1 = o; o += up(rows * 4); L.x2 = o; o += up(rows * 4); L.y2 = o; o += up(rows * 4);
+        L.off = o; o += up(((size_t)pairs + 1) * 8); L.thr = o; o += up((size_t)pairs * 8);
+        L.guess = o; o += up((size_t)pairs * 96); L.has = o; o += up(pairs);
+        L.edges = o; o += up((size_t)pairs * sizeof(pgi_edge)); L.masks = o; o += up(rows);
+        L.total = o;
+        return L;
+    };
+    for (int k = 0; k < 2; ++k)
+        if (!ctx->hslot[k].stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->hslot[k].stream, hipStreamNonBlocking));
+    std::vector<uint64_t> off_local[2];
+    Lay lay[2];
+    auto drain = [&](size_t c) -> int {  // results of chunk c back to the host (blocks until its kernel is done)
+        pgi_ctx::HostSlot& S = ctx->hslot[c & 1];
+        const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
+        const uint64_t r0 = h_offsets[p0] - h_offsets[0], rows = h_offsets[p0 + np] - h_offsets[p0];
+        char* d = (char*)S.d;
+        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + lay[c & 1].edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, S.stream));
+        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + lay[c & 1].masks, rows, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        return PGI_SUCCESS;
+    };
+    for (size_t c = 0; c < n_chunks; ++c) {
+        pgi_ctx::HostSlot& S = ctx->hslot[c & 1];
+        const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
+        const uint64_t rbase = h_offsets[p0], rows = h_offsets[p0 + np] - rbase, r0 = rbase - h_offsets[0];
+        const Lay L = layout(rows, np);
+        lay[c & 1] = L;
+        if (L.total > S.bytes) {
+            if (S.d) (void)hipFree(S.d);
+            S.d = nullptr; S.bytes = 0;
+            HIP_TRY(hipMalloc(&S.d, L.total + L.total / 4));
+            S.bytes = L.total + L.total / 4;
+        }
+        char* d = (char*)S.d;
+        std::vector<uint64_t>& ol = off_local[c & 1];
+        ol.resize((size_t)np + 1);
+        uint32_t max_corr = 0;
+        for (uint32_t k = 0; k <= np; ++k) ol[k] = h_offsets[p0 + k] - rbase;
+        for (uint32_t k = 0; k < np; ++k) max_corr = std::max(max_corr, (uint32_t)(ol[k + 1] - ol[k]));
+        if (rows) {
+            HIP_TRY(hipMemcpyAsync(d + L.x1, h_x1 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.y1, h_y1 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.x2, h_x2 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(d + L.off, ol.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, S.stream));
+        HIP_TRY(hipMemcpyAsync(d + L.thr, h_thr + p0, (size_t)np * 8, hipMemcpyHostToDevice, S.stream));
+        if (guesses) {
+            HIP_TRY(hipMemcpyAsync(d + L.guess, h_guess_Rt + 12 * (size_t)p0, (size_t)np * 96, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.has, h_has_guess + p0, np, hipMemcpyHostToDevice, S.stream));
+        }
+        pgi_batch b{};
+        b.d_x1 = (const float*)(d + L.x1); b.d_y1 = (const float*)(d + L.y1); b.d_x2 = (const float*)(d + L.x2); b.d_y2 = (const float*)(d + L.y2);
+        b.d_offsets = (const uint64_t*)(d + L.off); b.d_thr = (const double*)(d + L.thr);
+        b.d_guess_Rt = guesses ? (const double*)(d + L.guess) : nullptr;
+        b.d_has_guess = guesses ? (const uint8_t*)(d + L.has) : nullptr;
+        b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
+        const int rc = launch_estimate(ctx, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
+        if (rc < 0) return rc;
+        // results of the previous chunk come back while this chunk's kernel runs; its slot is free again afterwards
+        if (c >= 1) { const int rc2 = drain(c - 1); if (rc2 < 0) return rc2; }
+    }
+    return drain(n_chunks - 1);
+}
+
 
 int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, const double* guesses, uint32_t g,
                       uint64_t seed, uint64_t pair_id, pgi_edge* h_edge, uint8_t* h_mask) {

@@ -89,6 +89,24 @@ class Engine:
         L.check(self._lib.pgi_estimate_pose_batch(self._ctx, C.byref(s), _ptr(edges), _ptr(masks)))
         return edges, masks[:rows]
 
+    def estimate_pose_batch_host(self, x1, y1, x2, y2, offsets, thr, guesses=None, has_guess=None, seed=0, pair_id_base=0):
+        """Host (numpy) SoA in, (edges structured array, masks) out; copies are pipelined against the kernels."""
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        x1, y1, x2, y2 = f(x1), f(y1), f(x2), f(y2)
+        off = np.ascontiguousarray(offsets, np.uint64)
+        P = len(off) - 1
+        thr = np.array(np.broadcast_to(thr, (P,)), np.float64)
+        g = hg = None
+        if guesses is not None:
+            g = np.ascontiguousarray(guesses, np.float64).reshape(P, 12)
+            hg = np.ones(P, np.uint8) if has_guess is None else np.ascontiguousarray(has_guess, np.uint8)
+        edges = np.zeros(P, L.EDGE_DTYPE)
+        masks = np.zeros(max(int(off[-1] - off[0]), 1), np.uint8)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        L.check(self._lib.pgi_estimate_pose_batch_host(self._ctx, p(x1), p(y1), p(x2), p(y2), p(off), p(thr), p(g), p(hg), P,
+                                                       int(pair_id_base), int(seed), p(edges), p(masks)))
+        return edges, masks[:int(off[-1] - off[0])]
+
     @staticmethod
     def edges_to_numpy(edges):
         return edges.cpu().numpy().view(L.EDGE_DTYPE).reshape(-1)

@@ -385,3 +385,38 @@ def test_size_bucketed_launches_match_oracle(eng):
     # a second call reuses the bucket workspace and is bit-identical
     edges2, masks2 = eng.estimate_pose_batch(db)
     assert np.array_equal(edges.cpu().numpy(), edges2.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_host_buffer_batch_equals_device_batch():
+    """pgi_estimate_pose_batch_host (chunked, two streams, copies overlapping kernels) == one launch on resident data."""
+    from pyposegraphbuilder import Engine
+    rng = np.random.default_rng(5150)
+    P = 3000
+    sizes = rng.choice([5, 40, 64, 300, 700, 1500, 2600, 4100], P)   # > 2.5 M rows: several chunks, ragged buckets
+    b = S.make_batch(np.arange(40000, 40000 + P), sizes)
+    guesses = np.zeros((P, 12))
+    has = (rng.random(P) < 0.2).astype(np.uint8)
+    for i in np.nonzero(has)[0]:
+        guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
+    eng = Engine()
+    try:
+        db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has, seed=11,
+                        pair_id_base=123)
+        e, m = eng.estimate_pose_batch(db)
+        ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+        got, got_m = eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses,
+                                                  has_guess=has, seed=11, pair_id_base=123)
+        assert np.array_equal(got_m, ref_m)
+        for k in ref.dtype.names:
+            assert np.array_equal(got[k], ref[k]), k
+        # without guesses, and a single tiny chunk
+        got2, m2 = eng.estimate_pose_batch_host(b["x1"][:int(b["offsets"][7])], b["y1"][:int(b["offsets"][7])],
+                                                b["x2"][:int(b["offsets"][7])], b["y2"][:int(b["offsets"][7])], b["offsets"][:8], 7.5e-4,
+                                                seed=11, pair_id_base=123)
+        db2 = eng.upload(b["x1"][:int(b["offsets"][7])], b["y1"][:int(b["offsets"][7])], b["x2"][:int(b["offsets"][7])],
+                         b["y2"][:int(b["offsets"][7])], b["offsets"][:8], 7.5e-4, seed=11, pair_id_base=123)
+        e2, mm2 = eng.estimate_pose_batch(db2)
+        assert np.array_equal(eng.edges_to_numpy(e2)["E"], got2["E"]) and np.array_equal(mm2.cpu().numpy(), m2)
+    finally:
+        eng.close()
