@@ -32,13 +32,6 @@ struct MatchPair {
     uint64_t col_off;  // column-best index of column 0 of this pair
 };
 
-// DS operations of one wavefront execute in order; this only keeps the compiler from moving LDS accesses across it
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // C/D layout of the 32x32 MFMA: register r of lane (c = lane & 31, h = lane >> 5) holds C[row][c]
 __device__ __forceinline__ uint32_t mfma_row(int r, uint32_t h) { return (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h; }
 
