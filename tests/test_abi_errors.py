@@ -17,6 +17,8 @@ def test_null_context_is_rejected_everywhere():
         lambda: lib.pgi_set_stream(z, z), lambda: lib.pgi_set_params(z, None), lambda: lib.pgi_synchronize(z),
         lambda: lib.pgi_estimate_pose_batch(z, None, z, z),
         lambda: lib.pgi_estimate_pose(z, z, 0, 0.0, z, 0, 0, 0, None, z),
+        lambda: lib.pgi_estimate_pose_batch_host(z, z, z, z, z, z, z, z, z, 1, 0, 0, z, z),
+        lambda: lib.pgi_desc_prepare_screen(z, z, 0, z, z),
         lambda: lib.pgi_desc_prepare(z, z, 0, z, z),
         lambda: lib.pgi_match_descriptors_batch(z, None, None, 1, 1, z, z, z, z),
         lambda: lib.pgi_build_correspondences(z, None, None, 1, 1, z, z, z, 0, 1.0, 0, z, z, z, z, z, z),
