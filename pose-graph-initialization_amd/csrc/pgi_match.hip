@@ -292,7 +292,9 @@ struct ScreenRow {
     uint32_t j[kCand];
 };
 
-template <int NW>
+// TOPK = 2: a row's two nearest columns are wanted (each lane keeps two columns + the value of its third);
+// TOPK = 1: only the nearest (the column-wise pass of the swapped problem): one column + the value of the second.
+template <int NW, int TOPK>
 __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPair* __restrict__ pairs, ScreenRow* __restrict__ out,
                                                                 uint32_t splits, uint32_t wgs_per_pair, uint64_t split_stride) {
     __shared__ __attribute__((aligned(16))) unsigned short bt[2][kTileJ * kD];  // 2 x 16 KB, MFMA operand order
@@ -362,14 +364,20 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
             for (int r = 0; r < 16; ++r) {
                 float d = fmaf(-2.0f, acc[sub][r], nar[r] + nbj[sub]);
                 d = jvalid ? d : INFINITY;  // (no clamp at 0: the window only needs |d~ - d| <= eps, and max(0, .) is 1-Lipschitz)
-                // keep the lane's best two columns and the value of its third: medians and selects, no branches
-                const bool lt1 = d < b1[r], lt2 = d < b2[r];
-                b3[r] = fminf(b3[r], fmaxf(b2[r], d));
-                const float nb2 = lt1 ? b1[r] : (lt2 ? d : b2[r]);
-                const uint32_t nj2 = lt1 ? j1[r] : (lt2 ? j : j2[r]);
-                b2[r] = nb2; j2[r] = nj2;
-                b1[r] = lt1 ? d : b1[r];
-                j1[r] = lt1 ? j : j1[r];
+                if constexpr (TOPK == 2) {  // the lane's best two columns and the value of its third: medians and selects
+                    const bool lt1 = d < b1[r], lt2 = d < b2[r];
+                    b3[r] = fminf(b3[r], fmaxf(b2[r], d));
+                    const float nb2 = lt1 ? b1[r] : (lt2 ? d : b2[r]);
+                    const uint32_t nj2 = lt1 ? j1[r] : (lt2 ? j : j2[r]);
+                    b2[r] = nb2; j2[r] = nj2;
+                    b1[r] = lt1 ? d : b1[r];
+                    j1[r] = lt1 ? j : j1[r];
+                } else {  // the lane's best column and the value of its second
+                    const bool lt1 = d < b1[r];
+                    b2[r] = fminf(b2[r], fmaxf(b1[r], d));
+                    b1[r] = fminf(b1[r], d);
+                    j1[r] = lt1 ? j : j1[r];
+                }
             }
         }
     }
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
     float nbm = 0.0f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) nbm = fmaxf(nbm, s_nbmax[ww]);
-    // per row: T = second smallest approximate distance over the 32 lanes of the row, window T + 2 eps
+    // per row: T = the TOPK-th smallest approximate distance over the 32 lanes of the row, window T + 2 eps
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float x1 = b1[r], x2 = b2[r];
@@ -389,10 +397,12 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
             x2 = n2;
         }
         const float eps = 2.0f * (kEpsS * sqrtf(nar[r] * nbm) + 3.4e-7f * (sqrtf(nar[r]) + sqrtf(nbm))) + 2.4e-7f * (nar[r] + nbm);
-        const float win = x2 + 2.0f * eps;  // +inf when the split has fewer than two valid columns: everything is kept
+        const float win = (TOPK == 2 ? x2 : x1) + 2.0f * eps;  // +inf when the split has too few valid columns: everything is kept
         const bool safe = nar[r] <= 3.0e9f && nbm <= 3.0e9f;  // f16 range; also false for NaN norms
-        const bool k1 = b1[r] <= win && b1[r] < INFINITY, k2 = b2[r] <= win && b2[r] < INFINITY;
-        const bool miss = (b3[r] <= win && b3[r] < INFINITY) || !safe;  // a third column of this lane could matter: not stored
+        const bool k1 = b1[r] <= win && b1[r] < INFINITY;
+        const bool k2 = TOPK == 2 && b2[r] <= win && b2[r] < INFINITY;
+        const float unstored = TOPK == 2 ? b3[r] : b2[r];  // best column of this lane that is NOT stored
+        const bool miss = (unstored <= win && unstored < INFINITY) || !safe;
         const unsigned long long m1 = __ballot(k1), m2 = __ballot(k2), mm = __ballot(miss);
         const uint32_t h1 = (uint32_t)(m1 >> (32u * h)), h2 = (uint32_t)(m2 >> (32u * h)), hm = (uint32_t)(mm >> (32u * h));
         const uint32_t n1 = __popc(h1), total = n1 + __popc(h2);
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(256) void desc_verify_kernel(const ScreenPair* __re
             ++seen;
         }
     }
-    if (P.n_b >= 2u && seen < 2u) flagged = true;
+    if (as_keys ? (P.n_b >= 1u && seen < 1u) : (P.n_b >= 2u && seen < 2u)) flagged = true;
     if (flagged) {  // queue the row in its pair's list (capacity n_a_pad)
         const uint32_t slot = atomicAdd(fb_count + blockIdx.y, 1u);
         fb_list[P.row_off + slot] = i;
@@ -852,8 +862,12 @@ static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_de
                          uint32_t as_keys, uint32_t* fb, uint32_t* cnt) {
         if (max_rb == 0) return;
         const uint32_t per_pair = max_rb * splits;
-        hipLaunchKernelGGL(desc_screen_kernel<NWS>, dim3(per_pair * n_pairs), dim3(NWS * 64), 0, ctx->stream, d_pairs, d_scr, splits, per_pair,
-                           stride);
+        if (as_keys)  // column-wise pass: only the nearest row of each column is needed
+            hipLaunchKernelGGL((desc_screen_kernel<NWS, 1>), dim3(per_pair * n_pairs), dim3(NWS * 64), 0, ctx->stream, d_pairs, d_scr, splits,
+                               per_pair, stride);
+        else
+            hipLaunchKernelGGL((desc_screen_kernel<NWS, 2>), dim3(per_pair * n_pairs), dim3(NWS * 64), 0, ctx->stream, d_pairs, d_scr, splits,
+                               per_pair, stride);
         hipLaunchKernelGGL(desc_verify_kernel, dim3((max_rows + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_scr, splits, stride,
                            max_rows, d_rows, d_keys, as_keys, fb, cnt);
         hipLaunchKernelGGL(desc_exact_rows_kernel, dim3(n_pairs < 16 ? 64 : 16, n_pairs), dim3(256), 0, ctx->stream, d_pairs, fb, cnt, d_rows,
