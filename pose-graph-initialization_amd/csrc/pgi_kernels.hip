@@ -1252,6 +1252,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, 
 
 int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
     if (!ctx) return fail(PGI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);  // the size-bucket scratch belongs to the context
     return launch_estimate(ctx, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
 }
 
@@ -1398,7 +1399,8 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
     b.d_guess_Rt = g ? (double*)(d + o_guess) : nullptr;
     b.d_has_guess = g ? (uint8_t*)(d + o_has) : nullptr;
     b.n_pairs = 1; b.max_corr = n; b.pair_id_base = pair_id; b.seed = seed;
-    int rc = pgi_estimate_pose_batch(ctx, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask));
+    // (the context is already locked here: go to the launcher, not through the locking entry point)
+    int rc = launch_estimate(ctx, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask), ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
     if (rc != PGI_SUCCESS) return rc;
     HIP_TRY(hipMemcpyAsync(h_edge, d + o_edge, sizeof(pgi_edge), hipMemcpyDeviceToHost, ctx->stream));
     if (n) HIP_TRY(hipMemcpyAsync(h_mask, d + o_mask, n, hipMemcpyDeviceToHost, ctx->stream));
