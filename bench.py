@@ -87,6 +87,18 @@ def main():
     edges = torch.empty((P, EDGE_RECORD_BYTES), dtype=torch.uint8, device=eng.device)
     masks = torch.empty(P * N, dtype=torch.uint8, device=eng.device)
     gathered = torch.empty((world * P, EDGE_RECORD_BYTES), dtype=torch.uint8, device=eng.device) if world > 1 else None
+    # the path's one exchange step goes through the C ABI (pgi_allgather_edges: RCCL inside libpgi.so on the engine's
+    # stream, bootstrapped here by shipping the 128-byte unique id through torch.distributed); if that cannot be set up
+    # the bench falls back to torch.distributed's own all-gather and says so in the JSON line
+    comm, exchange = None, "none (single GPU)"
+    if world > 1:
+        from pyposegraphbuilder import distributed as D
+        try:
+            comm = D.Communicator(eng, transport="rccl")
+            exchange = "pgi_allgather_edges (RCCL inside libpgi.so)"
+        except Exception as ex:  # noqa: BLE001
+            comm, exchange = None, "torch.distributed all_gather_into_tensor (C-ABI communicator unavailable: %s)" % ex
+    counts = [P] * world
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -97,7 +109,10 @@ def main():
         if i is not None:
             ev[i][1].record()
         if world > 1:  # the path's one exchange: per-edge records to every rank (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, edges)
+            if comm is not None:
+                comm.allgather_edges(edges, counts, out=gathered)
+            else:
+                dist.all_gather_into_tensor(gathered, edges)
 
     def fence():
         if world > 1:
@@ -148,7 +163,8 @@ def main():
                    "noise_px": 0.25, "thr_px": args.thr_px,
                    "mode": "fixed budget %d" % args.fixed_budget if args.fixed_budget else
                            "adaptive (confidence 0.99, cap 1000, rounds of 32)",
-                   "parallelism": "pairs sharded over %d GPU(s)%s" % (world, ", all-gather of edge records" if world > 1 else "")},
+                   "parallelism": "pairs sharded over %d GPU(s)%s" % (world, ", all-gather of edge records" if world > 1 else ""),
+                   "exchange": exchange},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "estimate_pose_kernel", "kernel_ms": round(kern_ms, 3),
@@ -286,8 +302,18 @@ def main():
         out["cpu_baseline"] = {"value": round(m / t_cpu, 1), "unit": "edges/s", "cores": int(cores), "kind": "port",
                                "sample": "first %d pairs of the same batch (%.1f s); build CPU restatement, not OpenCV" % (m, t_cpu),
                                "gpu_matches_on_sample": parity}
+    if world > 1:
+        # every rank must hold every rank's records after the exchange (checked outside the timed region)
+        g = eng.edges_to_numpy(gathered)
+        mine = g[rank * P:(rank + 1) * P]
+        okx = bool(np.array_equal(mine["E"], got["E"]) and np.array_equal(mine["n_inl"], got["n_inl"]))
+        flag = torch.tensor([1 if okx else 0], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out["exchange_verified"] = bool(flag.item())
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

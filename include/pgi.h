@@ -24,14 +24,15 @@
 extern "C" {
 #endif
 
-#define PGI_VERSION 1
+#define PGI_VERSION 2
 
 typedef enum {
     PGI_SUCCESS = 0,
     PGI_ERR_INVALID = -1,  /* bad argument                                   */
     PGI_ERR_DEVICE = -2,   /* HIP runtime error (message in pgi_last_error)  */
     PGI_ERR_NOMEM = -3,
-    PGI_ERR_TOO_LARGE = -4 /* a pair exceeds the supported correspondence count */
+    PGI_ERR_TOO_LARGE = -4, /* a pair exceeds the supported correspondence count */
+    PGI_ERR_COMM = -5       /* the multi-GPU exchange failed (RCCL error / callback error) */
 } pgi_error;
 
 /* per-edge status (pgi_edge.status) -- estimatePose's bool, refined */
@@ -98,11 +99,15 @@ int pgi_device_count(void);
 void pgi_default_params(pgi_params* p);
 
 /* device < 0: current device.  stream: a hipStream_t (e.g. torch's current
- * stream) or NULL for the default stream; all work is enqueued there. */
+ * stream) or NULL for the default stream; all work is enqueued there.
+ * pgi_set_stream orders the new stream after everything already enqueued on the
+ * previous one (event wait), because the asynchronous entry points share
+ * context-owned scratch.  pgi_set_params / pgi_set_stream are thread-safe. */
 pgi_ctx* pgi_create(int device, const pgi_params* params);
 void pgi_destroy(pgi_ctx* ctx);
 int pgi_set_stream(pgi_ctx* ctx, void* hip_stream);
 int pgi_set_params(pgi_ctx* ctx, const pgi_params* params);
+int pgi_get_params(pgi_ctx* ctx, pgi_params* params);
 int pgi_synchronize(pgi_ctx* ctx);
 
 /* ---- estimatePose, batched (asynchronous on the ctx stream) ------------- */
@@ -121,11 +126,18 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
 /* ---- estimatePose, literal drop-in (host pointers, synchronous, re-entrant)
  * corr_aos: n x 4 doubles [x1 y1 x2 y2] == cv::Mat N x 4 CV_64F (:946);
  * guesses_Rt: g x 12 doubles (the reference passes 0 or 1 guess, SURVEY §8a-12;
- * the LAST guess wins as in :974-1029); mask: n bytes (std::vector<uchar>).
+ * the LAST guess wins as in :974-1029); min_inliers: the seam's own
+ * kMinimumInlierNumber_ argument (:155; 0 = the context's parameter), applied
+ * to this call only; mask: n bytes (std::vector<uchar>).
+ * Re-entrant like the reference's seam, which is called from kCoreNumber OpenMP
+ * threads (:391-392): every call takes a private slot (own stream, device
+ * scratch and pinned staging) from a pool of PGI_PAIR_SLOTS, so concurrent
+ * callers overlap on the GPU instead of queueing behind one another.
  * Returns 1 (true), 0 (false) or a negative pgi_error. */
+#define PGI_PAIR_SLOTS 32
 int pgi_estimate_pose(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, double thr,
-                      const double* h_guesses_Rt, uint32_t g, uint64_t seed, uint64_t pair_id,
-                      pgi_edge* h_edge, uint8_t* h_mask);
+                      const double* h_guesses_Rt, uint32_t g, uint32_t min_inliers, uint64_t seed,
+                      uint64_t pair_id, pgi_edge* h_edge, uint8_t* h_mask);
 
 /* ---- getInliers / InTraversalPoseTester, batched ------------------------ */
 /* One model per pair.  d_E: n_pairs x 9 doubles.  d_tau2: per-pair bound on the
@@ -172,6 +184,45 @@ void pgi_default_rotavg_params(pgi_rotavg_params* p);
 int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_edges,
                          uint32_t n_views, const pgi_rotavg_params* prm, double* h_R_out,
                          uint32_t* h_iters_out);
+
+/* The same solve fed from the DEVICE-resident edge table the all-gather leaves on every rank (no
+ * 200-byte-per-edge host round trip): pair p = (h_src[p], h_dst[p]) with record d_edges[p]; records
+ * whose status is not PGI_EDGE_OK are skipped; weight = n_inl / h_rows[p] (the reference's edge score,
+ * pose_graph_builder.h:645-654; h_rows NULL = weight 1).  Only status/n_inl (8 B per pair) and the
+ * rotations of the spanning-forest edges travel to the host. */
+int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint32_t* h_src, const uint32_t* h_dst,
+                               const uint32_t* h_rows, uint32_t n_pairs, uint32_t n_views,
+                               const pgi_rotavg_params* prm, double* h_R_out, uint32_t* h_iters_out,
+                               uint32_t* h_edges_used);
+
+/* ---- multi-GPU: the path's single exchange step -----------------------------------
+ * Pairs are sharded over ranks (one process per GPU); every rank estimates its own block and the
+ * fixed-size edge records are all-gathered so that each rank holds the full table for the
+ * replicated rotation averaging / the next scheduler wave.  Two transports:
+ *   RCCL  (production: one GPU per rank, xGMI): rank 0 calls pgi_comm_unique_id, the caller ships the
+ *         128 bytes to the other ranks (any bootstrap: TCP, torch.distributed, MPI), every rank calls
+ *         pgi_comm_init_rccl.  Uneven blocks are gathered without padding as one grouped set of
+ *         ncclBroadcast(root = r) calls on the context stream (asynchronous).
+ *   host  (ranks sharing a device -- RCCL refuses that -- and CPU-side tests): the caller supplies an
+ *         all-gather-v over host memory; the records make a D2H / H2D hop (synchronous).
+ * Without a communicator (single process) pgi_allgather_edges degenerates to a device copy. */
+#define PGI_COMM_ID_BYTES 128
+/* gathers send_bytes from every rank into recv (rank order); recv_bytes[r] = bytes of rank r; 0 = ok */
+typedef int (*pgi_allgatherv_fn)(void* user, const void* h_send, uint64_t send_bytes, void* h_recv,
+                                 const uint64_t* recv_bytes, uint32_t world);
+int pgi_comm_unique_id(uint8_t id[PGI_COMM_ID_BYTES]);
+int pgi_comm_init_rccl(pgi_ctx* ctx, uint32_t world, uint32_t rank, const uint8_t id[PGI_COMM_ID_BYTES]);
+int pgi_comm_init_host(pgi_ctx* ctx, uint32_t world, uint32_t rank, pgi_allgatherv_fn fn, void* user);
+int pgi_comm_destroy(pgi_ctx* ctx);
+/* world = 1, rank = 0 without a communicator; *kind: 0 none, 1 RCCL, 2 host */
+int pgi_comm_info(pgi_ctx* ctx, uint32_t* world, uint32_t* rank, uint32_t* kind);
+/* h_counts[world]: records contributed by each rank (h_counts[rank] = this rank's; the partition is
+ * known to every rank by construction, so no size exchange is needed).  d_all receives sum(h_counts)
+ * records in rank order == global pair order for contiguous blocks.  d_local may alias its own slot
+ * of d_all. */
+int pgi_allgather_edges(pgi_ctx* ctx, const pgi_edge* d_local, const uint32_t* h_counts, pgi_edge* d_all);
+/* the same for raw bytes (inlier masks, match lists): h_bytes[world] */
+int pgi_allgatherv(pgi_ctx* ctx, const void* d_local, const uint64_t* h_bytes, void* d_all);
 
 /* ---- descriptor matching (feature_utils.h:135-202) ----------
  * The step that produces the correspondences estimatePose consumes: two brute-force

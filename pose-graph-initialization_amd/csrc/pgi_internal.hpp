@@ -1,6 +1,7 @@
 // pgi_internal.hpp -- shared by the translation units of libpgi.so (not part of the C ABI)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include "../../include/pgi.h"
@@ -24,14 +25,27 @@ struct pgi_ctx {
     hipStream_t stream;
     pgi_params prm;
     std::mutex mu;
-    // scratch for the single-pair drop-in
-    void* d_scratch = nullptr;
-    size_t scratch_bytes = 0;
     int max_lds = 0;
     unsigned long long* d_prof = nullptr;
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
-    bool lds_attr_set = false;
+    // pool of private slots for the re-entrant single-pair drop-in (pgi_estimate_pose): the reference's seam is
+    // called from kCoreNumber OpenMP threads (pose_graph_builder.h:391-392), so concurrent callers must overlap
+    struct PairSlot {
+        hipStream_t stream = nullptr;
+        void* d = nullptr;       // device scratch
+        void* h = nullptr;       // pinned staging (hipHostMalloc): true async DMA in both directions
+        size_t bytes = 0;
+        bool busy = false;
+    } pslot[PGI_PAIR_SLOTS];
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    // multi-GPU exchange (pgi_comm.hip)
+    uint32_t comm_world = 1, comm_rank = 0;
+    int comm_kind = 0;             // 0 none, 1 RCCL, 2 host callback
+    void* comm_rccl = nullptr;     // ncclComm_t
+    pgi_allgatherv_fn comm_fn = nullptr;
+    void* comm_user = nullptr;
     // double-buffered device slots of pgi_estimate_pose_batch_host (own streams: copies overlap kernels)
     struct HostSlot {
         void* d = nullptr;

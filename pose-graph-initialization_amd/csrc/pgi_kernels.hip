@@ -17,6 +17,7 @@
 #include "pgi_internal.hpp"
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -881,13 +882,19 @@ __global__ __launch_bounds__(256) void score_pose_kernel(const float* __restrict
     const float* py2 = y2 + o;
     uint8_t* pm = masks ? masks + o : nullptr;
     uint32_t cnt = 0;
-    // head rows until the float4 stream is 16-byte aligned (o is arbitrary)
-    const uint32_t head = min(n, (uint32_t)((4 - (o & 3)) & 3));
-    if ((uint32_t)lane < head) {
+    // Head rows until the float4 streams are 16-byte aligned.  The head is derived from the actual addresses (the
+    // caller's arrays may be slices); the vector body runs only if all four streams -- and the packed mask stores --
+    // share that alignment, otherwise every row takes the scalar path.
+    const uint32_t head_x = (uint32_t)((16u - ((uintptr_t)px1 & 15u)) & 15u) >> 2;
+    const bool vec_ok = (((uintptr_t)px1 | (uintptr_t)py1 | (uintptr_t)px2 | (uintptr_t)py2) & 3u) == 0 &&
+                        (((uintptr_t)px1 ^ (uintptr_t)py1) & 15u) == 0 && (((uintptr_t)px1 ^ (uintptr_t)px2) & 15u) == 0 &&
+                        (((uintptr_t)px1 ^ (uintptr_t)py2) & 15u) == 0 && (!pm || (((uintptr_t)pm + head_x) & 3u) == 0);
+    const uint32_t head = vec_ok ? min(n, head_x) : n;
+    for (uint32_t i = lane; i < head; i += 64) {
         float r2, den;
-        sampson_terms(e, px1[lane], py1[lane], px2[lane], py2[lane], r2, den);
+        sampson_terms(e, px1[i], py1[i], px2[i], py2[i], r2, den);
         const bool in = r2 < tau2 * den;
-        if (pm) pm[lane] = in;
+        if (pm) pm[i] = in;
         cnt += in;
     }
     const uint32_t nv = (n - head) / 4;
@@ -1130,6 +1137,9 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     int lds = 0;
     (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     c->max_lds = lds > 0 ? lds : 65536;
+    // K1 may use the whole LDS of a CU for staged rows
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
@@ -1138,7 +1148,12 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
 
 void pgi_destroy(pgi_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    (void)pgi_comm_destroy(ctx);
+    for (auto& S : ctx->pslot) {
+        if (S.d) (void)hipFree(S.d);
+        if (S.h) (void)hipHostFree(S.h);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+    }
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
     for (int k = 0; k < 2; ++k) {
@@ -1151,14 +1166,34 @@ void pgi_destroy(pgi_ctx* ctx) {
 
 int pgi_set_stream(pgi_ctx* ctx, void* s) {
     if (!ctx) return fail(PGI_ERR_INVALID, "null ctx");
-    ctx->stream = (hipStream_t)s;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t ns = (hipStream_t)s;
+    if (ns == ctx->stream) return PGI_SUCCESS;
+    // The asynchronous entry points share context-owned scratch (matching workspace, bucket lists): work enqueued
+    // on the new stream must not start before what is already queued on the old one has finished with it.
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ns, ev, 0);
+    (void)hipEventDestroy(ev);  // released once the recorded work completes
+    if (e != hipSuccess) return fail(PGI_ERR_DEVICE, std::string("pgi_set_stream: ") + hipGetErrorString(e));
+    ctx->stream = ns;
     return PGI_SUCCESS;
 }
 
 int pgi_set_params(pgi_ctx* ctx, const pgi_params* p) {
     if (!ctx || !p) return fail(PGI_ERR_INVALID, "null argument");
     if (!(p->confidence > 0.0 && p->confidence < 1.0)) return fail(PGI_ERR_INVALID, "confidence must be in (0,1)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->prm = *p;
+    return PGI_SUCCESS;
+}
+
+int pgi_get_params(pgi_ctx* ctx, pgi_params* p) {
+    if (!ctx || !p) return fail(PGI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *p = ctx->prm;
     return PGI_SUCCESS;
 }
 
@@ -1176,8 +1211,8 @@ int pgi_internal_set_profile_buffer(pgi_ctx* ctx, unsigned long long* d_buf) {
 }
 
 // enqueues K1 for a device-resident batch on `stream`; `bucket` is the caller's scratch for the size-bucket lists
-static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks, hipStream_t stream, uint32_t** bucket,
-                           size_t* bucket_cap) {
+static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks,
+                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1186,7 +1221,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, 
     a.x1 = b->d_x1; a.y1 = b->d_y1; a.x2 = b->d_x2; a.y2 = b->d_y2;
     a.off = b->d_offsets; a.thr = b->d_thr; a.guess = b->d_guess_Rt; a.has_guess = b->d_has_guess;
     a.edges = d_edges; a.masks = d_masks; a.n_pairs = b->n_pairs;
-    a.pair_id_base = b->pair_id_base; a.seed = b->seed; a.prm = ctx->prm;
+    a.pair_id_base = b->pair_id_base; a.seed = b->seed; a.prm = prm;
     a.prof = ctx->d_prof;
     a.pair_list = nullptr;
     a.pair_count = nullptr;
@@ -1209,13 +1244,6 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, 
         if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<false, true>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
         else hipLaunchKernelGGL((estimate_pose_kernel<false, false>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
     };
-    if (!ctx->lds_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ctx->max_lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)estimate_pose_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ctx->max_lds));
-        ctx->lds_attr_set = true;
-    }
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // Rows are staged in LDS only while at least `lds_min_wgs` workgroups still fit per CU; bigger pairs read
     // their rows from HBM/L2 at full occupancy instead (measured: faster than LDS at one workgroup per CU,
@@ -1224,6 +1252,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, 
     if (cap <= cap3 || b->n_pairs < 64) {  // uniform enough (or tiny): one launch sized for the largest pair
         if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // ragged: bucket by row count on the device, one launch per occupancy class
+        if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
         const size_t need = ((size_t)4 * b->n_pairs + 8) * sizeof(uint32_t);
         if (need > *bucket_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -1253,7 +1282,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, 
 int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks) {
     if (!ctx) return fail(PGI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(ctx->mu);  // the size-bucket scratch belongs to the context
-    return launch_estimate(ctx, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
+    return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
 }
 
 // Host buffers in, host buffers out: the batch is cut into chunks that travel through two device slots on two
@@ -1345,7 +1374,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         b.d_guess_Rt = guesses ? (const double*)(d + L.guess) : nullptr;
         b.d_has_guess = guesses ? (const uint8_t*)(d + L.has) : nullptr;
         b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
-        const int rc = launch_estimate(ctx, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
+        const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
         if (rc < 0) return rc;
         // results of the previous chunk come back while this chunk's kernel runs; its slot is free again afterwards
         if (c >= 1) { const int rc2 = drain(c - 1); if (rc2 < 0) return rc2; }
@@ -1354,57 +1383,97 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
 }
 
 
+namespace {
+// takes a free slot of the pool (blocks while all PGI_PAIR_SLOTS are busy); released by the destructor
+struct SlotLease {
+    pgi_ctx* ctx;
+    pgi_ctx::PairSlot* S;
+    explicit SlotLease(pgi_ctx* c) : ctx(c), S(nullptr) {
+        std::unique_lock<std::mutex> lk(ctx->slot_mu);
+        for (;;) {
+            pgi_ctx::PairSlot* fresh = nullptr;
+            for (auto& s : ctx->pslot) {
+                if (s.busy) continue;
+                if (s.stream) { S = &s; break; }  // prefer a slot whose stream and buffers already exist
+                if (!fresh) fresh = &s;
+            }
+            if (!S) S = fresh;
+            if (S) break;
+            ctx->slot_cv.wait(lk);
+        }
+        S->busy = true;
+    }
+    ~SlotLease() {
+        {
+            std::lock_guard<std::mutex> lk(ctx->slot_mu);
+            S->busy = false;
+        }
+        ctx->slot_cv.notify_one();
+    }
+};
+}  // namespace
+
 int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, const double* guesses, uint32_t g,
-                      uint64_t seed, uint64_t pair_id, pgi_edge* h_edge, uint8_t* h_mask) {
+                      uint32_t min_inliers, uint64_t seed, uint64_t pair_id, pgi_edge* h_edge, uint8_t* h_mask) {
     if (!ctx || !corr || !h_edge || !h_mask) return fail(PGI_ERR_INVALID, "null argument");
     if (g && !guesses) return fail(PGI_ERR_INVALID, "guess count without guesses");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
-    // layout of the scratch: x1 y1 x2 y2 (n floats each) | off[2] | thr | guess[12] | has | edge | mask
-    const size_t nf = ((size_t)n + 3) & ~(size_t)3;
-    const size_t bytes = 4 * nf * 4 + 16 + 8 + 96 + 8 + sizeof(pgi_edge) + nf + 64;
-    if (bytes > ctx->scratch_bytes) {
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->d_scratch, bytes));
-        ctx->scratch_bytes = bytes;
+    pgi_params prm;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        prm = ctx->prm;
     }
-    std::vector<char> h(bytes, 0);
-    float* hx1 = (float*)h.data();
+    if (min_inliers) prm.min_inliers = min_inliers;  // this call only (the seam's kMinimumInlierNumber_ argument)
+    HIP_TRY(hipSetDevice(ctx->device));
+    SlotLease lease(ctx);
+    pgi_ctx::PairSlot& S = *lease.S;
+    if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    // layout (host staging == device scratch): x1 y1 x2 y2 (nf floats each) | off[2] | thr | guess[12] | has | edge | mask
+    const size_t nf = ((size_t)n + 3) & ~(size_t)3;
+    const size_t o_off = 4 * nf * 4, o_thr = o_off + 16, o_guess = o_thr + 8, o_has = o_guess + 96, o_edge = o_has + 8,
+                 o_mask = o_edge + sizeof(pgi_edge), bytes = o_mask + nf + 64;
+    if (bytes > S.bytes) {
+        const size_t cap = bytes + bytes / 2;
+        if (S.d) (void)hipFree(S.d);
+        if (S.h) (void)hipHostFree(S.h);
+        S.d = S.h = nullptr;
+        S.bytes = 0;
+        HIP_TRY(hipMalloc(&S.d, cap));
+        HIP_TRY(hipHostMalloc(&S.h, cap, hipHostMallocDefault));
+        S.bytes = cap;
+    }
+    char* h = (char*)S.h;
+    char* d = (char*)S.d;
+    float* hx1 = (float*)h;
     float* hy1 = hx1 + nf;
     float* hx2 = hy1 + nf;
     float* hy2 = hx2 + nf;
-    for (uint32_t i = 0; i < n; ++i) {  // cv::Mat N x 4 CV_64F rows -> f32 SoA
+    for (uint32_t i = 0; i < n; ++i) {  // cv::Mat N x 4 CV_64F rows -> f32 SoA, straight into the pinned staging
         hx1[i] = (float)corr[4 * (size_t)i + 0];
         hy1[i] = (float)corr[4 * (size_t)i + 1];
         hx2[i] = (float)corr[4 * (size_t)i + 2];
         hy2[i] = (float)corr[4 * (size_t)i + 3];
     }
-    char* p = (char*)(hy2 + nf);
-    uint64_t* hoff = (uint64_t*)p; hoff[0] = 0; hoff[1] = n; p += 16;
-    *(double*)p = thr; const size_t o_thr = p - h.data(); p += 8;
-    const size_t o_guess = p - h.data();
-    if (g) memcpy(p, guesses + 12 * (size_t)(g - 1), 96);  // the last guess wins (:974-1029)
-    p += 96;
-    const size_t o_has = p - h.data(); *p = g ? 1 : 0; p += 8;
-    const size_t o_edge = p - h.data(); p += sizeof(pgi_edge);
-    const size_t o_mask = p - h.data();
-    char* d = (char*)ctx->d_scratch;
-    HIP_TRY(hipMemcpyAsync(d, h.data(), o_edge, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* hoff = (uint64_t*)(h + o_off);
+    hoff[0] = 0;
+    hoff[1] = n;
+    *(double*)(h + o_thr) = thr;
+    if (g) memcpy(h + o_guess, guesses + 12 * (size_t)(g - 1), 96);  // the last guess wins (:974-1029)
+    h[o_has] = g ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(d, h, o_edge, hipMemcpyHostToDevice, S.stream));
     pgi_batch b;
     b.d_x1 = (float*)d; b.d_y1 = b.d_x1 + nf; b.d_x2 = b.d_y1 + nf; b.d_y2 = b.d_x2 + nf;
-    b.d_offsets = (uint64_t*)(d + 4 * nf * 4);
+    b.d_offsets = (uint64_t*)(d + o_off);
     b.d_thr = (double*)(d + o_thr);
     b.d_guess_Rt = g ? (double*)(d + o_guess) : nullptr;
     b.d_has_guess = g ? (uint8_t*)(d + o_has) : nullptr;
     b.n_pairs = 1; b.max_corr = n; b.pair_id_base = pair_id; b.seed = seed;
-    // (the context is already locked here: go to the launcher, not through the locking entry point)
-    int rc = launch_estimate(ctx, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask), ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
+    // a single pair is never bucketed, so the launch needs no context-owned scratch and no context lock
+    int rc = launch_estimate(ctx, prm, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask), S.stream, nullptr, nullptr);
     if (rc != PGI_SUCCESS) return rc;
-    HIP_TRY(hipMemcpyAsync(h_edge, d + o_edge, sizeof(pgi_edge), hipMemcpyDeviceToHost, ctx->stream));
-    if (n) HIP_TRY(hipMemcpyAsync(h_mask, d + o_mask, n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h + o_edge, d + o_edge, sizeof(pgi_edge) + n, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    memcpy(h_edge, h + o_edge, sizeof(pgi_edge));
+    if (n) memcpy(h_mask, h + o_mask, n);
     return h_edge->status == PGI_EDGE_OK ? 1 : 0;
 }
 

@@ -454,12 +454,42 @@ __global__ __launch_bounds__(256) void rot_update_kernel(uint32_t n_views, const
     for (int c = 0; c < 9; ++c) R[9 * (size_t)k + c] = Rn[c];
 }
 
+// pgi_edge records (status OK) -> rotation-graph edges, all on the device: idx[e] = pair of edge e
+__global__ __launch_bounds__(256) void rot_edges_from_table_kernel(const pgi_edge* __restrict__ table, const uint32_t* __restrict__ idx,
+                                                                    const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst,
+                                                                    const double* __restrict__ weight, uint32_t n_edges,
+                                                                    RotEdgeDev* __restrict__ out) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const pgi_edge* rec = table + idx[e];
+    RotEdgeDev o;
+    o.src = src[e];
+    o.dst = dst[e];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o.R[c] = rec->R[c];
+    o.weight = weight[e];
+    out[e] = o;
+}
+// rotations of selected edges (the spanning forest's) -> a dense array for the host
+__global__ __launch_bounds__(256) void rot_gather_R_kernel(const RotEdgeDev* __restrict__ edges, const uint32_t* __restrict__ sel,
+                                                           uint32_t n_sel, double* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_sel) return;
+    const RotEdgeDev* e = edges + sel[k];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) out[9 * (size_t)k + c] = e->R[c];
+}
+
 // ---- host: maximum-weight spanning forest + BFS initialisation ----------------------------------------
-static void spanning_forest_init(uint32_t V, const pgi_rot_edge* E, uint32_t nE, std::vector<double>& R,
-                                 std::vector<uint8_t>& is_root) {
+struct ForestEdge {
+    uint32_t edge, other;  // other | inv << 31
+};
+// Kruskal on (weight desc, edge index asc); returns the forest's edge list and its adjacency
+static void spanning_forest(uint32_t V, const uint32_t* src, const uint32_t* dst, const double* weight, uint32_t nE,
+                            std::vector<uint32_t>& tree, std::vector<std::vector<ForestEdge>>& adj) {
     std::vector<uint32_t> order(nE);
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return E[a].weight > E[b].weight; });
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
     std::vector<uint32_t> parent(V);
     std::iota(parent.begin(), parent.end(), 0u);
     auto find = [&](uint32_t a) {
@@ -469,14 +499,21 @@ static void spanning_forest_init(uint32_t V, const pgi_rot_edge* E, uint32_t nE,
         }
         return a;
     };
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> adj(V);  // (edge, other|inv<<31)
+    adj.assign(V, {});
+    tree.clear();
     for (uint32_t e : order) {
-        const uint32_t a = find(E[e].src), b = find(E[e].dst);
+        const uint32_t a = find(src[e]), b = find(dst[e]);
         if (a == b) continue;
         parent[std::max(a, b)] = std::min(a, b);
-        adj[E[e].src].push_back({e, E[e].dst});
-        adj[E[e].dst].push_back({e, E[e].src | 0x80000000u});
+        adj[src[e]].push_back({e, dst[e]});
+        adj[dst[e]].push_back({e, src[e] | 0x80000000u});
+        tree.push_back(e);
     }
+}
+// BFS over the forest; R_of(e) = pointer to the 9 doubles of edge e's relative rotation
+template <class RofE>
+static void forest_bfs_init(uint32_t V, const std::vector<std::vector<ForestEdge>>& adj, RofE R_of, std::vector<double>& R,
+                            std::vector<uint8_t>& is_root) {
     R.assign((size_t)V * 9, 0.0);
     is_root.assign(V, 0);
     std::vector<uint8_t> seen(V, 0);
@@ -489,12 +526,12 @@ static void spanning_forest_init(uint32_t V, const pgi_rot_edge* E, uint32_t nE,
         queue.assign(1, root);
         for (size_t h = 0; h < queue.size(); ++h) {
             const uint32_t u = queue[h];
-            for (auto& pr : adj[u]) {
-                const uint32_t e = pr.first, v = pr.second & 0x7FFFFFFFu;
-                const bool inv = pr.second >> 31;
+            for (const ForestEdge& pr : adj[u]) {
+                const uint32_t e = pr.edge, v = pr.other & 0x7FFFFFFFu;
+                const bool inv = pr.other >> 31;
                 if (seen[v]) continue;
                 seen[v] = 1;
-                const double* Rr = E[e].R;
+                const double* Rr = R_of(e);
                 const double* Ru = &R[9 * (size_t)u];
                 double* Rv = &R[9 * (size_t)v];
                 for (int i = 0; i < 3; ++i)
@@ -509,57 +546,28 @@ static void spanning_forest_init(uint32_t V, const pgi_rot_edge* E, uint32_t nE,
     }
 }
 
-}  // namespace pgi
-
-using namespace pgi;
-
-extern "C" {
-
-void pgi_default_rotavg_params(pgi_rotavg_params* p) {
-    p->l1_iters = 5;
-    p->irls_iters = 100;
-    p->cg_iters = 200;
-    p->sigma_deg = 5.0;
-    p->tol = 1e-8;
-}
-
-int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_edges, uint32_t n_views,
-                         const pgi_rotavg_params* prm_in, double* h_R_out, uint32_t* h_iters_out) {
-    if (!ctx || !h_R_out || (n_edges && !h_edges)) return fail(PGI_ERR_INVALID, "null argument");
-    pgi_rotavg_params prm;
-    if (prm_in) prm = *prm_in; else pgi_default_rotavg_params(&prm);
-    for (uint32_t e = 0; e < n_edges; ++e)
-        if (h_edges[e].src >= n_views || h_edges[e].dst >= n_views || h_edges[e].src == h_edges[e].dst)
-            return fail(PGI_ERR_INVALID, "edge endpoints out of range");
-    if (n_views == 0) return PGI_SUCCESS;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<double> R;
-    std::vector<uint8_t> is_root;
-    spanning_forest_init(n_views, h_edges, n_edges, R, is_root);
-    if (h_iters_out) *h_iters_out = 0;
-    if (n_edges == 0) {
-        memcpy(h_R_out, R.data(), R.size() * 8);
-        return PGI_SUCCESS;
-    }
+// The solve proper.  The rotation-graph edges are already in HBM at d_rot (RotEdgeDev[n_edges]); the host holds only
+// their endpoints, the initial rotations and the root flags.
+static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_views, uint32_t n_edges, const uint32_t* h_src,
+                        const uint32_t* h_dst, const RotEdgeDev* d_rot, const std::vector<double>& R,
+                        const std::vector<uint8_t>& is_root, double* h_R_out, uint32_t* h_iters_out) {
     // CSR adjacency, incidences in edge order
     std::vector<uint32_t> ptr(n_views + 1, 0), aedge(2 * (size_t)n_edges), aother(2 * (size_t)n_edges);
     std::vector<int8_t> asign(2 * (size_t)n_edges);
     for (uint32_t e = 0; e < n_edges; ++e) {
-        ++ptr[h_edges[e].src + 1];
-        ++ptr[h_edges[e].dst + 1];
+        ++ptr[h_src[e] + 1];
+        ++ptr[h_dst[e] + 1];
     }
     for (uint32_t k = 0; k < n_views; ++k) ptr[k + 1] += ptr[k];
     {
         std::vector<uint32_t> fill(ptr.begin(), ptr.end() - 1);
         for (uint32_t e = 0; e < n_edges; ++e) {
-            uint32_t a = fill[h_edges[e].src]++;
-            aedge[a] = e; aother[a] = h_edges[e].dst; asign[a] = -1;
-            a = fill[h_edges[e].dst]++;
-            aedge[a] = e; aother[a] = h_edges[e].src; asign[a] = +1;
+            uint32_t a = fill[h_src[e]]++;
+            aedge[a] = e; aother[a] = h_dst[e]; asign[a] = -1;
+            a = fill[h_dst[e]]++;
+            aedge[a] = e; aother[a] = h_src[e]; asign[a] = +1;
         }
     }
-    static_assert(sizeof(RotEdgeDev) == sizeof(pgi_rot_edge), "edge layout");
     const size_t V = n_views, E = n_edges;
     // one allocation, carved
     size_t off = 0;
@@ -568,7 +576,7 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    const size_t o_edges = carve(E * sizeof(pgi_rot_edge)), o_R = carve(V * 72), o_ptr = carve((V + 1) * 4),
+    const size_t o_R = carve(V * 72), o_ptr = carve((V + 1) * 4),
                  o_aedge = carve(2 * E * 4), o_aother = carve(2 * E * 4), o_asign = carve(2 * E),
                  o_root = carve(V), o_omega = carve(E * 24), o_w = carve(E * 8), o_diag = carve(V * 8),
                  o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24),
@@ -581,7 +589,6 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
         ~Guard() { (void)hipFree(p); }
     } guard{d};
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d + o_edges, h_edges, E * sizeof(pgi_rot_edge), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_R, R.data(), V * 72, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_ptr, ptr.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_aedge, aedge.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
@@ -591,9 +598,8 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
     const double sigma = prm.sigma_deg * 3.14159265358979323846 / 180.0;
     uint32_t iters = 0;
     for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
-        hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st,
-                           (const RotEdgeDev*)(d + o_edges), n_edges, (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0,
-                           sigma, (double*)(d + o_omega), (double*)(d + o_w));
+        hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_rot, n_edges,
+                           (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0, sigma, (double*)(d + o_omega), (double*)(d + o_w));
         if (n_views <= kSingleWgViews) {
             hipLaunchKernelGGL(rot_solve_kernel, dim3(1), dim3(1024), 0, st, n_views, (const uint32_t*)(d + o_ptr),
                                (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const int8_t*)(d + o_asign),
@@ -655,6 +661,132 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
     HIP_TRY(hipStreamSynchronize(st));
     if (h_iters_out) *h_iters_out = iters;
     return PGI_SUCCESS;
+}
+
+}  // namespace pgi
+
+using namespace pgi;
+
+extern "C" {
+
+void pgi_default_rotavg_params(pgi_rotavg_params* p) {
+    p->l1_iters = 5;
+    p->irls_iters = 100;
+    p->cg_iters = 200;
+    p->sigma_deg = 5.0;
+    p->tol = 1e-8;
+}
+
+int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_edges, uint32_t n_views,
+                         const pgi_rotavg_params* prm_in, double* h_R_out, uint32_t* h_iters_out) {
+    if (!ctx || !h_R_out || (n_edges && !h_edges)) return fail(PGI_ERR_INVALID, "null argument");
+    pgi_rotavg_params prm;
+    if (prm_in) prm = *prm_in; else pgi_default_rotavg_params(&prm);
+    for (uint32_t e = 0; e < n_edges; ++e)
+        if (h_edges[e].src >= n_views || h_edges[e].dst >= n_views || h_edges[e].src == h_edges[e].dst)
+            return fail(PGI_ERR_INVALID, "edge endpoints out of range");
+    if (n_views == 0) return PGI_SUCCESS;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> src(n_edges), dst(n_edges), tree;
+    std::vector<double> wt(n_edges);
+    for (uint32_t e = 0; e < n_edges; ++e) {
+        src[e] = h_edges[e].src;
+        dst[e] = h_edges[e].dst;
+        wt[e] = h_edges[e].weight;
+    }
+    std::vector<std::vector<ForestEdge>> adj;
+    spanning_forest(n_views, src.data(), dst.data(), wt.data(), n_edges, tree, adj);
+    std::vector<double> R;
+    std::vector<uint8_t> is_root;
+    forest_bfs_init(n_views, adj, [&](uint32_t e) { return h_edges[e].R; }, R, is_root);
+    if (h_iters_out) *h_iters_out = 0;
+    if (n_edges == 0) {
+        memcpy(h_R_out, R.data(), R.size() * 8);
+        return PGI_SUCCESS;
+    }
+    static_assert(sizeof(RotEdgeDev) == sizeof(pgi_rot_edge), "edge layout");
+    RotEdgeDev* d_rot = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rot, (size_t)n_edges * sizeof(RotEdgeDev)));
+    struct Guard {
+        void* p;
+        ~Guard() { (void)hipFree(p); }
+    } guard{d_rot};
+    HIP_TRY(hipMemcpyAsync(d_rot, h_edges, (size_t)n_edges * sizeof(pgi_rot_edge), hipMemcpyHostToDevice, ctx->stream));
+    return rotavg_solve(ctx, prm, n_views, n_edges, src.data(), dst.data(), d_rot, R, is_root, h_R_out, h_iters_out);
+}
+
+int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint32_t* h_src, const uint32_t* h_dst,
+                               const uint32_t* h_rows, uint32_t n_pairs, uint32_t n_views, const pgi_rotavg_params* prm_in,
+                               double* h_R_out, uint32_t* h_iters_out, uint32_t* h_edges_used) {
+    if (!ctx || !h_R_out || (n_pairs && (!d_edges || !h_src || !h_dst))) return fail(PGI_ERR_INVALID, "null argument");
+    pgi_rotavg_params prm;
+    if (prm_in) prm = *prm_in; else pgi_default_rotavg_params(&prm);
+    if (h_iters_out) *h_iters_out = 0;
+    if (h_edges_used) *h_edges_used = 0;
+    if (n_views == 0) return PGI_SUCCESS;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // (status, n_inl) of every record: an 8-byte column of the 200-byte table
+    struct Meta { int32_t status; uint32_t n_inl; };
+    std::vector<Meta> meta(n_pairs);
+    if (n_pairs) {
+        HIP_TRY(hipMemcpy2DAsync(meta.data(), sizeof(Meta), (const char*)d_edges + offsetof(pgi_edge, status), sizeof(pgi_edge),
+                                 sizeof(Meta), n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    std::vector<uint32_t> idx, src, dst;
+    std::vector<double> wt;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        if (meta[p].status != PGI_EDGE_OK) continue;
+        if (h_src[p] >= n_views || h_dst[p] >= n_views || h_src[p] == h_dst[p])
+            return fail(PGI_ERR_INVALID, "edge endpoints out of range");
+        idx.push_back(p);
+        src.push_back(h_src[p]);
+        dst.push_back(h_dst[p]);
+        wt.push_back(h_rows ? (double)meta[p].n_inl / (double)std::max<uint32_t>(1u, h_rows[p]) : 1.0);
+    }
+    const uint32_t nE = (uint32_t)idx.size();
+    if (h_edges_used) *h_edges_used = nE;
+    std::vector<uint32_t> tree;
+    std::vector<std::vector<ForestEdge>> adj;
+    spanning_forest(n_views, src.data(), dst.data(), wt.data(), nE, tree, adj);
+    std::vector<double> R;
+    std::vector<uint8_t> is_root;
+    if (nE == 0) {
+        forest_bfs_init(n_views, adj, [&](uint32_t) { return (const double*)nullptr; }, R, is_root);
+        memcpy(h_R_out, R.data(), R.size() * 8);
+        return PGI_SUCCESS;
+    }
+    const size_t nT = tree.size();
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_rot = 0, o_idx = up((size_t)nE * sizeof(RotEdgeDev)), o_src = o_idx + up((size_t)nE * 4),
+                 o_dst = o_src + up((size_t)nE * 4), o_wt = o_dst + up((size_t)nE * 4), o_tree = o_wt + up((size_t)nE * 8),
+                 o_treeR = o_tree + up(nT * 4), total = o_treeR + up(nT * 72);
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, total));
+    struct Guard {
+        void* p;
+        ~Guard() { (void)hipFree(p); }
+    } guard{d};
+    HIP_TRY(hipMemcpyAsync(d + o_idx, idx.data(), (size_t)nE * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_src, src.data(), (size_t)nE * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_dst, dst.data(), (size_t)nE * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_wt, wt.data(), (size_t)nE * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_tree, tree.data(), nT * 4, hipMemcpyHostToDevice, st));
+    RotEdgeDev* d_rot = (RotEdgeDev*)(d + o_rot);
+    hipLaunchKernelGGL(rot_edges_from_table_kernel, dim3((nE + 255) / 256), dim3(256), 0, st, d_edges, (const uint32_t*)(d + o_idx),
+                       (const uint32_t*)(d + o_src), (const uint32_t*)(d + o_dst), (const double*)(d + o_wt), nE, d_rot);
+    hipLaunchKernelGGL(rot_gather_R_kernel, dim3(((uint32_t)nT + 255) / 256), dim3(256), 0, st, d_rot, (const uint32_t*)(d + o_tree),
+                       (uint32_t)nT, (double*)(d + o_treeR));
+    std::vector<double> treeR(nT * 9);
+    HIP_TRY(hipMemcpyAsync(treeR.data(), d + o_treeR, nT * 72, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> slot(nE, 0u);  // edge -> position in the forest list
+    for (size_t k = 0; k < nT; ++k) slot[tree[k]] = (uint32_t)k;
+    forest_bfs_init(n_views, adj, [&](uint32_t e) { return &treeR[9 * (size_t)slot[e]]; }, R, is_root);
+    return rotavg_solve(ctx, prm, n_views, nE, src.data(), dst.data(), d_rot, R, is_root, h_R_out, h_iters_out);
 }
 
 }  // extern "C"

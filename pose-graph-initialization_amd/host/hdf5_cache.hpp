@@ -16,6 +16,7 @@
 #include <limits>
 
 #include "graph_traversal.hpp"
+#include "reconstruction.hpp"
 #include "utils.hpp"
 
 namespace reconstruction {
@@ -163,11 +164,13 @@ inline bool saveCorrespondences(Hdf5File& db, const std::string& src, const std:
 // optionally, correspondences.h5.  Keypoint DETECTION is out of scope: keypoints.h5 must be finished (:1100-1168).
 inline PoseGraphBuilder::FeatureRunStatistics runWorkspace(PoseGraphBuilder& builder, const std::string& kFocalLengthPath,
                                                            const std::string& kSimilarityGraphPath, const std::string& kWorkspacePath,
-                                                           double kSimilarityThreshold, PoseGraph& poseGraph_, size_t waveSize = 1024) {
+                                                           double kSimilarityThreshold, PoseGraph& poseGraph_, size_t waveSize = 1024,
+                                                           Reconstruction* reconstruction_ = nullptr) {
     std::vector<ImageData> imageData;
     size_t totalImageNumber = 0;
     if (!load1DSfMImageList(kFocalLengthPath, totalImageNumber, imageData)) throw PgiError("cannot read " + kFocalLengthPath);
     if (!loadImageData(kWorkspacePath + "image_data.h5", imageData)) throw PgiError("cannot read image_data.h5");
+    if (reconstruction_) builder.initializeReconstruction(imageData.size(), imageData, *reconstruction_, poseGraph_);  // :213-217
     Hdf5File keypointDb(kWorkspacePath + "keypoints.h5", /*readOnly*/ true);
     if (!keypointDb.isOpen() || !keypointDb.atexists("finished")) throw PgiError("keypoints.h5 missing or not finished");
     const size_t V = imageData.size();
@@ -202,4 +205,14 @@ inline PoseGraphBuilder::FeatureRunStatistics runWorkspace(PoseGraphBuilder& bui
 }
 
 }  // namespace cache
+
+// The reference's outer entry point (pose_graph_builder.h:69-71, 173-239) with its own argument list: everything
+// else comes from the 17 constructor arguments.  Ends like the reference (:711-714): statistics, then the edge count.
+inline void PoseGraphBuilder::run(Reconstruction& reconstruction_, PoseGraph& poseGraph_) {
+    cache::runWorkspace(*this, kFocalLengthPath, kSimilarityGraphPath, kWorkspacePath, kSimilarityThreshold, poseGraph_, 1024,
+                        &reconstruction_);
+    statistics.print();
+    std::printf("Edges in the pose-graph = %d\n", (int)poseGraph_.numEdges());
+}
+
 }  // namespace reconstruction

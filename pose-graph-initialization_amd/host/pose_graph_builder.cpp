@@ -1,6 +1,8 @@
 // pose_graph_builder.cpp -- implementation of the C++ host layer (links against libpgi.so).
 // HIP is used here for device buffers and copies only; every computation is a C-ABI call.
+#include "distributed.hpp"
 #include "graph_traversal.hpp"
+#include "reconstruction.hpp"
 #include "tracklets.hpp"
 
 #include <hip/hip_runtime.h>
@@ -61,80 +63,105 @@ struct DeviceBatch {
 };
 }  // namespace
 
+uint32_t PoseGraphBuilder::worldSize() const { return hostComm ? hostComm->world() : 1u; }
+uint32_t PoseGraphBuilder::worldRank() const { return hostComm ? hostComm->rank() : 0u; }
+
 size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
-                                       std::vector<pgi_edge>* edges_out, bool screenGuesses) {
+                                       std::vector<pgi_edge>* edges_out, bool screenGuesses, pgi_edge* d_edges_out) {
     const size_t P = pairs.size();
     if (!P) return 0;
-    std::vector<uint64_t> off(P + 1, 0);
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t0 = Clock::now();
+    // this rank's contiguous, row-balanced block [lo, hi) of the wave
+    const uint32_t world = worldSize(), rank = worldRank();
+    std::vector<uint64_t> rowsPerPair(P);
+    for (size_t i = 0; i < P; ++i) rowsPerPair[i] = (uint64_t)pairs[i].correspondences.rows;
+    const std::vector<std::pair<size_t, size_t>> blocks = dist::shardBounds(rowsPerPair, world);
+    const size_t lo = blocks[rank].first, hi = blocks[rank].second, L = hi - lo;
+    std::vector<uint64_t> off(L + 1, 0);
     uint32_t max_corr = 0;
-    for (size_t i = 0; i < P; ++i) {
-        off[i + 1] = off[i] + (uint64_t)pairs[i].correspondences.rows;
-        max_corr = std::max(max_corr, (uint32_t)pairs[i].correspondences.rows);
+    for (size_t k = 0; k < L; ++k) {
+        off[k + 1] = off[k] + rowsPerPair[lo + k];
+        max_corr = std::max(max_corr, (uint32_t)rowsPerPair[lo + k]);
     }
-    const size_t rows = off[P];
+    const size_t rows = off[L];
     std::vector<float> x1(rows), y1(rows), x2(rows), y2(rows);
-    std::vector<double> thr(P), guess(12 * P, 0.0);
-    std::vector<uint8_t> has(P, 0);
+    std::vector<double> thr(L), guess(12 * L, 0.0);
+    std::vector<uint8_t> has(L, 0);
     bool any_guess = false;
-    for (size_t i = 0; i < P; ++i) {
-        const CorrespondenceMatrix& c = pairs[i].correspondences;
+    for (size_t k = 0; k < L; ++k) {
+        const ViewPair& vp = pairs[lo + k];
+        const CorrespondenceMatrix& c = vp.correspondences;
         for (int r = 0; r < c.rows; ++r) {
             const double* q = c.ptr(r);
-            const size_t k = off[i] + (size_t)r;
-            x1[k] = (float)q[0]; y1[k] = (float)q[1]; x2[k] = (float)q[2]; y2[k] = (float)q[3];
+            const size_t o = off[k] + (size_t)r;
+            x1[o] = (float)q[0]; y1[o] = (float)q[1]; x2[o] = (float)q[2]; y2[o] = (float)q[3];
         }
-        thr[i] = pairs[i].normalizedThreshold;
-        if (!pairs[i].poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
-            const SE3d& g = pairs[i].poseGuesses.back();
-            for (int c2 = 0; c2 < 9; ++c2) guess[12 * i + c2] = g.R[c2];
-            for (int c2 = 0; c2 < 3; ++c2) guess[12 * i + 9 + c2] = g.t[c2];
-            has[i] = 1;
+        thr[k] = vp.normalizedThreshold;
+        if (!vp.poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
+            const SE3d& g = vp.poseGuesses.back();
+            for (int c2 = 0; c2 < 9; ++c2) guess[12 * k + c2] = g.R[c2];
+            for (int c2 = 0; c2 < 3; ++c2) guess[12 * k + 9 + c2] = g.t[c2];
+            has[k] = 1;
             any_guess = true;
         }
     }
-    DevBuf dx1(rows * 4), dy1(rows * 4), dx2(rows * 4), dy2(rows * 4), doff((P + 1) * 8), dthr(P * 8),
-        dguess(P * 96), dhas(P), dedges(P * sizeof(pgi_edge)), dmasks(rows);
-    h2d(dx1.p, x1.data(), rows * 4); h2d(dy1.p, y1.data(), rows * 4);
-    h2d(dx2.p, x2.data(), rows * 4); h2d(dy2.p, y2.data(), rows * 4);
-    h2d(doff.p, off.data(), (P + 1) * 8); h2d(dthr.p, thr.data(), P * 8);
-    pgi_batch b{};
-    b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
-    b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
-    b.d_guess_Rt = any_guess ? dguess.as<double>() : nullptr;
-    b.d_has_guess = any_guess ? dhas.as<uint8_t>() : nullptr;
-    b.n_pairs = (uint32_t)P; b.max_corr = max_corr; b.pair_id_base = 0; b.seed = seed;
-    if (any_guess && screenGuesses) {
-        // InTraversalPoseTester::test for every chained pose of the wave in ONE launch:
-        // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
-        std::vector<double> Eg(9 * P, 0.0), tau2(P, 0.0);
-        for (size_t i = 0; i < P; ++i) {
-            if (!has[i]) { Eg[9 * i] = 1.0; continue; }
-            const Matrix3d E = pose::getEssentialMatrixFromRelativePose(pairs[i].poseGuesses.back());
-            for (int c = 0; c < 9; ++c) Eg[9 * i + c] = E[c];
-            tau2[i] = (1.5 * thr[i]) * (1.5 * thr[i]);
-        }
-        DevBuf dE(P * 72), dtau(P * 8), dcnt(P * 4);
-        h2d(dE.p, Eg.data(), P * 72);
-        h2d(dtau.p, tau2.data(), P * 8);
+    // the gathered table (P records); this rank's block is written in place at [lo, hi)
+    std::unique_ptr<DevBuf> own_all;
+    pgi_edge* d_all = d_edges_out;
+    if (!d_all) {
+        own_all.reset(new DevBuf(P * sizeof(pgi_edge)));
+        d_all = own_all->as<pgi_edge>();
+    }
+    if (L) {
+        DevBuf dx1(rows * 4), dy1(rows * 4), dx2(rows * 4), dy2(rows * 4), doff((L + 1) * 8), dthr(L * 8), dguess(L * 96), dhas(L),
+            dmasks(rows);
+        h2d(dx1.p, x1.data(), rows * 4); h2d(dy1.p, y1.data(), rows * 4);
+        h2d(dx2.p, x2.data(), rows * 4); h2d(dy2.p, y2.data(), rows * 4);
+        h2d(doff.p, off.data(), (L + 1) * 8); h2d(dthr.p, thr.data(), L * 8);
+        pgi_batch b{};
+        b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
+        b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>();
         b.d_guess_Rt = nullptr; b.d_has_guess = nullptr;
-        Engine::check(pgi_score_pose_batch(engine->get(), &b, dE.as<double>(), dtau.as<double>(), dcnt.as<uint32_t>(), nullptr));
-        Engine::check(pgi_synchronize(engine->get()));
-        std::vector<uint32_t> cnt(P);
-        d2h(cnt.data(), dcnt.p, P * 4);
-        for (size_t i = 0; i < P; ++i)
-            if (has[i] && cnt[i] < 5) has[i] = 0;
-        b.d_guess_Rt = dguess.as<double>(); b.d_has_guess = dhas.as<uint8_t>();
+        b.n_pairs = (uint32_t)L; b.max_corr = max_corr; b.pair_id_base = lo; b.seed = seed;  // ids = positions in `pairs`
+        if (any_guess && screenGuesses) {
+            // InTraversalPoseTester::test for every chained pose of the block in ONE launch:
+            // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
+            std::vector<double> Eg(9 * L, 0.0), tau2(L, 0.0);
+            for (size_t k = 0; k < L; ++k) {
+                if (!has[k]) { Eg[9 * k] = 1.0; continue; }
+                const Matrix3d E = pose::getEssentialMatrixFromRelativePose(pairs[lo + k].poseGuesses.back());
+                for (int c = 0; c < 9; ++c) Eg[9 * k + c] = E[c];
+                tau2[k] = (1.5 * thr[k]) * (1.5 * thr[k]);
+            }
+            DevBuf dE(L * 72), dtau(L * 8), dcnt(L * 4);
+            h2d(dE.p, Eg.data(), L * 72);
+            h2d(dtau.p, tau2.data(), L * 8);
+            Engine::check(pgi_score_pose_batch(engine->get(), &b, dE.as<double>(), dtau.as<double>(), dcnt.as<uint32_t>(), nullptr));
+            Engine::check(pgi_synchronize(engine->get()));
+            std::vector<uint32_t> cnt(L);
+            d2h(cnt.data(), dcnt.p, L * 4);
+            for (size_t k = 0; k < L; ++k)
+                if (has[k] && cnt[k] < 5) has[k] = 0;
+        }
+        if (any_guess) {
+            h2d(dguess.p, guess.data(), L * 96);
+            h2d(dhas.p, has.data(), L);
+            b.d_guess_Rt = dguess.as<double>(); b.d_has_guess = dhas.as<uint8_t>();
+        }
+        Engine::check(pgi_estimate_pose_batch(engine->get(), &b, d_all + lo, dmasks.as<uint8_t>()));
+        Engine::check(pgi_synchronize(engine->get()));  // the batch buffers die with this scope
     }
-    if (any_guess) {
-        h2d(dguess.p, guess.data(), P * 96);
-        h2d(dhas.p, has.data(), P);
-    }
-    Engine::check(pgi_estimate_pose_batch(engine->get(), &b, dedges.as<pgi_edge>(), dmasks.as<uint8_t>()));
+    // the path's one exchange step (no-op copy in a single process)
+    std::vector<uint32_t> counts(world);
+    for (uint32_t r = 0; r < world; ++r) counts[r] = (uint32_t)(blocks[r].second - blocks[r].first);
+    Engine::check(pgi_allgather_edges(engine->get(), d_all + lo, counts.data(), d_all));
     Engine::check(pgi_synchronize(engine->get()));
     std::vector<pgi_edge> edges(P);
-    d2h(edges.data(), dedges.p, P * sizeof(pgi_edge));
-    size_t added = 0;
+    d2h(edges.data(), d_all, P * sizeof(pgi_edge));
+    size_t added = 0, inliers = 0;
     for (size_t i = 0; i < P; ++i) {
+        inliers += edges[i].n_inl;
         if (edges[i].status != PGI_EDGE_OK) continue;  // caller `continue`s (pose_graph_builder.h:641-642)
         SE3d T;
         for (int c = 0; c < 9; ++c) T.R[c] = edges[i].R[c];
@@ -143,13 +170,66 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         poseGraph_.addEdge(pairs[i].src, pairs[i].dst, Pose(T), score);  // :645-654
         ++added;
     }
+    // observability keys of pose_graph_builder.h:636-638 (one timed event per batch, one run per pair)
+    statistics.addTime("[Pose estimation]", std::chrono::duration<double>(Clock::now() - t0).count(), P);
+    statistics.addCount("[Pose estimation] Runs", P, P);
+    statistics.addCount("[Pose estimation] Inlier number", inliers, P);
     if (edges_out) *edges_out = std::move(edges);
     return added;
+}
+
+PoseGraphBuilder::GlobalRotations PoseGraphBuilder::estimateAndAverage(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_,
+                                                                        size_t numViews, uint64_t seed,
+                                                                        std::vector<pgi_edge>* edges_out,
+                                                                        const pgi_rotavg_params* rotavgParams) {
+    GlobalRotations out;
+    out.rotations.assign(numViews, Matrix3d{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
+    const size_t P = pairs.size();
+    if (!P || !numViews) return out;
+    for (const ViewPair& vp : pairs) {
+        poseGraph_.addVertex(vp.src);
+        poseGraph_.addVertex(vp.dst);
+    }
+    DevBuf table(P * sizeof(pgi_edge));
+    estimatePoses(pairs, poseGraph_, seed, edges_out, false, table.as<pgi_edge>());
+    std::vector<uint32_t> src(P), dst(P), rows(P);
+    for (size_t i = 0; i < P; ++i) {
+        src[i] = (uint32_t)pairs[i].src;
+        dst[i] = (uint32_t)pairs[i].dst;
+        rows[i] = (uint32_t)pairs[i].correspondences.rows;
+    }
+    static_assert(sizeof(Matrix3d) == 72, "Matrix3d must be 9 packed doubles");
+    Engine::check(pgi_rotation_average_edges(engine->get(), table.as<pgi_edge>(), src.data(), dst.data(), rows.data(), (uint32_t)P,
+                                             (uint32_t)numViews, rotavgParams, out.rotations[0].data(), &out.iterations,
+                                             &out.edgesUsed));
+    return out;
+}
+
+PoseGraphBuilder::GlobalRotations PoseGraphBuilder::averageRotations(const PoseGraph& poseGraph_, size_t numViews,
+                                                                      const pgi_rotavg_params* rotavgParams) {
+    GlobalRotations out;
+    out.rotations.assign(numViews, Matrix3d{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
+    if (!numViews) return out;
+    std::vector<pgi_rot_edge> re;
+    for (const EdgeId& id : poseGraph_.getEdgeIds()) {
+        const PoseGraphEdge e = poseGraph_.getEdgeById(id);
+        pgi_rot_edge r{};
+        r.src = (uint32_t)id.first;
+        r.dst = (uint32_t)id.second;
+        for (int c = 0; c < 9; ++c) r.R[c] = e.getValue().getRotation()[c];
+        r.weight = e.getScore();
+        re.push_back(r);
+    }
+    out.edgesUsed = (uint32_t)re.size();
+    Engine::check(pgi_rotation_average(engine->get(), re.data(), (uint32_t)re.size(), (uint32_t)numViews, rotavgParams,
+                                       out.rotations[0].data(), &out.iterations));
+    return out;
 }
 
 PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& cand, PoseGraph& poseGraph_, size_t waveSize,
                                                       const SimilarityTable* similarityTable) {
     RunStatistics st;
+    typedef std::chrono::steady_clock Clock;
     // descending similarity, ties by (src,dst): the order the reference pops its heap
     std::stable_sort(cand.begin(), cand.end(), [](const ViewPair& a, const ViewPair& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
@@ -160,33 +240,58 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     VisibilityTable visibilityTable(maxId + 1);  // :366-367
     for (const EdgeId& id : poseGraph_.getEdgeIds()) visibilityTable.addLink(id.first, id.second);
     const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
+    const uint32_t world = worldSize(), rank = worldRank();
     std::vector<ViewPair> wave;
     uint64_t seed = 0;
     auto flush = [&]() {
         if (wave.empty()) return;
         if (pathFinding) {  // findPath (:785-862) on the graph committed by the previous waves
+            const Clock::time_point t0 = Clock::now();
+            // every rank searches only for the pairs it will estimate (same partition as estimatePoses)
+            std::vector<uint64_t> rowsPerPair(wave.size());
+            for (size_t i = 0; i < wave.size(); ++i) rowsPerPair[i] = (uint64_t)wave[i].correspondences.rows;
+            const std::pair<size_t, size_t> mine = dist::shardBounds(rowsPerPair, world)[rank];
             ImageSimilarityHeuristics heuristics(*similarityTable);
             AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
                                                                 kMaximumSearchDepth);
-            for (ViewPair& vp : wave) {
+            struct Tally { uint64_t searched = 0, touched = 0, found = 0; } tally;
+            for (size_t i = 0; i < wave.size(); ++i) {
+                ViewPair& vp = wave[i];
                 vp.poseGuesses.clear();
+                if (i < mine.first || i >= mine.second) continue;
                 if (!visibilityTable.hasLink(vp.src, vp.dst)) continue;  // kAreViewsVisible (:456-457, 568)
                 std::vector<ViewId> path;
                 size_t touched = 0, found = 0;
                 bool exists = false;
                 traversal.getPath(vp.src, vp.dst, path, vp.poseGuesses, touched, found, exists);
-                ++st.pathsSearched;
-                st.touchedNodes += touched;
-                st.pathsFound += found;
+                ++tally.searched;
+                tally.touched += touched;
+                tally.found += found;
             }
+            if (world > 1) {  // the searches' tallies of all ranks (host-side bookkeeping, 24 bytes per rank)
+                const std::vector<Tally> all = hostComm->allgather(tally);
+                tally = Tally();
+                for (const Tally& t : all) { tally.searched += t.searched; tally.touched += t.touched; tally.found += t.found; }
+            }
+            st.pathsSearched += tally.searched;
+            st.touchedNodes += tally.touched;
+            st.pathsFound += tally.found;
+            // :599-602
+            statistics.addTime("[A*]", std::chrono::duration<double>(Clock::now() - t0).count(), tally.searched);
+            statistics.addCount("[A*] Runs", tally.searched, tally.searched);
+            statistics.addCount("[A*] Touched nodes", tally.touched, tally.searched);
+            statistics.addCount("[A*] Paths tested", tally.found, tally.searched);
         }
         std::vector<pgi_edge> edges;
         const size_t added = estimatePoses(wave, poseGraph_, seed++, &edges, /*screenGuesses*/ pathFinding);
+        const Clock::time_point t1 = Clock::now();
         for (size_t i = 0; i < wave.size(); ++i) {
             st.hypotheses += edges[i].iters;
             st.posesFromGuess += edges[i].used_guess;
             if (edges[i].status == PGI_EDGE_OK) visibilityTable.addLink(wave[i].src, wave[i].dst);  // :692
         }
+        statistics.addTime("[Visibility update]", std::chrono::duration<double>(Clock::now() - t1).count(), added);  // :698-699
+        statistics.addCount("[Visibility update] Runs", added, added);
         st.edgesAdded += added;
         st.pairsProcessed += wave.size();
         ++st.waves;
@@ -204,6 +309,28 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     }
     flush();
     return st;
+}
+
+// pose_graph_builder.h:241-291: one camera + one view per listed image, K = [f 0 w/2; 0 f h/2; 0 0 1], metadata
+// "name" / "extension", one pose-graph vertex per image
+void PoseGraphBuilder::initializeReconstruction(const size_t& kImageNumber_,
+                                                const std::vector<std::tuple<std::string, double, double, double>>& imageData_,
+                                                Reconstruction& reconstruction_, PoseGraph& poseGraph_) {
+    for (size_t imageIdx = 0; imageIdx < kImageNumber_ && imageIdx < imageData_.size(); ++imageIdx) {
+        if (!reconstruction_.addCamera(imageIdx)) continue;
+        if (!reconstruction_.addView(imageIdx, imageIdx)) continue;
+        const std::string& kImageName = std::get<0>(imageData_[imageIdx]);
+        const double kFocalLength = std::get<1>(imageData_[imageIdx]), kImageWidth = std::get<2>(imageData_[imageIdx]),
+                     kImageHeight = std::get<3>(imageData_[imageIdx]);
+        ViewMetadata& metadata = reconstruction_.getMutableView(imageIdx).getMutableMetadata();
+        metadata["name"] = kImageName.size() > 4 ? kImageName.substr(0, kImageName.size() - 4) : kImageName;
+        metadata["extension"] = kImageName.size() >= 3 ? kImageName.substr(kImageName.size() - 3) : std::string();
+        PinholeCamera& camera = reconstruction_.getMutableCamera(imageIdx);
+        camera.setWidth(kImageWidth);
+        camera.setHeight(kImageHeight);
+        camera.setIntrinsics(kFocalLength, kFocalLength, kImageWidth / 2.0, kImageHeight / 2.0);
+        poseGraph_.addVertex(imageIdx);
+    }
 }
 
 PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeatures>& views,
@@ -270,7 +397,15 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 ++st.cachedMatchLoads;
             }
         }
-        st.secQuickMatching += since(tick); tick = Clock::now();
+        {   // :505-518
+            const double dt = since(tick);
+            size_t tried = 0, ok = 0;
+            for (size_t i = 0; i < P; ++i) { tried += (kUseEpipolarHashing && visible[i]) ? 1 : 0; ok += quick[i] ? 1 : 0; }
+            st.secQuickMatching += dt;
+            if (tried) statistics.addTime("[Quick matching]", dt, tried);
+            if (ok) statistics.addCount("[Quick matching] Runs", ok, ok);
+        }
+        tick = Clock::now();
         // batch order: descriptor-matched pairs first (the matcher writes rows 0..Pn-1), host-provided matches after them
         std::vector<size_t> order;
         for (size_t i = 0; i < P; ++i) if (!fromHost[i]) order.push_back(i);
@@ -300,7 +435,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 for (uint32_t q = 0; q < hcnt[k]; ++q) m[q] = Tracklets::Match(hsrc[k * (size_t)mm + q], hdst[k * (size_t)mm + q], 0.0);
             }
         }
-        st.secMatching += since(tick); tick = Clock::now();
+        {   // :545-546
+            const double dt = since(tick);
+            st.secMatching += dt;
+            if (Pn) { statistics.addTime("[Matching]", dt, Pn); statistics.addCount("[Matching] Runs", Pn, Pn); }
+        }
+        tick = Clock::now();
         for (size_t k = Pn; k < P; ++k) {  // tracklet matches join the same device layout
             const Matches& m = matches[order[k]];
             hcnt[k] = (uint32_t)m.size();
@@ -336,6 +476,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         std::vector<double> guess(12 * P, 0.0);
         std::vector<uint8_t> has(P, 0);
         bool anyGuess = false;
+        size_t waveSearched = 0, waveTouched = 0, waveFound = 0;
         if (pathFinding) {
             ImageSimilarityHeuristics heuristics(*similarityTable);
             AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
@@ -351,6 +492,9 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 ++st.pathsSearched;
                 st.touchedNodes += touched;
                 st.pathsFound += found;
+                ++waveSearched;
+                waveTouched += touched;
+                waveFound += found;
                 if (poses.empty()) continue;
                 for (int c = 0; c < 9; ++c) guess[12 * k + c] = poses.back().R[c];
                 for (int c = 0; c < 3; ++c) guess[12 * k + 9 + c] = poses.back().t[c];
@@ -358,7 +502,17 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 anyGuess = true;
             }
         }
-        st.secAStar += since(tick); tick = Clock::now();
+        {
+            const double dt = since(tick);
+            st.secAStar += dt;
+            if (waveSearched) {  // :599-602
+                statistics.addTime("[A*]", dt, waveSearched);
+                statistics.addCount("[A*] Runs", waveSearched, waveSearched);
+                statistics.addCount("[A*] Touched nodes", waveTouched, waveSearched);
+                statistics.addCount("[A*] Paths tested", waveFound, waveSearched);
+            }
+        }
+        tick = Clock::now();
         if (anyGuess) {
             std::vector<double> thr(P), Eg(9 * P, 0.0), tau2(P, 0.0);
             Engine::check(pgi_synchronize(ctx));
@@ -395,7 +549,19 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         d2h(off.data(), doff.p, (P + 1) * 8);
         std::vector<uint8_t> masks((size_t)off[P]);
         d2h(masks.data(), dmasks.p, masks.size());
-        st.secPoseEstimation += since(tick); tick = Clock::now();
+        {   // :636-638
+            const double dt = since(tick);
+            st.secPoseEstimation += dt;
+            size_t runs = 0, inl = 0;
+            for (size_t k = 0; k < P; ++k)
+                if (!skipped[k]) { ++runs; inl += edges[k].n_inl; }
+            if (runs) {
+                statistics.addTime("[Pose estimation]", dt, runs);
+                statistics.addCount("[Pose estimation] Runs", runs, runs);
+                statistics.addCount("[Pose estimation] Inlier number", inl, runs);
+            }
+        }
+        tick = Clock::now();
         // (6) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
         std::vector<size_t> guidedOf;
         std::vector<pgi_feature_view> ga, gb;
@@ -422,7 +588,18 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             d2h(gcnt.data(), dc.p, G * 4);
             st.guidedMatchingRuns += G;
         }
-        st.secGuidedMatching += since(tick); tick = Clock::now();
+        {   // :684-686
+            const double dt = since(tick);
+            st.secGuidedMatching += dt;
+            if (!guidedOf.empty()) {
+                size_t extra = 0;
+                for (uint32_t c : gcnt) extra += c;
+                statistics.addTime("[Epipolar Hashing]", dt, guidedOf.size());
+                statistics.addCount("[Epipolar Hashing] Runs", guidedOf.size(), guidedOf.size());
+                statistics.addCount("[Epipolar Hashing] Correspondences added", extra, guidedOf.size());
+            }
+        }
+        tick = Clock::now();
         // (7) commit in wave order: edge (:645-654), visibility (:692), tracklets (:677-681, :702-709)
         std::vector<size_t> slotOf(P);
         for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
@@ -455,7 +632,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 tracks.add(wave[i].src, wave[i].dst, matches[i], mask);
             }
         }
-        st.secTrackUpdate += since(tick);
+        {   // :698-699 (the commit loop holds the visibility update)
+            const double dt = since(tick);
+            st.secTrackUpdate += dt;
+            statistics.addTime("[Visibility update]", dt, P);
+            statistics.addCount("[Visibility update] Runs", P, P);
+        }
         ++st.waves;
     };
 

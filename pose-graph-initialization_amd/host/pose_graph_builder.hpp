@@ -31,8 +31,14 @@
 #include <vector>
 
 #include "../../include/pgi.h"
+#include "utils.hpp"
 
 namespace reconstruction {
+
+class Reconstruction;  // host/reconstruction.hpp
+namespace dist {
+class HostComm;  // host/distributed.hpp
+}
 
 typedef size_t ViewId;  // include/types.h:9-14
 typedef std::pair<ViewId, ViewId> EdgeId;
@@ -346,10 +352,6 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
                       const double kThreshold_, const std::vector<SE3d>& poseGuesses_, SE3d& estimatedPose_,
                       std::vector<uchar>& inlierMask_, size_t& inlierNumber_, uint64_t seed = 0,
                       uint64_t pairId = 0) {
-        pgi_params p;
-        pgi_default_params(&p);
-        p.min_inliers = (uint32_t)kMinimumInlierNumber_;
-        Engine::check(pgi_set_params(engine->get(), &p));
         std::vector<double> g(12 * poseGuesses_.size());
         for (size_t i = 0; i < poseGuesses_.size(); ++i) {
             for (int c = 0; c < 9; ++c) g[12 * i + c] = poseGuesses_[i].R[c];
@@ -360,7 +362,8 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
         uchar dummy = 0;
         const int rc = pgi_estimate_pose(engine->get(), kCorrespondences_.ptr(), (uint32_t)kCorrespondences_.rows,
                                          kThreshold_, g.empty() ? nullptr : g.data(), (uint32_t)poseGuesses_.size(),
-                                         seed, pairId, &e, inlierMask_.empty() ? &dummy : inlierMask_.data());
+                                         (uint32_t)kMinimumInlierNumber_, seed, pairId, &e,
+                                         inlierMask_.empty() ? &dummy : inlierMask_.data());
         Engine::check(rc);
         inlierNumber_ = e.n_inl;
         if (rc != 1) return false;  // :1053-1054, :1069-1070
@@ -374,8 +377,29 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // poseGuess (if any) is first screened like InTraversalPoseTester::test does inside the A* traversal
     // (>= 5 rows with squared Sampson distance < (1.5 thr)^2; pose_graph_builder.h:798-811) -- all
     // screens of the wave in one score launch -- and only accepted guesses reach estimatePose.
+    //
+    // Multi-GPU (setHostComm + dist::attach): the pairs are cut into world contiguous, row-balanced blocks
+    // (dist::shardBounds); this rank uploads and estimates only its block (seeds are keyed by the pair's index in
+    // `pairs`, so a block reproduces the single-process result bit for bit), the 200-byte edge records are
+    // all-gathered (pgi_allgather_edges: RCCL over xGMI, or the host transport when ranks share a device) and every
+    // rank commits the identical full table.  d_edges_out (optional): receives the gathered table, still in HBM
+    // (pairs.size() records; caller-allocated), e.g. to feed pgi_rotation_average_edges without a host round trip.
     size_t estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed = 0,
-                         std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false);
+                         std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false,
+                         pgi_edge* d_edges_out = nullptr);
+
+    // BASELINE config 4: shard -> estimate -> gather -> replicated L1/IRLS rotation averaging; the gathered records
+    // stay in HBM between the exchange and the solve.  R_i are world->camera, one per view id < numViews.
+    struct GlobalRotations {
+        std::vector<Matrix3d> rotations;
+        uint32_t iterations = 0, edgesUsed = 0;
+    };
+    GlobalRotations estimateAndAverage(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, size_t numViews,
+                                       uint64_t seed = 0, std::vector<pgi_edge>* edges_out = nullptr,
+                                       const pgi_rotavg_params* rotavgParams = nullptr);
+    // Rotation averaging over the edges already in a pose graph (weights = edge scores), e.g. after run().
+    GlobalRotations averageRotations(const PoseGraph& poseGraph_, size_t numViews,
+                                     const pgi_rotavg_params* rotavgParams = nullptr);
 
     struct RunStatistics {  // the reference's RunningStatistics keys that concern this path (utils.h:15-73)
         size_t pairsProcessed = 0, edgesAdded = 0, pathsSearched = 0, pathsFound = 0, touchedNodes = 0,
@@ -388,8 +412,21 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // descending similarity (imagesimilarity_graph.h max-heap order), are estimated in batches.  With
     // kUsePathFinding and a similarity table, pairs already connected in the graph (VisibilityTable) get
     // an A* pose guess computed on the graph committed by the previous waves (findPath, :785-862).
+    // Multi-GPU (BASELINE config 5, SURVEY §8e wave protocol): every rank walks the same sorted candidate list and
+    // forms the same wave; a rank runs host A* on the committed snapshot only for the pairs of its share, estimates
+    // them, the records are all-gathered and every rank commits the whole wave in wave order -- graph, visibility
+    // and statistics are identical on all ranks and identical to the single-process run.
     RunStatistics run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096,
                       const class SimilarityTable* similarityTable = nullptr);
+
+    // The outer API of the reference: void run(Reconstruction&, PoseGraph&) (pose_graph_builder.h:69-71, 173-239) on
+    // the workspace named by the constructor's paths (list_with_focals.txt, similarity matrix, image_data.h5,
+    // keypoints.h5, correspondences.h5).  Defined in host/hdf5_cache.hpp (needs the HDF5 C library).
+    void run(Reconstruction& reconstruction_, PoseGraph& poseGraph_);
+    // pose_graph_builder.h:241-291
+    void initializeReconstruction(const size_t& kImageNumber_,
+                                  const std::vector<std::tuple<std::string, double, double, double>>& imageData_,
+                                  Reconstruction& reconstruction_, PoseGraph& poseGraph_);
 
     // ---- the loop body of processImages on in-memory features (pose_graph_builder.h:391-709 minus file I/O) ----
     // What loadFeatures returns for one image (:463-482) plus its pinhole camera K = [f 0 w/2; 0 f h/2; 0 0 1] (:286).
@@ -425,8 +462,17 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
                                          const MatchLookup* cachedMatches = nullptr);
 
     Engine& getEngine() { return *engine; }
+    // the reference's `RunningStatistics statistics` (pose_graph_builder.h:385): filled by run / processFeatures with
+    // the reference's key names, printed by run(Reconstruction&, PoseGraph&) like :712
+    RunningStatistics& getStatistics() { return statistics; }
+    // one process per GPU: the host-side channel of this rank (also install the engine's transport: dist::attach)
+    void setHostComm(dist::HostComm* comm) { hostComm = comm; }
+    uint32_t worldSize() const;
+    uint32_t worldRank() const;
 
    protected:
+    RunningStatistics statistics;
+    dist::HostComm* hostComm = nullptr;
     const size_t kCoreNumber, kMinimumInlierNumber, kMinimumPointNumber, kMaximumPointNumberForEpipolarHashing,
         kMaximumSearchDepth, kMaximumPathNumber, kMaximumTrackletNumber;
     const std::string kImagePath, kWorkspacePath, kSimilarityGraphPath, kFocalLengthPath;

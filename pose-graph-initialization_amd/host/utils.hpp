@@ -1,5 +1,5 @@
 // utils.hpp -- host utilities around the path (no GPU, no OpenCV): mirrors include/utils.h
-//   RunningStatistics    utils.h:15-73  (mutex-guarded name -> (sum, count); the observability keys of
+//   RunningStatistics    utils.h:15-73  (mutex-guarded time and count tables; the observability keys of
 //                        processImages: "[A*]", "[Pose estimation]", ... SURVEY.md §5)
 //   load1DSfMImageList   utils.h:122-182 ("images/<name> 0 <focal>" lines of list_with_focals.txt)
 #pragma once
@@ -15,39 +15,72 @@
 
 namespace reconstruction {
 
+// Two tables like the reference's: elapsed seconds per stage and event counts, each entry = (sum, number of
+// additions).  The key strings used by run / processFeatures are the reference's own (pose_graph_builder.h:505-518,
+// 545-546, 599-602, 636-638, 684-686, 698-699): "[Quick matching]", "[Matching]", "[A*]", "[Pose estimation]",
+// "[Epipolar Hashing]", "[Visibility update]" and their " Runs" / " Touched nodes" / " Paths tested" /
+// " Inlier number" / " Correspondences added" counters.
 class RunningStatistics {
    public:
-    void addValue(const std::string& name, double value) {
-        std::lock_guard<std::mutex> l(mu);
-        auto& e = values[name];
-        e.first += value;
-        e.second += 1;
+    typedef std::map<std::string, std::pair<double, size_t>> TimeTable;
+    typedef std::map<std::string, std::pair<size_t, size_t>> CountTable;
+    void addTime(const std::string& kPropertyName_, double value_, size_t events_ = 1) {
+        std::lock_guard<std::mutex> l(guard);
+        auto& e = timeValues[kPropertyName_];
+        e.first += value_;
+        e.second += events_;
     }
-    double getSum(const std::string& name) const {
-        std::lock_guard<std::mutex> l(mu);
-        auto it = values.find(name);
-        return it == values.end() ? 0.0 : it->second.first;
+    void addCount(const std::string& kPropertyName_, size_t value_, size_t events_ = 1) {
+        std::lock_guard<std::mutex> l(guard);
+        auto& e = countValues[kPropertyName_];
+        e.first += value_;
+        e.second += events_;
     }
-    size_t getCount(const std::string& name) const {
-        std::lock_guard<std::mutex> l(mu);
-        auto it = values.find(name);
-        return it == values.end() ? 0 : it->second.second;
+    TimeTable getTimes() const {
+        std::lock_guard<std::mutex> l(guard);
+        return timeValues;
     }
-    double getAverage(const std::string& name) const {
-        const size_t c = getCount(name);
-        return c ? getSum(name) / (double)c : 0.0;
+    CountTable getCounts() const {
+        std::lock_guard<std::mutex> l(guard);
+        return countValues;
     }
-    void print() const {  // utils.h:59-72
-        std::lock_guard<std::mutex> l(mu);
-        for (auto& kv : values)
-            std::printf("%s\n\tAverage = %f\n\tTotal = %f\n\tCount = %zu\n", kv.first.c_str(),
-                        kv.second.second ? kv.second.first / (double)kv.second.second : 0.0, kv.second.first,
-                        kv.second.second);
+    size_t getCount(const std::string& kPropertyName_) const {
+        std::lock_guard<std::mutex> l(guard);
+        auto it = countValues.find(kPropertyName_);
+        return it == countValues.end() ? 0 : it->second.first;
+    }
+    double getTime(const std::string& kPropertyName_) const {
+        std::lock_guard<std::mutex> l(guard);
+        auto it = timeValues.find(kPropertyName_);
+        return it == timeValues.end() ? 0.0 : it->second.first;
+    }
+    std::pair<double, bool> getAverageTime(const std::string& kPropertyName_) const {
+        std::lock_guard<std::mutex> l(guard);
+        auto it = timeValues.find(kPropertyName_);
+        if (it == timeValues.end() || it->second.second == 0) return {0.0, false};
+        return {it->second.first / (double)it->second.second, true};
+    }
+    void clear() {
+        std::lock_guard<std::mutex> l(guard);
+        timeValues.clear();
+        countValues.clear();
+    }
+    void print() const {  // layout of utils.h:59-72
+        const TimeTable t = getTimes();
+        const CountTable c = getCounts();
+        std::printf("Statistics:\n");
+        for (auto& kv : t)
+            std::printf("\tAverage '%s' time = %f seconds\n", kv.first.c_str(), kv.second.second ? kv.second.first / (double)kv.second.second : 0.0);
+        std::printf("\t------------------\n");
+        for (auto& kv : t) std::printf("\tTotal '%s' time = %f seconds\n", kv.first.c_str(), kv.second.first);
+        std::printf("\t------------------\n");
+        for (auto& kv : c) std::printf("\tNumber of '%s' = %d\n", kv.first.c_str(), (int)kv.second.first);
     }
 
    protected:
-    mutable std::mutex mu;
-    std::map<std::string, std::pair<double, size_t>> values;
+    mutable std::mutex guard;
+    TimeTable timeValues;
+    CountTable countValues;
 };
 
 // utils.h:122-182.  results_: (image name without the "images/" prefix, focal length, width, height).

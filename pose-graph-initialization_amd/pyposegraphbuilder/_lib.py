@@ -51,7 +51,12 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_set_stream", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch", "pgi_estimate_pose_batch_host",
            "pgi_estimate_pose", "pgi_score_pose_batch", "pgi_score_pose_f64", "pgi_decompose_batch",
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
-           "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch"]
+           "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch",
+           "pgi_get_params", "pgi_rotation_average_edges", "pgi_comm_unique_id", "pgi_comm_init_rccl", "pgi_comm_init_host",
+           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv"]
+COMM_ID_BYTES = 128
+# pgi_allgatherv_fn: int (*)(void* user, const void* send, uint64 send_bytes, void* recv, const uint64* recv_bytes, uint32 world)
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
 
 _lib = None
 
@@ -107,8 +112,18 @@ def load():
                                            C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch_host.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
-    lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32,
+    lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]
+    lib.pgi_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.pgi_rotation_average_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.POINTER(RotAvgParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pgi_comm_unique_id.argtypes = [C.c_void_p]
+    lib.pgi_comm_init_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.pgi_comm_init_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALLGATHERV_FN, C.c_void_p]
+    lib.pgi_comm_destroy.argtypes = [C.c_void_p]
+    lib.pgi_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.pgi_allgather_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pgi_allgatherv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_score_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]
     lib.pgi_score_pose_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,

@@ -180,6 +180,47 @@ class Engine:
                                                R.ctypes.data_as(C.c_void_p), C.byref(iters)))
         return R, iters.value
 
+    def rotation_average_edges(self, edges, src, dst, rows, n_views, **kw):
+        """The same solve fed from the device-resident edge table (uint8 [P, 200], e.g. the output of allgather_edges):
+        only status / n_inl and the spanning forest's rotations travel to the host.  weight = n_inl / rows.
+        -> (R[n_views,3,3], iters, edges_used)"""
+        P = int(edges.shape[0])
+        src = np.ascontiguousarray(src, np.uint32)
+        dst = np.ascontiguousarray(dst, np.uint32)
+        rows = None if rows is None else np.ascontiguousarray(rows, np.uint32)
+        prm = L.RotAvgParams()
+        self._lib.pgi_default_rotavg_params(C.byref(prm))
+        for k, v in kw.items():
+            if not hasattr(prm, k):
+                raise TypeError("unknown parameter %r" % k)
+            setattr(prm, k, v)
+        R = np.zeros((n_views, 3, 3))
+        iters, used = C.c_uint32(0), C.c_uint32(0)
+        self._bind_stream()
+        L.check(self._lib.pgi_rotation_average_edges(
+            self._ctx, _ptr(edges), src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p),
+            None if rows is None else rows.ctypes.data_as(C.c_void_p), P, n_views, C.byref(prm), R.ctypes.data_as(C.c_void_p),
+            C.byref(iters), C.byref(used)))
+        return R, iters.value, used.value
+
+    # ---- multi-GPU exchange (include/pgi.h: pgi_comm_*, pgi_allgather_edges) ----------------------------------------
+    def comm_info(self):
+        w, r, k = C.c_uint32(1), C.c_uint32(0), C.c_uint32(0)
+        L.check(self._lib.pgi_comm_info(self._ctx, C.byref(w), C.byref(r), C.byref(k)))
+        return w.value, r.value, ("none", "rccl", "host")[k.value]
+
+    def allgather_edges(self, local_edges, counts, out=None):
+        """local_edges: uint8 [P_r, 200] on this engine's device; counts[r] = records of rank r (counts[rank] == P_r).
+        Returns the [sum(counts), 200] table in rank order (asynchronous on the current stream with RCCL)."""
+        counts = np.ascontiguousarray(counts, np.uint32)
+        total = int(counts.sum())
+        if out is None:
+            out = torch.empty((total, L.EDGE_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        self._bind_stream()
+        L.check(self._lib.pgi_allgather_edges(self._ctx, _ptr(local_edges) if local_edges.numel() else None,
+                                              counts.ctypes.data_as(C.c_void_p), _ptr(out)))
+        return out
+
     # ---- descriptor matching (feature_utils.h:135-202) ------------------------------------------
     def prepare_descriptors(self, desc, screen=True):
         """n x 128 float32 (numpy or device tensor) -> prepared image (transposed copy + norms in HBM; with screen=True
@@ -289,8 +330,10 @@ class Engine:
         return [(s_h[p, :c[p]].astype(np.uint32), d_h[p, :c[p]].astype(np.uint32), r_h[p, :c[p]]) for p in range(P)]
 
     # ---- single-pair drop-in (host pointers) --------------------------------------------------
-    def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0):
-        """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078)."""
+    def estimate_pose(self, corr_aos, thr, guesses=None, seed=0, pair_id=0, min_inliers=0):
+        """estimatePose(corr N x 4 f64, thr, guesses) -> (ok, Edge, mask) (pose_graph_builder.h:940-1078).
+        min_inliers: the seam's kMinimumInlierNumber_ for this call (0 = the engine's parameter).  Re-entrant:
+        concurrent callers get private slots (stream + pinned staging) and overlap on the GPU."""
         c = np.ascontiguousarray(corr_aos, np.float64).reshape(-1, 4)
         g = None if guesses is None else np.ascontiguousarray(guesses, np.float64).reshape(-1, 12)
         e = L.Edge()
@@ -298,6 +341,6 @@ class Engine:
         self._bind_stream()
         rc = L.check(self._lib.pgi_estimate_pose(
             self._ctx, c.ctypes.data_as(C.c_void_p), len(c), float(thr),
-            None if g is None else g.ctypes.data_as(C.c_void_p), 0 if g is None else len(g),
+            None if g is None else g.ctypes.data_as(C.c_void_p), 0 if g is None else len(g), int(min_inliers),
             int(seed), int(pair_id), C.byref(e), mask.ctypes.data_as(C.c_void_p)))
         return bool(rc), e, mask[:len(c)]

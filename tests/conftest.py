@@ -31,7 +31,7 @@ def _native_artifacts():
     if (_stale(os.path.join(PKG, "libpgi.so"), csrc + hdr) or _stale(os.path.join(PKG, "libpgi_host.so"), host + hdr)
             or _stale(os.path.join(PKG, "test_host_api"), host + hdr)
             or any(_stale(os.path.join(PKG, exe), host + [os.path.join(ROOT, "tests", "cpp", exe + ".cpp")])
-                   for exe in ("test_astar", "test_scheduler", "test_pipeline"))):
+                   for exe in ("test_astar", "test_scheduler", "test_pipeline", "test_distributed"))):
         subprocess.check_call(["make", "-C", PKG, "-s"])
     if _stale(os.path.join(ROOT, "oracle", "libpgi_oracle.so"),
               [os.path.join(ROOT, "oracle", f) for f in ("pgi_oracle.c", "pgi_oracle.h")]):

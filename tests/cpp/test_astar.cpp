@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <fstream>
 
+#include "distributed.hpp"
 #include "graph_traversal.hpp"
 #include "tracklets.hpp"
 #include "utils.hpp"
@@ -29,10 +30,12 @@ static int formats(char** argv) {
     std::fprintf(out, "total %zu\n", total);
     for (auto& t : imgs) std::fprintf(out, "%s %.4f\n", std::get<0>(t).c_str(), std::get<1>(t));
     RunningStatistics st;
-    st.addValue("[Pose estimation]", 2.0);
-    st.addValue("[Pose estimation]", 4.0);
-    std::fprintf(out, "stat %.1f %zu %.1f\n", st.getSum("[Pose estimation]"), st.getCount("[Pose estimation]"),
-                 st.getAverage("[Pose estimation]"));
+    st.addTime("[Pose estimation]", 2.0);
+    st.addTime("[Pose estimation]", 4.0);
+    st.addCount("[Pose estimation] Runs", 1);
+    st.addCount("[Pose estimation] Runs", 1);
+    std::fprintf(out, "stat %.1f %zu %.1f\n", st.getTime("[Pose estimation]"), st.getCount("[Pose estimation] Runs"),
+                 st.getAverageTime("[Pose estimation]").first);
     std::fclose(out);
     return 0;
 }
@@ -72,9 +75,56 @@ static int tracklets(char** argv) {
     return 0;
 }
 
+// mode "hostcomm": <out prefix>; RANK / WORLD_SIZE / MASTER_* from the environment.  Exercises the TCP star that
+// bootstraps the multi-GPU path (host/distributed.hpp): broadcast, uneven all-gather-v, fixed-size all-gather, barrier.
+static int hostcomm(char** argv) {
+    const dist::LaunchEnv env = dist::LaunchEnv::fromEnvironment();
+    dist::HostComm comm(env);
+    uint8_t id[128];
+    for (int i = 0; i < 128; ++i) id[i] = env.rank == 0 ? (uint8_t)(i * 7 + 3) : 0;
+    comm.broadcast(id, sizeof id);
+    std::vector<uint64_t> bytes(env.world);
+    for (uint32_t r = 0; r < env.world; ++r) bytes[r] = r == 1 ? 0 : 1000 * (r + 1) + 13;  // one empty block
+    std::vector<uint8_t> mine(bytes[env.rank]);
+    for (size_t i = 0; i < mine.size(); ++i) mine[i] = (uint8_t)(env.rank * 31 + i);
+    uint64_t total = 0;
+    for (uint64_t b : bytes) total += b;
+    std::vector<uint8_t> all(total);
+    comm.allgatherv(mine.data(), mine.size(), all.data(), bytes.data());
+    struct Rec { uint32_t rank; uint32_t sq; };
+    const std::vector<Rec> recs = comm.allgather(Rec{env.rank, env.rank * env.rank});
+    comm.barrier();
+    std::ofstream out(std::string(argv[2]) + "." + std::to_string(env.rank), std::ios::binary);
+    out.write((const char*)id, sizeof id);
+    out.write((const char*)all.data(), (std::streamsize)all.size());
+    out.write((const char*)recs.data(), (std::streamsize)(recs.size() * sizeof(Rec)));
+    return 0;
+}
+
+// mode "shards": <sizes.txt> <world> <out.txt>: dist::shardBounds (must equal pyposegraphbuilder.distributed.shard_bounds)
+static int shards(char** argv) {
+    std::ifstream in(argv[2]);
+    std::vector<uint64_t> sizes;
+    uint64_t v;
+    while (in >> v) sizes.push_back(v);
+    std::FILE* out = std::fopen(argv[4], "w");
+    for (auto& b : dist::shardBounds(sizes, (uint32_t)std::atoi(argv[3]))) std::fprintf(out, "%zu %zu\n", b.first, b.second);
+    std::fclose(out);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 7 && std::string(argv[1]) == "formats") return formats(argv);
     if (argc >= 4 && std::string(argv[1]) == "tracklets") return tracklets(argv);
+    if (argc >= 3 && std::string(argv[1]) == "hostcomm") {
+        try {
+            return hostcomm(argv);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "hostcomm: %s\n", e.what());
+            return 1;
+        }
+    }
+    if (argc >= 5 && std::string(argv[1]) == "shards") return shards(argv);
     if (argc < 3) return 2;
     std::ifstream in(argv[1], std::ios::binary);
     uint32_t V, E, Q;

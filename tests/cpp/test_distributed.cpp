@@ -1,0 +1,88 @@
+// Multi-rank pose-graph path (BASELINE configs 4 and 5), one process per rank.
+//   test_distributed <scene.bin> <out prefix> shard   config 4: pairs sharded -> estimate -> all-gather -> replicated
+//                                                      rotation averaging (PoseGraphBuilder::estimateAndAverage)
+//   test_distributed <scene.bin> <out prefix> waves   config 5: A*-scheduled waves, every wave sharded over the ranks
+//                                                      (PoseGraphBuilder::run), then rotation averaging of the graph
+// RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT come from the environment (torch.distributed.run style).
+// Each rank writes <out prefix>.<rank>; tests/test_distributed_gpu.py demands that every rank's file equals the
+// single-process file byte for byte.  Scene format: tests/test_distributed_gpu.py (write_scene).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "distributed.hpp"
+#include "graph_traversal.hpp"
+
+using namespace reconstruction;
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    const std::string mode = argv[3];
+    try {
+        const dist::LaunchEnv env = dist::LaunchEnv::fromEnvironment();
+        dist::HostComm comm(env);
+        dist::selectDevice(env);
+        std::ifstream in(argv[1], std::ios::binary);
+        uint32_t V, P, wave, simKind;  // simKind 0: none, 1: dense V x V doubles, 2: only the candidate pairs' values (others 0)
+        in.read((char*)&V, 4); in.read((char*)&P, 4); in.read((char*)&wave, 4); in.read((char*)&simKind, 4);
+        SimilarityTable sim(simKind ? V : 1, 0.0, false);
+        if (simKind == 1) {
+            std::vector<double> row(V);
+            for (uint32_t i = 0; i < V; ++i) {
+                in.read((char*)row.data(), (size_t)V * 8);
+                for (uint32_t j = i + 1; j < V; ++j) sim.setSimilarity(i, j, row[j]);
+            }
+        } else if (simKind == 2) {
+            for (uint32_t i = 0; i < V; ++i)
+                for (uint32_t j = i + 1; j < V; ++j) sim.setSimilarity(i, j, 0.0);
+        }
+        std::vector<PoseGraphBuilder::ViewPair> pairs(P);
+        for (uint32_t i = 0; i < P; ++i) {
+            uint32_t s, d, n;
+            double thr, simv;
+            in.read((char*)&s, 4); in.read((char*)&d, 4); in.read((char*)&n, 4); in.read((char*)&thr, 8); in.read((char*)&simv, 8);
+            pairs[i].src = s; pairs[i].dst = d; pairs[i].similarity = simv; pairs[i].normalizedThreshold = thr;
+            pairs[i].correspondences = CorrespondenceMatrix((int)n);
+            in.read((char*)pairs[i].correspondences.ptr(), (size_t)n * 32);
+            if (simKind == 2) sim.setSimilarity(s, d, simv);
+        }
+        if (!in) return 3;
+        PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", mode == "waves", true, true);
+        const dist::Transport tr = dist::attach(builder.getEngine(), comm);
+        builder.setHostComm(&comm);
+        std::ofstream out(std::string(argv[2]) + "." + std::to_string(env.rank), std::ios::binary);
+        PoseGraph graph;
+        PoseGraphBuilder::GlobalRotations rot;
+        if (mode == "shard") {
+            std::vector<pgi_edge> edges;
+            rot = builder.estimateAndAverage(pairs, graph, V, /*seed*/ 7, &edges);
+            const uint64_t hdr[4] = {P, graph.numEdges(), rot.iterations, rot.edgesUsed};
+            out.write((const char*)hdr, sizeof hdr);
+            out.write((const char*)edges.data(), (std::streamsize)(edges.size() * sizeof(pgi_edge)));
+        } else {
+            const auto st = builder.run(pairs, graph, wave, &sim);
+            rot = builder.averageRotations(graph, V);
+            const uint64_t hdr[12] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
+                                      st.posesFromGuess, st.hypotheses, st.waves, graph.numEdges(), rot.iterations, rot.edgesUsed,
+                                      builder.getStatistics().getCount("[A*] Touched nodes")};
+            out.write((const char*)hdr, sizeof hdr);
+            for (auto& id : graph.getEdgeIds()) {
+                const PoseGraphEdge e = graph.getEdgeById(id);
+                const uint32_t s = (uint32_t)id.first, d = (uint32_t)id.second;
+                const double sc = e.getScore();
+                out.write((const char*)&s, 4); out.write((const char*)&d, 4); out.write((const char*)&sc, 8);
+                out.write((const char*)e.getValue().getRotation().data(), 72);
+                out.write((const char*)e.getValue().getTranslation().data(), 24);
+            }
+        }
+        out.write((const char*)rot.rotations.data(), (std::streamsize)(rot.rotations.size() * sizeof(Matrix3d)));
+        comm.barrier();
+        std::printf("rank %u/%u transport %s mode %s edges %zu rotavg iters %u\n", env.rank, env.world,
+                    env.world == 1 ? "none" : tr == dist::Transport::Rccl ? "rccl" : "host", mode.c_str(), graph.numEdges(),
+                    rot.iterations);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "test_distributed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -6,7 +6,7 @@ import pytest
 
 from pyposegraphbuilder import _lib as L
 
-PGI_ERR_INVALID, PGI_ERR_TOO_LARGE = -1, -4
+PGI_ERR_INVALID, PGI_ERR_TOO_LARGE, PGI_ERR_COMM = -1, -4, -5
 
 
 def test_null_context_is_rejected_everywhere():
@@ -16,13 +16,18 @@ def test_null_context_is_rejected_everywhere():
     calls = [
         lambda: lib.pgi_set_stream(z, z), lambda: lib.pgi_set_params(z, None), lambda: lib.pgi_synchronize(z),
         lambda: lib.pgi_estimate_pose_batch(z, None, z, z),
-        lambda: lib.pgi_estimate_pose(z, z, 0, 0.0, z, 0, 0, 0, None, z),
+        lambda: lib.pgi_estimate_pose(z, z, 0, 0.0, z, 0, 0, 0, 0, None, z),
         lambda: lib.pgi_estimate_pose_batch_host(z, z, z, z, z, z, z, z, z, 1, 0, 0, z, z),
         lambda: lib.pgi_desc_prepare_screen(z, z, 0, z, z),
         lambda: lib.pgi_desc_prepare(z, z, 0, z, z),
         lambda: lib.pgi_match_descriptors_batch(z, None, None, 1, 1, z, z, z, z),
         lambda: lib.pgi_build_correspondences(z, None, None, 1, 1, z, z, z, 0, 1.0, 0, z, z, z, z, z, z),
         lambda: lib.pgi_guided_match_batch(z, None, None, 1, z, 0, 1, z, z, z, z),
+        lambda: lib.pgi_get_params(z, None), lambda: lib.pgi_comm_destroy(z), lambda: lib.pgi_comm_info(z, None, None, None),
+        lambda: lib.pgi_comm_init_rccl(z, 2, 0, z), lambda: lib.pgi_comm_init_host(z, 2, 0, L.ALLGATHERV_FN(0), z),
+        lambda: lib.pgi_allgather_edges(z, z, z, z), lambda: lib.pgi_allgatherv(z, z, z, z),
+        lambda: lib.pgi_rotation_average_edges(z, z, z, z, z, 0, 1, None, z, z, z),
+        lambda: lib.pgi_comm_unique_id(z),
     ]
     for call in calls:
         assert call() < 0
@@ -65,8 +70,12 @@ def test_bad_arguments_on_a_live_context(eng):
     corr = np.zeros((8, 4))
     e = L.Edge()
     m = np.zeros(8, np.uint8)
-    assert lib.pgi_estimate_pose(ctx, corr.ctypes.data_as(C.c_void_p), 8, 1e-3, None, 1, 0, 0, C.byref(e),
+    assert lib.pgi_estimate_pose(ctx, corr.ctypes.data_as(C.c_void_p), 8, 1e-3, None, 1, 0, 0, 0, C.byref(e),
                                  m.ctypes.data_as(C.c_void_p)) == PGI_ERR_INVALID
+    # communicator misuse: rank outside the world; no callback
+    assert lib.pgi_comm_init_host(ctx, 2, 2, L.ALLGATHERV_FN(lambda *a: 0), None) == PGI_ERR_INVALID
+    w, r, k = C.c_uint32(9), C.c_uint32(9), C.c_uint32(9)
+    assert lib.pgi_comm_info(ctx, C.byref(w), C.byref(r), C.byref(k)) == 0 and (w.value, r.value, k.value) == (1, 0, 0)
     # the context still works afterwards
     from pyposegraphbuilder import synthetic as S
     p = S.make_pair(1, 300)
@@ -101,3 +110,84 @@ def test_contexts_do_not_leak(eng):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+@pytest.mark.gpu
+def test_single_pair_seam_is_reentrant_with_per_call_min_inliers(eng):
+    """The reference calls estimatePose from kCoreNumber OpenMP threads (pose_graph_builder.h:391-392), each with its own
+    kMinimumInlierNumber_ argument (:155): 24 concurrent callers with two different minimum-inlier values must each get
+    the single-threaded answer, and a per-call value must not leak into the context's parameters."""
+    import threading
+    from pyposegraphbuilder import synthetic as S
+    pairs = [S.make_pair(100 + i, 200 + 37 * i, inlier_ratio=0.5) for i in range(24)]
+    corr = [np.stack([p["x1"], p["y1"], p["x2"], p["y2"]], 1).astype(np.float64) for p in pairs]
+    # a minimum nobody reaches for odd callers: they must report failure while even callers succeed
+    mins = [0 if i % 2 == 0 else 100000 for i in range(24)]
+    ref = [eng.estimate_pose(corr[i], 7.5e-4, seed=5, pair_id=i, min_inliers=mins[i]) for i in range(24)]
+    assert all(ref[i][0] == (i % 2 == 0) for i in range(24))
+    out = [None] * 24
+
+    def work(i):
+        for _ in range(3):
+            out[i] = eng.estimate_pose(corr[i], 7.5e-4, seed=5, pair_id=i, min_inliers=mins[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(24):
+        assert out[i][0] == ref[i][0] and np.array_equal(out[i][2], ref[i][2])
+        assert bytes(out[i][1]) == bytes(ref[i][1])
+    p = L.Params()
+    assert eng._lib.pgi_get_params(eng._ctx, C.byref(p)) == 0 and p.min_inliers == 20
+
+
+@pytest.mark.gpu
+def test_stream_switch_orders_context_scratch(eng):
+    """pgi_set_stream must order the new stream after the old one: calls that share context-owned scratch, issued under
+    different torch streams without any host synchronisation, give the same result as the serial sequence."""
+    import torch
+    from pyposegraphbuilder import synthetic as S
+    rng = np.random.default_rng(11)
+    A, B, _ = S.make_descriptors(rng, 3000, 3100)
+    A2, B2, _ = S.make_descriptors(rng, 2900, 3050)
+    im = [eng.prepare_descriptors(x) for x in (A, B, A2, B2)]
+    torch.cuda.synchronize()
+    ref1 = [t.clone() for t in eng.match_descriptors_batch(im, [(0, 1)] * 6, raw=True)]
+    ref2 = [t.clone() for t in eng.match_descriptors_batch(im, [(2, 3)] * 6, raw=True)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            g1 = eng.match_descriptors_batch(im, [(0, 1)] * 6, raw=True)
+        with torch.cuda.stream(s2):   # reuses the matching workspace while s1's kernels may still be running
+            g2 = eng.match_descriptors_batch(im, [(2, 3)] * 6, raw=True)
+        torch.cuda.synchronize()
+        n1, n2 = int(ref1[3][0]), int(ref2[3][0])
+        assert torch.equal(g1[3], ref1[3]) and torch.equal(g2[3], ref2[3])
+        assert torch.equal(g1[0][:, :n1], ref1[0][:, :n1]) and torch.equal(g2[0][:, :n2], ref2[0][:, :n2])
+        assert torch.equal(g1[2][:, :n1], ref1[2][:, :n1]) and torch.equal(g2[2][:, :n2], ref2[2][:, :n2])
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_of_one_rank(eng):
+    """The RCCL transport end to end on the one GPU there is: librccl is opened at run time, a unique id is created,
+    a one-rank communicator is initialised and pgi_allgather_edges runs ncclAllGather on the engine's stream."""
+    import torch
+    lib, ctx = eng._lib, eng._ctx
+    ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+    L.check(lib.pgi_comm_unique_id(ident))
+    assert any(ident)
+    L.check(lib.pgi_comm_init_rccl(ctx, 1, 0, ident))
+    try:
+        assert eng.comm_info() == (1, 0, "rccl")
+        rec = np.zeros(37, L.EDGE_DTYPE)
+        rec["n_inl"] = np.arange(37)
+        rec["R"] = np.arange(37)[:, None] * 0.5 + np.arange(9)[None, :]
+        local = torch.from_numpy(rec.view(np.uint8).reshape(37, 200).copy()).to(eng.device)
+        out = eng.allgather_edges(local, [37])
+        torch.cuda.synchronize()
+        assert torch.equal(out, local)
+    finally:
+        L.check(lib.pgi_comm_destroy(ctx))
+    assert eng.comm_info() == (1, 0, "none")

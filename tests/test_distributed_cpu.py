@@ -63,3 +63,54 @@ def test_allgather_edges_gloo_world2():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]  # every rank holds the identical global edge table
+
+
+# ---- the C++ side of the multi-rank path (host/distributed.hpp): no torch, no GPU ------------------------------
+import subprocess  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASTAR_EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_astar")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_cpp_shard_bounds_equal_python(tmp_path):
+    rng = np.random.default_rng(3)
+    for case, sizes in enumerate([rng.integers(50, 4000, 777), [0, 0, 5, 0], [10, 10], [7], rng.integers(1, 3, 40)]):
+        f = tmp_path / ("sizes%d.txt" % case)
+        f.write_text(" ".join(str(int(x)) for x in sizes))
+        for world in (1, 2, 3, 8):
+            out = tmp_path / "b.txt"
+            subprocess.run([ASTAR_EXE, "shards", str(f), str(world), str(out)], check=True, timeout=60)
+            got = [tuple(int(v) for v in line.split()) for line in open(out)]
+            assert got == [(int(a), int(b)) for a, b in D.shard_bounds(sizes, world)], (case, world)
+
+
+def test_cpp_hostcomm_world3(tmp_path):
+    """The TCP star that ships the RCCL unique id and carries the host-side exchanges: broadcast, uneven all-gather
+    (one empty block), fixed-size all-gather, barrier -- three processes, identical results on every rank."""
+    world, port = 3, _free_port()
+    prefix = str(tmp_path / "hc")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([ASTAR_EXE, "hostcomm", prefix], env=env, stderr=subprocess.PIPE))
+    for p in procs:
+        assert p.wait(timeout=120) == 0, p.stderr.read()
+    blobs = [open("%s.%d" % (prefix, r), "rb").read() for r in range(world)]
+    assert blobs[0] == blobs[1] == blobs[2]
+    b = np.frombuffer(blobs[0], np.uint8)
+    assert np.array_equal(b[:128], (np.arange(128) * 7 + 3).astype(np.uint8))
+    sizes = [1013, 0, 3013]
+    pos = 128
+    for r, n in enumerate(sizes):
+        assert np.array_equal(b[pos:pos + n], (r * 31 + np.arange(n)).astype(np.uint8))
+        pos += n
+    recs = np.frombuffer(blobs[0][pos:], np.uint32).reshape(world, 2)
+    assert np.array_equal(recs, [[0, 0], [1, 1], [2, 4]])
