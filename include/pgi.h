@@ -285,23 +285,30 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
  * reference looks for additional matches consistent with the pose: for every source keypoint,
  * the destination keypoints within 0.75 px symmetric epipolar distance (:340-354) compete by
  * descriptor SSD, and the winner is kept if the count-adapted ratio test passes (:375-399).
- * The reference pre-selects candidates with 45 angular bins; this implementation visits all of
- * them (its own commented alternative, :327).  If more than max_n matches survive, the max_n with
- * the smallest adapted ratio are returned in that order (pose_graph_builder.h:759-772); otherwise
- * all, in source order.  max_n = 0 keeps everything. */
+ * n_bins > 0 (the reference instantiates 45, pose_graph_builder.h:738) reproduces its epipolar
+ * hashing: destination keypoints are binned by the angle of their epipolar line's normal in the
+ * source image, and a source keypoint only competes inside its own bin (matcher.h:218-331).
+ * n_bins = 0 visits every destination keypoint (the loop the reference keeps commented at :327) --
+ * a superset of the binned candidates, so ~1 % of the matches differ from the reference's.
+ * If more than max_n matches survive, the max_n with the smallest adapted ratio are returned in
+ * that order (pose_graph_builder.h:759-772); otherwise all, in source order.  max_n = 0 keeps
+ * everything. */
 typedef struct {
     const float* d_xy;   /* n x 2 pixel coordinates        */
     const float* d_desc; /* n x 128 row-major descriptors  */
     uint32_t n;
     uint32_t reserved;
     double fx, fy, cx, cy;
+    double width, height; /* image size (PinholeCamera::getWidth/getHeight -> cv::Size, pose_graph_builder.h:741-742);
+                             read only when n_bins > 0 */
 } pgi_feature_view;
 /* h_pose_Rt: n_pairs x 12 doubles (R_dst_src row-major, t_dst_src).  Outputs per pair at stride
  * out_stride (>= max_n, or >= the largest source keypoint count when max_n = 0).  d_ratio holds
  * dist_ratio_sq_adapted (:394).  Asynchronous on the stream. */
 int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pgi_feature_view* h_dst,
-                           uint32_t n_pairs, const double* h_pose_Rt, uint32_t max_n, uint32_t out_stride,
-                           uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts);
+                           uint32_t n_pairs, const double* h_pose_Rt, uint32_t n_bins, uint32_t max_n,
+                           uint32_t out_stride, uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio,
+                           uint32_t* d_counts);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,146 @@
+/*
+ * pgi_reference_adapter.h -- the binding a maintainer of danini/pose-graph-initialization adds.
+ *
+ * Header-only C++17, compiled INSIDE the reference tree, where OpenCV, Eigen and Sophus exist.  It maps the
+ * reference's own types onto the C ABI of include/pgi.h so that the bodies of
+ *     PoseGraphBuilder::estimatePose                      src/pyposegraphbuilder/include/pose_graph_builder.h:940-1078
+ *     EssentialMatrixEvaluator::getInliers                 .../graph_traversal.h:136-168
+ *     InTraversalPoseTester::test                          .../graph_traversal.h:194-233
+ *     pose::getPoseFromEssentialMatrix                     .../pose_utils.h:172-252
+ * become one call each; signatures, ownership (caller-owned outputs resized by the callee) and the bool error
+ * convention are the reference's.  cv::Mat N x 4 CV_64F is exactly `corr_aos`; Sophus::SE3d is (R row-major, t);
+ * std::vector<uchar> is the mask buffer.
+ *
+ * On this image none of the three libraries is installed, so the header compiles to nothing here (guarded by
+ * __has_include); tests/test_host_cpp.py checks that it at least preprocesses, and the same mapping is exercised for
+ * real through the dependency-free host layer (pose-graph-initialization_amd/host/pose_graph_builder.hpp).
+ */
+#ifndef PGI_REFERENCE_ADAPTER_H
+#define PGI_REFERENCE_ADAPTER_H
+
+#include "pgi.h"
+
+#if defined(__cplusplus) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && __has_include(<sophus/se3.hpp>) && __has_include(<Eigen/Core>)
+#define PGI_REFERENCE_ADAPTER_AVAILABLE 1
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <opencv2/core.hpp>
+#include <sophus/se3.hpp>
+
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+namespace reconstruction {
+namespace mi355x {
+
+/* One context per process.  pgi_estimate_pose is re-entrant (a pool of private stream + staging slots), so the
+ * kCoreNumber OpenMP threads of processImages (pose_graph_builder.h:391-392) share it and overlap on the GPU. */
+inline pgi_ctx* context() {
+    static pgi_ctx* ctx = [] {
+        pgi_ctx* c = pgi_create(/*device*/ -1, /*params: defaults*/ nullptr);
+        if (!c) throw std::runtime_error(pgi_last_error());  /* no HIP device: there is no CPU fallback */
+        return c;
+    }();
+    return ctx;
+}
+
+typedef Eigen::Matrix<double, 3, 3, Eigen::RowMajor> RowMajor3d;
+
+/* Replaces the body of PoseGraphBuilder::estimatePose (pose_graph_builder.h:940-1078).  kReconstruction_, the pixel
+ * threshold and the view indices are unused by the reference's body; seed / pairId select the RNG stream (use the
+ * pair's position in the similarity queue for run-to-run reproducibility). */
+inline bool estimatePose(const size_t kMinimumInlierNumber_, const cv::Mat& kCorrespondences_ /* N x 4 CV_64F */,
+                         const double kThreshold_ /* normalised, :934-937 */, const std::vector<Sophus::SE3d>& poseGuesses_,
+                         Sophus::SE3d& estimatedPose_, std::vector<uchar>& inlierMask_, size_t& inlierNumber_,
+                         const uint64_t seed = 0, const uint64_t pairId = 0) {
+    CV_Assert(kCorrespondences_.type() == CV_64F && kCorrespondences_.cols == 4 && kCorrespondences_.isContinuous());
+    std::vector<double> g(12 * poseGuesses_.size());
+    for (size_t i = 0; i < poseGuesses_.size(); ++i) {  /* row-major R, then t */
+        Eigen::Map<RowMajor3d>(&g[12 * i]) = poseGuesses_[i].rotationMatrix();
+        Eigen::Map<Eigen::Vector3d>(&g[12 * i + 9]) = poseGuesses_[i].translation();
+    }
+    inlierMask_.assign((size_t)kCorrespondences_.rows, 0);  /* :1000, :1034 */
+    pgi_edge e;
+    uchar none = 0;
+    const int rc = pgi_estimate_pose(context(), kCorrespondences_.ptr<double>(), (uint32_t)kCorrespondences_.rows, kThreshold_,
+                                     g.empty() ? nullptr : g.data(), (uint32_t)poseGuesses_.size(),
+                                     (uint32_t)kMinimumInlierNumber_, seed, pairId, &e,
+                                     inlierMask_.empty() ? &none : inlierMask_.data());
+    if (rc < 0) throw std::runtime_error(pgi_last_error());
+    inlierNumber_ = e.n_inl;                 /* :1022, :1047 */
+    if (rc != 1) return false;               /* :1053-1054 (too few inliers), :1069-1070 (NaN) */
+    const Eigen::Matrix3d R = Eigen::Map<const RowMajor3d>(e.R);
+    estimatedPose_ = Sophus::SE3d(Eigen::Quaterniond(R), Eigen::Map<const Eigen::Vector3d>(e.t));  /* :1073-1075 */
+    return true;
+}
+
+/* Device-side helper shared by the two scoring seams: rows and model up, mask / count down. */
+inline uint32_t scoreF64(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kEssential_, const double tau2,
+                         std::vector<uchar>* mask);
+
+/* EssentialMatrixEvaluator::getInliers (graph_traversal.h:136-168).  The reference compares the SQUARED Sampson
+ * distance with the un-squared kThreshold_ (line 164); pass kThreshold_ through unchanged to reproduce that. */
+inline void getInliers(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kDescriptor_, const double& kThreshold_,
+                       std::vector<size_t>& inliers_) {
+    std::vector<uchar> mask;
+    scoreF64(kCorrespondences_, kDescriptor_, kThreshold_, &mask);
+    inliers_.reserve(mask.size());
+    for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i]) inliers_.emplace_back(i);
+}
+
+/* InTraversalPoseTester::test (graph_traversal.h:194-233): true at kMinimumInlierNumber_ inliers of the squared bound. */
+inline bool testPose(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kEssential_, const double kSquaredThreshold_,
+                     const size_t kMinimumInlierNumber_, size_t& inlierNumber_) {
+    const uint32_t n = scoreF64(kCorrespondences_, kEssential_, kSquaredThreshold_, nullptr);
+    const bool ok = n >= kMinimumInlierNumber_;
+    inlierNumber_ = ok ? kMinimumInlierNumber_ : n;  /* the reference returns at that inlier (:221-225) */
+    return ok;
+}
+
+}  // namespace mi355x
+}  // namespace reconstruction
+
+/* scoreF64 needs device buffers; it is the only place this header touches the HIP runtime */
+#include <hip/hip_runtime_api.h>
+namespace reconstruction {
+namespace mi355x {
+inline uint32_t scoreF64(const cv::Mat& c, const Eigen::Matrix3d& E, const double tau2, std::vector<uchar>* mask) {
+    CV_Assert(c.type() == CV_64F && c.cols == 4 && c.isContinuous());
+    const uint32_t n = (uint32_t)c.rows;
+    const RowMajor3d Er = E;
+    const uint64_t off[2] = {0, n};
+    char* d = nullptr;
+    const size_t o_off = (size_t)n * 32, o_E = o_off + 16, o_tau = o_E + 72, o_cnt = o_tau + 8, o_mask = o_cnt + 8;
+    if (hipMalloc((void**)&d, o_mask + n + 8) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+    (void)hipMemcpy(d, c.ptr<double>(), (size_t)n * 32, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d + o_off, off, 16, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d + o_E, Er.data(), 72, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d + o_tau, &tau2, 8, hipMemcpyHostToDevice);
+    int rc = pgi_score_pose_f64(context(), (const double*)d, (const uint64_t*)(d + o_off), 1, (const double*)(d + o_E),
+                                (const double*)(d + o_tau), (uint32_t*)(d + o_cnt), (uint8_t*)(d + o_mask));
+    if (rc == PGI_SUCCESS) rc = pgi_synchronize(context());
+    uint32_t count = 0;
+    (void)hipMemcpy(&count, d + o_cnt, 4, hipMemcpyDeviceToHost);
+    if (mask) {
+        mask->assign(n, 0);
+        if (n) (void)hipMemcpy(mask->data(), d + o_mask, n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (rc < 0) throw std::runtime_error(pgi_last_error());
+    return count;
+}
+}  // namespace mi355x
+}  // namespace reconstruction
+
+#endif /* __has_include(...) */
+#endif /* __cplusplus && __has_include */
+
+#ifndef PGI_REFERENCE_ADAPTER_AVAILABLE
+#define PGI_REFERENCE_ADAPTER_AVAILABLE 0 /* OpenCV / Eigen / Sophus headers not found: nothing is declared */
+#endif
+
+#endif /* PGI_REFERENCE_ADAPTER_H */

@@ -5,6 +5,7 @@
  * Every FP statement is one IEEE op in a fixed order (the HIP kernels mirror it).
  */
 #include "pgi_oracle.h"
+#define _USE_MATH_DEFINES
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
@@ -756,6 +757,254 @@ void pgo_decompose(const double E[9], const float* x1, const float* y1, const fl
     for (int i = 0; i < 3; ++i) t[i] = (best & 1) ? -tt[i] : tt[i];
 }
 
+/* ======================================================================= */
+/* LITERAL restatement of the reference's candidate selection: */
+/* pose::getPoseFromEssentialMatrix pose_utils.h:172-252 with                    */
+/* pose::linearTriangulation pose_utils.h:491-506 and decomposeEssentialMatrix    */
+/* pose_utils.h:144-169.  NOT what the product computes (that is pgo_decompose:   */
+/* depth signs, inlier rows) -- this exists to MEASURE how the two rules differ.  */
+/* ======================================================================= */
+/* Right singular vectors by one-sided (Hestenes) Jacobi: A (n x n, row-major) V = U S, columns of V sorted by
+ * decreasing singular value like Eigen::JacobiSVD.  V is a product of plane rotations started from the identity plus
+ * the final column permutation; its column SIGNS are this routine's own -- Eigen's are not reproducible here. */
+static void jacobi_right_vectors(const double* A, int n, double* V, double* sv) {
+    double B[16];
+    for (int i = 0; i < n * n; ++i) B[i] = A[i];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[n * i + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int k = 0; k < n; ++k) {
+                    al += B[n * k + p] * B[n * k + p];
+                    be += B[n * k + q] * B[n * k + q];
+                    ga += B[n * k + p] * B[n * k + q];
+                }
+                if (fabs(ga) <= 1e-17 * sqrt(al * be) || ga == 0.0) continue;
+                rotated = 1;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+                for (int k = 0; k < n; ++k) {
+                    const double bp = B[n * k + p], bq = B[n * k + q];
+                    B[n * k + p] = c * bp - sn * bq;
+                    B[n * k + q] = sn * bp + c * bq;
+                    const double vp = V[n * k + p], vq = V[n * k + q];
+                    V[n * k + p] = c * vp - sn * vq;
+                    V[n * k + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < n; ++j) {
+        double s2 = 0;
+        for (int k = 0; k < n; ++k) s2 += B[n * k + j] * B[n * k + j];
+        sv[j] = sqrt(s2);
+    }
+    for (int a = 0; a < n - 1; ++a) { /* selection sort, descending; swap columns of V along */
+        int m = a;
+        for (int b = a + 1; b < n; ++b)
+            if (sv[b] > sv[m]) m = b;
+        if (m != a) {
+            const double ts = sv[a]; sv[a] = sv[m]; sv[m] = ts;
+            for (int k = 0; k < n; ++k) {
+                const double tv = V[n * k + a]; V[n * k + a] = V[n * k + m]; V[n * k + m] = tv;
+            }
+        }
+    }
+}
+
+/* pose_utils.h:491-506: rows x*P3-P1, y*P3-P2 for both views; null vector = last column of V (sign NOT normalised) */
+void pgo_ref_linear_triangulation(const double P1[12], const double P2[12], const double pt[4], double X[4]) {
+    double D[16], V[16], sv[4];
+    for (int c = 0; c < 4; ++c) {
+        D[0 + c] = pt[0] * P1[8 + c] - P1[0 + c];
+        D[4 + c] = pt[1] * P1[8 + c] - P1[4 + c];
+        D[8 + c] = pt[2] * P2[8 + c] - P2[0 + c];
+        D[12 + c] = pt[3] * P2[8 + c] - P2[4 + c];
+    }
+    jacobi_right_vectors(D, 4, V, sv);
+    for (int k = 0; k < 4; ++k) X[k] = V[4 * k + 3];
+}
+
+static double det3(const double* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+/* pose_utils.h:144-169, literally: full U, V of E; last column of U / V negated when det < 0;
+ * R1 = U d V^T, R2 = U d^T V^T with d = [0 1 0; -1 0 0; 0 0 1]; t = U.col(2).normalized() */
+void pgo_ref_decompose_essential(const double E[9], double R1[9], double R2[9], double t[3]) {
+    double U[9], V[9], sv[3], Et[9];
+    jacobi_right_vectors(E, 3, V, sv);           /* E = U S V^T: V from E ...            */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Et[3 * i + j] = E[3 * j + i];
+    /* ... and U = E V S^-1 for the two non-zero singular values, third column = U0 x U1 (any full U does: the
+     * reference then fixes det U = +1 by flipping exactly that column) */
+    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 3; ++i) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += E[3 * i + k] * V[3 * k + j];
+            U[3 * i + j] = a / sv[j];
+        }
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    (void)Et;
+    if (det3(U) < 0) { U[2] = -U[2]; U[5] = -U[5]; U[8] = -U[8]; }
+    if (det3(V) < 0) { V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8]; }
+    static const double d[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    double Ud[9], Udt[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; ++k) {
+                a += U[3 * i + k] * d[3 * k + j];
+                b += U[3 * i + k] * d[3 * j + k];
+            }
+            Ud[3 * i + j] = a;
+            Udt[3 * i + j] = b;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; ++k) {
+                a += Ud[3 * i + k] * V[3 * j + k];
+                b += Udt[3 * i + k] * V[3 * j + k];
+            }
+            R1[3 * i + j] = a;
+            R2[3 * i + j] = b;
+        }
+    const double nn = sqrt(U[2] * U[2] + U[5] * U[5] + U[8] * U[8]);
+    t[0] = U[2] / nn; t[1] = U[5] / nn; t[2] = U[8] / nn;
+}
+
+/* pose_utils.h:172-252.  For each of the 4 candidates (R1,+t) (R1,-t) (R2,+t) (R2,-t) and EVERY row: DLT point, skip
+ * when raw projected z < 0 in view 1 or view 2 (:208-216; no division by w), squared reprojection error in both
+ * views (:223-224), strict-< arg-min per row (:226-230), one vote per row (:237-239), first maximum wins (:242-245).
+ * The raw-z test depends on the SIGN of the homogeneous null vector, which in the reference is whatever Eigen's
+ * JacobiSVD returns.  All three possibilities are evaluated from the same null vectors:
+ *   mode 0 "raw"  : the sign this file's Jacobi produces            (one arbitrary convention)
+ *   mode 1 "w>=0" : null vector scaled so that w >= 0                (then z<0 IS the cheirality test)
+ *   mode 2 "w<=0" : the opposite sign                                 (then points BEHIND both cameras pass)
+ * out_R[m], out_t[m], out_votes[m][4], out_cand[m] for m = 0..2.  Returns the vote count of mode 0's winner (:251). */
+int pgo_ref_pose_from_essential(const double E[9], const double* corr_aos, uint32_t n, double out_R[3][9],
+                                double out_t[3][3], uint32_t out_votes[3][4], uint32_t out_cand[3]) {
+    double R1[9], R2[9], t[3];
+    pgo_ref_decompose_essential(E, R1, R2, t);
+    const double* rot[4] = {R1, R1, R2, R2};
+    const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double* bestd = (double*)malloc((size_t)n * 3 * sizeof(double));
+    int* bestp = (int*)malloc((size_t)n * 3 * sizeof(int));
+    for (size_t k = 0; k < (size_t)n * 3; ++k) { bestd[k] = DBL_MAX; bestp[k] = 5; }
+    for (int i = 0; i < 4; ++i) {
+        double P2[12];
+        const double sg = (i % 2) ? -1.0 : 1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) P2[4 * r + c] = rot[i][3 * r + c];
+            P2[4 * r + 3] = sg * t[r];
+        }
+        for (uint32_t p = 0; p < n; ++p) {
+            const double* pt = corr_aos + 4 * (size_t)p;
+            double X[4];
+            pgo_ref_linear_triangulation(P1, P2, pt, X);
+            for (int m = 0; m < 3; ++m) {
+                double Y[4];
+                const double f = (m == 0) ? 1.0 : (m == 1) ? (X[3] < 0 ? -1.0 : 1.0) : (X[3] > 0 ? -1.0 : 1.0);
+                for (int k = 0; k < 4; ++k) Y[k] = f * X[k];
+                const double p1[3] = {Y[0], Y[1], Y[2]}; /* proj_1 = [I | 0] */
+                if (p1[2] < 0) continue;
+                double p2[3];
+                for (int r = 0; r < 3; ++r) p2[r] = P2[4 * r] * Y[0] + P2[4 * r + 1] * Y[1] + P2[4 * r + 2] * Y[2] + P2[4 * r + 3] * Y[3];
+                if (p2[2] < 0) continue;
+                const double e1x = p1[0] / p1[2] - pt[0], e1y = p1[1] / p1[2] - pt[1];
+                const double e2x = p2[0] / p2[2] - pt[2], e2y = p2[1] / p2[2] - pt[3];
+                const double err = (e1x * e1x + e1y * e1y) + (e2x * e2x + e2y * e2y);
+                if (err < bestd[3 * (size_t)p + m]) {
+                    bestd[3 * (size_t)p + m] = err;
+                    bestp[3 * (size_t)p + m] = i;
+                }
+            }
+        }
+    }
+    for (int m = 0; m < 3; ++m) {
+        uint32_t* v = out_votes[m];
+        v[0] = v[1] = v[2] = v[3] = 0;
+        for (uint32_t p = 0; p < n; ++p)
+            if (bestp[3 * (size_t)p + m] < 5) ++v[bestp[3 * (size_t)p + m]];
+        uint32_t best = 0;
+        for (uint32_t c = 1; c < 4; ++c)
+            if (v[c] > v[best]) best = c;
+        out_cand[m] = best;
+        memcpy(out_R[m], rot[best], 9 * sizeof(double));
+        for (int k = 0; k < 3; ++k) out_t[m][k] = ((best % 2) ? -1.0 : 1.0) * t[k];
+    }
+    free(bestd);
+    free(bestp);
+    return (int)out_votes[0][out_cand[0]];
+}
+
+/* Agreement study (scripts/candidate_agreement.py): for every pair, the product's rule (pgo_decompose on the inlier
+ * rows, what the HIP kernels reproduce bit for bit) next to the literal rule in its three sign conventions.
+ * flags[p]: bit m (m=0..2): literal mode m chose the same rotation as the product; bit 4+m: the same translation sign;
+ * bit 7: pair evaluated (edge OK); bit 8: the product's vote_all_rows=1 variant gives literal mode 1's (R, t);
+ * bits 9/10/11: translation points the ground-truth way (t . t_gt > 0) for product(inliers) / product(all rows) /
+ * literal mode 1.  t_gt: n_pairs x 3. */
+void pgo_candidate_agreement_batch(const float* x1, const float* y1, const float* x2, const float* y2,
+                                   const uint64_t* offsets, uint32_t n_pairs, const pgo_edge* edges, const uint8_t* masks,
+                                   const double* t_gt, uint16_t* flags, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+        flags[p] = 0;
+        if (edges[p].status != PGO_OK) continue;
+        const uint64_t o = offsets[p];
+        const uint32_t n = (uint32_t)(offsets[p + 1] - o);
+        double* corr = (double*)malloc((size_t)n * 4 * sizeof(double));
+        for (uint32_t i = 0; i < n; ++i) { /* the reference's N x 4 f64 matrix */
+            corr[4 * i] = x1[o + i]; corr[4 * i + 1] = y1[o + i]; corr[4 * i + 2] = x2[o + i]; corr[4 * i + 3] = y2[o + i];
+        }
+        double R[3][9], t[3][3];
+        uint32_t votes[3][4], cand[3];
+        pgo_ref_pose_from_essential(edges[p].E, corr, n, R, t, votes, cand);
+        uint16_t f = 0x80;
+        for (int m = 0; m < 3; ++m) {
+            double dR = 0, dt = 0;
+            for (int k = 0; k < 9; ++k) dR = fmax(dR, fabs(R[m][k] - edges[p].R[k]));
+            for (int k = 0; k < 3; ++k) dt = fmax(dt, fabs(t[m][k] - edges[p].t[k]));
+            if (dR < 1e-6) f |= (uint16_t)(1u << m);
+            if (dt < 1e-6) f |= (uint16_t)(1u << (4 + m));
+        }
+        double Ra[9], ta[3];
+        uint32_t va[4], ca;
+        pgo_decompose(edges[p].E, x1 + o, y1 + o, x2 + o, y2 + o, masks + o, n, 1, Ra, ta, va, &ca);
+        double dRa = 0, dta = 0;
+        for (int k = 0; k < 9; ++k) dRa = fmax(dRa, fabs(Ra[k] - R[1][k]));
+        for (int k = 0; k < 3; ++k) dta = fmax(dta, fabs(ta[k] - t[1][k]));
+        if (dRa < 1e-6 && dta < 1e-6) f |= 0x100;
+        if (t_gt) {
+            const double* g = t_gt + 3 * (size_t)p;
+            if (edges[p].t[0] * g[0] + edges[p].t[1] * g[1] + edges[p].t[2] * g[2] > 0) f |= 0x200;
+            if (ta[0] * g[0] + ta[1] * g[1] + ta[2] * g[2] > 0) f |= 0x400;
+            if (t[1][0] * g[0] + t[1][1] * g[1] + t[1][2] * g[2] > 0) f |= 0x800;
+        }
+        flags[p] = f;
+        free(corr);
+    }
+}
+
+/* Unit-Frobenius f32 model from an f64 E, as the one-model scoring kernel (K2, pgi_score_pose_batch) prepares it:
+ * n2 by an fma chain over the nine entries in order, one reciprocal square root, product rounded to f32. */
+void pgo_model_from_essential(const double E[9], float e32[9]) {
+    double n2 = 0.0;
+    for (int c = 0; c < 9; ++c) n2 = fma(E[c], E[c], n2);
+    const double inv = 1.0 / sqrt(n2);
+    for (int c = 0; c < 9; ++c) e32[c] = (float)(E[c] * inv);
+}
+
 /* ---- robust estimator ---------------------------------------------------- */
 static double pow_uint(double q, uint32_t k) { /* binary exponentiation, fixed order */
     double r = 1.0, b = q;
@@ -1080,5 +1329,110 @@ uint32_t pgo_guided_match(const double F[9], const float* kp1, uint32_t n1, cons
             ++m;
         }
     }
+    return m;
+}
+
+/* LITERAL epipolar hashing of HashingBasedMatcherWithPose::match (matcher.h:199-405, instantiated with 45 bins at
+ * pose_graph_builder.h:738): destination keypoints are hashed by the angle of their epipolar line's normal in the
+ * source image (:283-301), a source keypoint only meets the destination keypoints of ITS bin (:306-327), everything
+ * after that is the candidate loop of pgo_guided_match.  Epipole = right null vector of F (:220-226, JacobiSVD
+ * ComputeFullV; the sign cancels in the division by its third component); when it lies inside the source image the
+ * angular range degenerates to min 180 / max 0 (:232-262), otherwise it comes from the destination image corners.
+ * atan2 / round are libm's, as in the reference.  size_src / size_dst: cv::Size (integers) of the two images.
+ * fragile[i] (optional, n1 bytes): 1 when source i's bin, or the bin of a destination keypoint that passes i's
+ * epipolar gate, lies within 1e-7 of a rounding boundary -- a result that a different libm / SVD may flip. */
+uint32_t pgo_ref_guided_match_binned(const double F[9], const float* kp1, uint32_t n1, const float* kp2, uint32_t n2,
+                                     const float* d1, const float* d2, uint32_t dim, const int size_src[2],
+                                     const int size_dst[2], int n_bins, uint32_t* out_i, uint32_t* out_j, double* out_ratio,
+                                     uint8_t* fragile) {
+    const double kRadianToDegree = 180.0 / 3.14159265358979323846; /* M_PI */
+    const double e11 = F[0], e12 = F[1], e13 = F[2], e21 = F[3], e22 = F[4], e23 = F[5], e31 = F[6], e32 = F[7],
+                 e33 = F[8];
+    double V[9], sv[3];
+    jacobi_right_vectors(F, 3, V, sv);
+    const double ep0 = V[2] / V[8], ep1 = V[5] / V[8];
+    const int in_image = ep0 >= 0 && ep0 < size_src[0] && ep1 >= 0 && ep1 < size_src[1];
+    double min_angle = 180, max_angle = 0;
+    if (!in_image) {
+        const double corner[8] = {0, 0, (double)size_dst[0], 0, (double)size_dst[0], (double)size_dst[1], 0, (double)size_dst[1]};
+        for (int c = 0; c < 8; c += 2) {
+            const double x = corner[c], y = corner[c + 1];
+            const double nx = e11 * x + e21 * y + e31;
+            const double ny = e12 * x + e22 * y + e32;
+            double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
+            if (angle > 180) angle -= 180;
+            min_angle = angle < min_angle ? angle : min_angle;
+            max_angle = angle > max_angle ? angle : max_angle;
+        }
+    }
+    const double range = max_angle - min_angle;
+    const int bins = n_bins > 0 ? n_bins : (int)range;
+    int* bin_of = (int*)malloc(((size_t)n2 + 1) * sizeof(int));
+    uint8_t* frag2 = (uint8_t*)calloc((size_t)n2 + 1, 1);
+    for (uint32_t j = 0; j < n2; ++j) {
+        const double px = kp2[2 * j], py = kp2[2 * j + 1];
+        const double nx = e11 * px + e21 * py + e31;
+        const double ny = e12 * px + e22 * py + e32;
+        double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
+        if (angle > 180) angle -= 180;
+        angle = (bins - 1) * (angle - min_angle) / range;
+        const int b = (int)round(angle);
+        bin_of[j] = b < 0 ? 0 : (b > bins - 1 ? bins - 1 : b);
+        frag2[j] = !(fabs(fabs(angle - floor(angle)) - 0.5) > 1e-7);  /* also catches NaN */
+    }
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n1; ++i) {
+        const double px = kp1[2 * i], py = kp1[2 * i + 1];
+        const double vx = px - ep0, vy = py - ep1;
+        const double nx = -vy, ny = vx;
+        double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
+        if (angle > 180) angle -= 180;
+        angle = (bins - 1) * (angle - min_angle) / range;
+        int bin = (int)round(angle);
+        bin = bin < 0 ? 0 : (bin > bins - 1 ? bins - 1 : bin);
+        int frag = !(fabs(fabs(angle - floor(angle)) - 0.5) > 1e-7);
+        double second = DBL_MAX, best = DBL_MAX;
+        int best_index = -1;
+        uint32_t count = 0;
+        const double x1 = px, y1 = py;
+        const double rx = (e11 * x1 + e12 * y1) + e13;
+        const double ry = (e21 * x1 + e22 * y1) + e23;
+        const double b1 = rx * rx + ry * ry;
+        for (uint32_t j = 0; j < n2; ++j) {
+            if (bin_of[j] != bin && !frag2[j]) continue;
+            const double x2 = kp2[2 * j], y2 = kp2[2 * j + 1];
+            const double rxc = (e11 * x2 + e21 * y2) + e31;
+            const double ryc = (e12 * x2 + e22 * y2) + e32;
+            const double rwc = (e13 * x2 + e23 * y2) + e33;
+            const double r = (x1 * rxc + y1 * ryc) + rwc;
+            const double a1 = rxc * rxc + ryc * ryc;
+            const double dist = ((r * r) * (a1 + b1)) / (a1 * b1);
+            if (dist >= 0.75 * 0.75) continue;
+            if (frag2[j]) frag = 1;       /* a borderline destination keypoint competes (or would compete) here */
+            if (bin_of[j] != bin) continue;
+            ++count;
+            double dd = 0.0;
+            for (uint32_t k = 0; k < dim; ++k) {
+                const float df = d1[(size_t)i * dim + k] - d2[(size_t)j * dim + k];
+                const double dv = df;
+                dd = dd + dv * dv;
+            }
+            if (dd < best) { second = best; best = dd; best_index = (int)j; }
+        }
+        if (fragile) fragile[i] = (uint8_t)frag;
+        double corr = 1.0;
+        if (count < 20) corr = 0.65 * 0.65;
+        if (count < 10) corr = 0.6 * 0.6;
+        if (count < 5) corr = 0.5 * 0.5;
+        if (count < 3) corr = 0.25 * 0.25;
+        const double ratio = (best / second) / corr;
+        if (ratio < 0.00001) continue;
+        if (best_index > -1 && (ratio < 0.8 * 0.8 || count == 1)) {
+            out_i[m] = i; out_j[m] = (uint32_t)best_index; out_ratio[m] = ratio;
+            ++m;
+        }
+    }
+    free(bin_of);
+    free(frag2);
     return m;
 }

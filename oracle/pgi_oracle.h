@@ -113,6 +113,8 @@ void pgo_score_model(const float E[9], const float* x1, const float* y1, const f
 /* pre-verification on the first min(64,n) rows against a best with n_bar inliers (1 = keep) */
 int pgo_preverify(const float E[9], const float* x1, const float* y1, const float* x2,
                   const float* y2, uint32_t n, double thr, uint32_t n_bar);
+/* f64 E -> the unit-norm f32 model the one-model scoring kernel uses (fma-chain norm) */
+void pgo_model_from_essential(const double E[9], float e32[9]);
 /* mask[i] = sampson^2 < tau2 (tau2 arbitrary; f32 arithmetic) */
 uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, const float* x2,
                         const float* y2, uint32_t n, float tau2, uint8_t* mask);
@@ -145,6 +147,16 @@ void pgo_decompose(const double E[9], const float* x1, const float* y1, const fl
                    const float* y2, const uint8_t* mask, uint32_t n, int vote_all,
                    double R[9], double t[3], uint32_t votes[4], uint32_t* cand);
 
+/* LITERAL restatements of the reference's candidate selection (pose_utils.h:144-169, 172-252, 491-506); used only
+ * to measure how the product's depth-sign vote differs from it (scripts/candidate_agreement.py) */
+void pgo_ref_linear_triangulation(const double P1[12], const double P2[12], const double pt[4], double X[4]);
+void pgo_ref_decompose_essential(const double E[9], double R1[9], double R2[9], double t[3]);
+int pgo_ref_pose_from_essential(const double E[9], const double* corr_aos, uint32_t n, double out_R[3][9],
+                                double out_t[3][3], uint32_t out_votes[3][4], uint32_t out_cand[3]);
+void pgo_candidate_agreement_batch(const float* x1, const float* y1, const float* x2, const float* y2,
+                                   const uint64_t* offsets, uint32_t n_pairs, const pgo_edge* edges, const uint8_t* masks,
+                                   const double* t_gt, uint16_t* flags, int threads);
+
 /* robust fit: rounds of hypotheses, LO on improvement, adaptive termination */
 void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, const float* y2,
                           uint32_t n, double thr, const pgo_params* prm, uint64_t seed,
@@ -165,6 +177,12 @@ void pgo_fundamental_from_essential(const double E[9], const double k_src[4], co
 uint32_t pgo_guided_match(const double F[9], const float* kp1, uint32_t n1, const float* kp2, uint32_t n2,
                           const float* d1, const float* d2, uint32_t dim, uint32_t* out_i, uint32_t* out_j,
                           double* out_ratio);
+
+/* the same with the reference's 45 epipolar bins, literally (matcher.h:218-331) */
+uint32_t pgo_ref_guided_match_binned(const double F[9], const float* kp1, uint32_t n1, const float* kp2, uint32_t n2,
+                                     const float* d1, const float* d2, uint32_t dim, const int size_src[2],
+                                     const int size_dst[2], int n_bins, uint32_t* out_i, uint32_t* out_j, double* out_ratio,
+                                     uint8_t* fragile);
 
 /* batch over a flattened (pair,corr) SoA; OpenMP over pairs (threads<=0: all) */
 void pgo_estimate_pose_batch(const float* x1, const float* y1, const float* x2,

@@ -566,7 +566,20 @@ struct GuidedPair {
     uint32_t n1, n2;
     double F[9];
     uint64_t off;  // first per-source scratch slot of this pair
+    // epipolar hashing (matcher.h:218-331): bins == 0 -> every destination keypoint is a candidate
+    double ep0, ep1, min_angle, range;
+    int32_t bins, pad;
 };
+constexpr double kRadianToDegree = 180.0 / 3.14159265358979323846;
+// matcher.h:292-301 / :318-324: angle of a line normal -> bin index
+__device__ __forceinline__ int32_t epipolar_bin(double ny, double nx, double min_angle, double range, int32_t bins) {
+    double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
+    if (angle > 180) angle -= 180;
+    angle = (double)(bins - 1) * (angle - min_angle) / range;
+    const double r = round(angle);
+    int32_t b = (r >= 2147483647.0) ? 2147483647 : (r > -2147483648.0 ? (int32_t)r : (int32_t)(-2147483647 - 1));  // NaN -> INT_MIN like x86
+    return b < 0 ? 0 : (b > bins - 1 ? bins - 1 : b);
+}
 constexpr int kGmTile = 512;  // destination keypoints whose epipolar-line records are staged per step
 constexpr int kGmList = 32;   // candidates a thread collects before the wavefront evaluates their descriptors
 
@@ -579,6 +592,7 @@ constexpr int kGmList = 32;   // candidates a thread collects before the wavefro
 __global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __restrict__ pairs, int32_t* __restrict__ best_out,
                                                           double* __restrict__ ratio_out) {
     __shared__ double rec[kGmTile][4];
+    __shared__ int32_t rbin[kGmTile];
     __shared__ uint32_t list[kGmList][256];
     const GuidedPair P = pairs[blockIdx.y];
     if (blockIdx.x * 256u >= P.n1) return;
@@ -591,6 +605,11 @@ __global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __re
     const double rx = (e11 * x1 + e12 * y1) + e13;
     const double ry = (e21 * x1 + e22 * y1) + e23;
     const double b1 = rx * rx + ry * ry;
+    int32_t my_bin = 0;
+    if (P.bins) {  // the normal of the line through the epipole and this keypoint (matcher.h:311-324)
+        const double vx = x1 - P.ep0, vy = y1 - P.ep1;
+        my_bin = epipolar_bin(vx, -vy, P.min_angle, P.range, P.bins);
+    }
     double best = DBL_MAX, second = DBL_MAX;
     int32_t best_index = -1;
     uint32_t count = 0, nlist = 0;
@@ -627,6 +646,8 @@ __global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __re
             const double ryc = (e12 * x2 + e22 * y2) + e32;
             const double rwc = (e13 * x2 + e23 * y2) + e33;
             rec[jj][0] = rxc; rec[jj][1] = ryc; rec[jj][2] = rwc; rec[jj][3] = rxc * rxc + ryc * ryc;
+            // the destination keypoint's bin: normal (nx, ny) = (rxc, ryc) of its epipolar line F^T x2 (matcher.h:283-301)
+            rbin[jj] = P.bins ? epipolar_bin(ryc, rxc, P.min_angle, P.range, P.bins) : 0;
         }
         __syncthreads();
         for (uint32_t jj = 0; jj < lim; ++jj) {
@@ -635,7 +656,7 @@ __global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __re
             const double num = (r * r) * (a1 + b1), den = a1 * b1;
             // cheap sufficient test for "dist >= 0.75^2" (no division); everything else takes the exact path
             const bool surely_far = den > 0.0 && num >= 0.57 * den;
-            if (active && !surely_far) {
+            if (active && !surely_far && rbin[jj] == my_bin) {
                 const double dist = num / den;
                 if (!(dist >= 0.75 * 0.75)) { list[nlist][tid] = j0 + jj; ++nlist; }
             }
@@ -1010,13 +1031,65 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
     return PGI_SUCCESS;
 }
 
+// Right null vector of a 3x3 matrix by one-sided (Hestenes) Jacobi: the epipole of matcher.h:220-226 (JacobiSVD,
+// ComputeFullV, column 2).  Host code; same operation order as the specification in oracle/pgi_oracle.c.
+static void right_null_vector3(const double* A, double out[3]) {
+    double B[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sv[3];
+    for (int i = 0; i < 9; ++i) B[i] = A[i];
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int k = 0; k < 3; ++k) {
+                    al += B[3 * k + p] * B[3 * k + p];
+                    be += B[3 * k + q] * B[3 * k + q];
+                    ga += B[3 * k + p] * B[3 * k + q];
+                }
+                if (std::fabs(ga) <= 1e-17 * std::sqrt(al * be) || ga == 0.0) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + tt * tt), sn = c * tt;
+                for (int k = 0; k < 3; ++k) {
+                    const double bp = B[3 * k + p], bq = B[3 * k + q];
+                    B[3 * k + p] = c * bp - sn * bq;
+                    B[3 * k + q] = sn * bp + c * bq;
+                    const double vp = V[3 * k + p], vq = V[3 * k + q];
+                    V[3 * k + p] = c * vp - sn * vq;
+                    V[3 * k + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < 3; ++j) {
+        double s2 = 0;
+        for (int k = 0; k < 3; ++k) s2 += B[3 * k + j] * B[3 * k + j];
+        sv[j] = std::sqrt(s2);
+    }
+    for (int a = 0; a < 2; ++a) {  // descending singular values, columns of V along
+        int m = a;
+        for (int b = a + 1; b < 3; ++b)
+            if (sv[b] > sv[m]) m = b;
+        if (m != a) {
+            std::swap(sv[a], sv[m]);
+            for (int k = 0; k < 3; ++k) std::swap(V[3 * k + a], V[3 * k + m]);
+        }
+    }
+    out[0] = V[2]; out[1] = V[5]; out[2] = V[8];
+}
+
 int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pgi_feature_view* h_dst, uint32_t n_pairs,
-                           const double* h_pose_Rt, uint32_t max_n, uint32_t out_stride, uint32_t* d_match_src,
-                           uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
+                           const double* h_pose_Rt, uint32_t n_bins, uint32_t max_n, uint32_t out_stride,
+                           uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
     if (!ctx || !d_counts) return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: null argument");
     if (n_pairs == 0) return PGI_SUCCESS;
     if (!h_src || !h_dst || !h_pose_Rt || !d_match_src || !d_match_dst || !d_ratio || out_stride == 0)
         return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: null argument");
+    if (n_bins > 4096) return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: n_bins out of range");
+    for (uint32_t p = 0; p < n_pairs; ++p)
+        if (max_n == 0 ? out_stride < h_src[p].n : out_stride < max_n)
+            return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: out_stride is smaller than the matches a pair may return");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<GuidedPair> hp(n_pairs);
@@ -1026,7 +1099,7 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         const pgi_feature_view &a = h_src[p], &b = h_dst[p];
         if ((a.n && (!a.d_xy || !a.d_desc)) || (b.n && (!b.d_xy || !b.d_desc)))
             return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: bad feature view");
-        GuidedPair g{a.d_xy, b.d_xy, a.d_desc, b.d_desc, a.n, b.n, {}, total};
+        GuidedPair g{a.d_xy, b.d_xy, a.d_desc, b.d_desc, a.n, b.n, {}, total, 0.0, 0.0, 0.0, 0.0, 0, 0};
         // E = [t]x R (pose.h:50, pose_utils.h), F = K_dst^-T E K_src^-1 (matcher.h:216-217), operation order as in the oracle
         const double* R = h_pose_Rt + 12 * (size_t)p;
         const double* t = R + 9;
@@ -1048,6 +1121,30 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
             g.F[3 + c] = G[3 + c] / b.fy;
             g.F[6 + c] = (G[6 + c] - g.F[c] * b.cx) - g.F[3 + c] * b.cy;
         }
+        if (n_bins) {  // epipole, angular range and bin count (matcher.h:218-266)
+            double nv[3];
+            right_null_vector3(g.F, nv);
+            g.ep0 = nv[0] / nv[2];
+            g.ep1 = nv[1] / nv[2];
+            const int sw = (int)a.width, sh = (int)a.height, dw = (int)b.width, dh = (int)b.height;  // cv::Size is integral
+            const bool inImage = g.ep0 >= 0 && g.ep0 < sw && g.ep1 >= 0 && g.ep1 < sh;
+            double minAngle = 180, maxAngle = 0;
+            if (!inImage) {
+                const double corner[8] = {0, 0, (double)dw, 0, (double)dw, (double)dh, 0, (double)dh};
+                for (int c = 0; c < 8; c += 2) {
+                    const double x = corner[c], y = corner[c + 1];
+                    const double nx = g.F[0] * x + g.F[3] * y + g.F[6];
+                    const double ny = g.F[1] * x + g.F[4] * y + g.F[7];
+                    double angle = kRadianToDegree * std::atan2(ny, nx) + 180.0;
+                    if (angle > 180) angle -= 180;
+                    minAngle = angle < minAngle ? angle : minAngle;
+                    maxAngle = angle > maxAngle ? angle : maxAngle;
+                }
+            }
+            g.min_angle = minAngle;
+            g.range = maxAngle - minAngle;
+            g.bins = (int32_t)n_bins;
+        }
         hp[p] = g;
         total += a.n;
         max_n1 = a.n > max_n1 ? a.n : max_n1;
@@ -1065,6 +1162,8 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
+    ctx->d_match_cnt = nullptr;  // the workspace is repurposed: the last screened match's counters are gone
+    ctx->match_cnt_pairs = 0;
     char* ws = (char*)ctx->d_match_ws;
     GuidedPair* d_pairs = (GuidedPair*)ws;
     double* d_rat = (double*)(ws + pair_bytes);

@@ -363,7 +363,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
         descView[v] = pgi_desc_view{ddt[v]->as<float>(), dnorm[v]->as<float>(), n, n_pad, drm[v]->as<float>(), df16[v]->as<uint16_t>()};
         kpView[v] = pgi_keypoint_view{dxy[v]->as<float>(), n, 0, f, f, cx, cy};
-        featView[v] = pgi_feature_view{dxy[v]->as<float>(), ddesc[v]->as<float>(), n, 0, f, f, cx, cy};
+        featView[v] = pgi_feature_view{dxy[v]->as<float>(), ddesc[v]->as<float>(), n, 0, f, f, cx, cy, views[v].width, views[v].height};
     }
     std::stable_sort(cand.begin(), cand.end(), [](const CandidatePair& a, const CandidatePair& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
@@ -575,11 +575,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             for (int c = 0; c < 3; ++c) gpose.push_back(edges[k].t[c]);
         }
         const uint32_t gstride = (uint32_t)std::max<size_t>(1, kMaximumPointNumberForEpipolarHashing);
+        constexpr uint32_t kEpipolarBins = 45;  // HashingBasedMatcherWithPose<false, 45> (pose_graph_builder.h:738)
         std::vector<uint32_t> gsrc, gdst, gcnt;
         if (!guidedOf.empty()) {
             const size_t G = guidedOf.size();
             DevBuf ds(G * (size_t)gstride * 4), dd(G * (size_t)gstride * 4), dr(G * (size_t)gstride * 8), dc(G * 4);
-            Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), gstride, gstride, ds.as<uint32_t>(),
+            Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds.as<uint32_t>(),
                                                  dd.as<uint32_t>(), dr.as<double>(), dc.as<uint32_t>()));
             Engine::check(pgi_synchronize(ctx));
             gsrc.resize(G * (size_t)gstride); gdst.resize(G * (size_t)gstride); gcnt.resize(G);

@@ -76,7 +76,8 @@ class KeypointView(C.Structure):
 class FeatureView(C.Structure):
     """pgi_feature_view (include/pgi.h)."""
     _fields_ = [("d_xy", C.c_void_p), ("d_desc", C.c_void_p), ("n", C.c_uint32), ("reserved", C.c_uint32),
-                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("width", C.c_double), ("height", C.c_double)]
 
 
 class PgiError(RuntimeError):
@@ -109,7 +110,7 @@ def load():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_guided_match_batch.argtypes = [C.c_void_p, C.POINTER(FeatureView), C.POINTER(FeatureView), C.c_uint32, C.c_void_p,
-                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                           C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch_host.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,

@@ -270,7 +270,8 @@ class Engine:
     def upload_keypoints(self, xy, f, w, h):
         """cv::KeyPoint::pt array (n x 2 pixels) + pinhole camera K = [f 0 w/2; 0 f h/2] (pose_graph_builder.h:286)."""
         t = torch.as_tensor(np.ascontiguousarray(xy, np.float32).reshape(-1, 2)).to(self.device)
-        return {"xy": t, "n": int(t.shape[0]), "fx": float(f), "fy": float(f), "cx": w / 2.0, "cy": h / 2.0}
+        return {"xy": t, "n": int(t.shape[0]), "fx": float(f), "fy": float(f), "cx": w / 2.0, "cy": h / 2.0,
+                "width": float(w), "height": float(h)}
 
     def build_correspondences(self, keypoints, pairs, matches, thr_px, top_k=0, dst_uses_src_intrinsics=False, seed=0,
                               pair_id_base=0):
@@ -304,9 +305,10 @@ class Engine:
         kp["desc"] = torch.as_tensor(np.ascontiguousarray(desc, np.float32).reshape(-1, 128)).to(self.device)
         return kp
 
-    def guided_match_batch(self, features, pairs, poses_Rt, max_n=100, raw=False):
+    def guided_match_batch(self, features, pairs, poses_Rt, max_n=100, raw=False, n_bins=45):
         """HashingBasedMatcherWithPose::match + the top-N cut of guidedMatching (matcher.h:199-405,
-        pose_graph_builder.h:715-783) for every (src, dst) pair with pose (R, t) = poses_Rt[p] (12 doubles)."""
+        pose_graph_builder.h:715-783) for every (src, dst) pair with pose (R, t) = poses_Rt[p] (12 doubles).
+        n_bins = 45 is the reference's epipolar hashing; n_bins = 0 visits every destination keypoint."""
         P = len(pairs)
         va, vb = (L.FeatureView * max(P, 1))(), (L.FeatureView * max(P, 1))()
         for p, (s, d) in enumerate(pairs):
@@ -314,6 +316,7 @@ class Engine:
                 v.d_xy = ft["xy"].data_ptr() if ft["n"] else None
                 v.d_desc = ft["desc"].data_ptr() if ft["n"] else None
                 v.n, v.fx, v.fy, v.cx, v.cy = ft["n"], ft["fx"], ft["fy"], ft["cx"], ft["cy"]
+                v.width, v.height = ft.get("width", 2.0 * ft["cx"]), ft.get("height", 2.0 * ft["cy"])
         stride = max_n if max_n else max([features[s]["n"] for s, _ in pairs] + [1])
         pose = np.ascontiguousarray(poses_Rt, np.float64).reshape(max(P, 0), 12)
         src = torch.empty((max(P, 1), stride), dtype=torch.int32, device=self.device)
@@ -321,7 +324,7 @@ class Engine:
         ratio = torch.empty((max(P, 1), stride), dtype=torch.float64, device=self.device)
         counts = torch.zeros(max(P, 1), dtype=torch.int32, device=self.device)
         self._bind_stream()
-        L.check(self._lib.pgi_guided_match_batch(self._ctx, va, vb, P, pose.ctypes.data_as(C.c_void_p), int(max_n), stride,
+        L.check(self._lib.pgi_guided_match_batch(self._ctx, va, vb, P, pose.ctypes.data_as(C.c_void_p), int(n_bins), int(max_n), stride,
                                                  _ptr(src), _ptr(dst), _ptr(ratio), _ptr(counts)))
         if raw:
             return src, dst, ratio, counts

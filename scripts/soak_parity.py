@@ -104,7 +104,7 @@ for q in range(n_scene):
     kk = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
     F = O.fundamental_from_essential(E, kk, kk)
     for (a_, b_), Rt in (((0, 1), np.r_[R.ravel(), t]),):
-        gi, gj, gr = eng.guided_match_batch(feats, [(a_, b_)], Rt[None], max_n=0)[0]
+        gi, gj, gr = eng.guided_match_batch(feats, [(a_, b_)], Rt[None], max_n=0, n_bins=0)[0]
         oi, oj, orr = O.guided_match(F, views[a_]["xy"], views[b_]["xy"], views[a_]["desc"], views[b_]["desc"])
         if not (np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gr, orr)):
             print("GUIDED MISMATCH at scene", q)

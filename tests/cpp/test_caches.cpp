@@ -117,6 +117,53 @@ static int workspace(const char* scene, const std::string& dir, const char* outP
         sb = cache::runWorkspace(builder, dir + "/list_with_focals.txt", dir + "/similarity.txt", dir + "/", 0.05, g, wave);
         edgesOf(g, eb);
     }
+    // (d) the reference's own call shape (examples/cpp_example.cpp:82-106), unchanged apart from the includes:
+    //     17 constructor arguments, then builder.run(reconstruction, poseGraph)
+    std::vector<double> ed;
+    int shape_ok = 0;
+    {
+        reconstruction::Reconstruction reconstruction;
+        reconstruction::PoseGraph poseGraph;
+
+        reconstruction::PoseGraphBuilder builder(
+            20,      // FLAGS_core_number
+            5000,    // FLAGS_maximum_tracklet_number
+            5,       // FLAGS_maximum_search_depth
+            100,     // FLAGS_maximum_path_number
+            20,      // FLAGS_minimum_inlier_number
+            50,      // FLAGS_minimum_point_number
+            100,     // FLAGS_maximum_points_from_epipolar_hashing
+            0.8,     // FLAGS_traversal_heuristics_weight
+            0.05,    // FLAGS_similarity_threshold
+            0.75,    // FLAGS_inlier_outlier_threshold
+            dir + "/images/",               // FLAGS_image_path
+            dir + "/",                      // FLAGS_workspace_path
+            dir + "/similarity.txt",        // FLAGS_similarity_graph_path
+            dir + "/list_with_focals.txt",  // FLAGS_focal_length_path
+            true,    // FLAGS_use_path_finding
+            true,    // FLAGS_use_gpu
+            true);   // FLAGS_use_epipolar_hashing
+
+        builder.run(reconstruction,
+            poseGraph);
+
+        edgesOf(poseGraph, ed);
+        // what initializeReconstruction leaves behind (pose_graph_builder.h:241-291) and the observability keys (:505-699)
+        const PinholeCamera cam0 = reconstruction.getCamera(0);
+        const View view0 = reconstruction.getView(0);
+        RunningStatistics& rs = builder.getStatistics();
+        shape_ok = reconstruction.getViewNumber() == V && reconstruction.getCameraIds().size() == V && poseGraph.numVertices() == V &&
+                   cam0.getIntrinsics()[0] == views[0].focalLength && cam0.getIntrinsics()[2] == views[0].width / 2.0 &&
+                   cam0.getIntrinsics()[5] == views[0].height / 2.0 && cam0.getWidth() == views[0].width &&
+                   view0.getMetadata().at("name") == "view000" && view0.getMetadata().at("extension") == "jpg" &&
+                   reconstruction.getView(V + 7).id() == UndefinedViewParameter &&
+                   rs.getCount("[Matching] Runs") == sb.matchingRuns && rs.getCount("[Quick matching] Runs") == sb.quickMatchingRuns &&
+                   rs.getCount("[Pose estimation] Runs") > 0 && rs.getCount("[Pose estimation] Inlier number") > 0 &&
+                   rs.getCount("[A*] Runs") == sb.pathsSearched && rs.getCount("[A*] Touched nodes") == sb.touchedNodes &&
+                   rs.getCount("[Epipolar Hashing] Runs") == sb.guidedMatchingRuns &&
+                   rs.getCount("[Epipolar Hashing] Correspondences added") == sb.guidedMatchesAdded &&
+                   rs.getTime("[Pose estimation]") > 0.0 && rs.getCount("[Visibility update] Runs") == sb.pairsProcessed;
+    }
     // (c) with a correspondences.h5 holding a deliberately tiny match list for the most similar pair
     {
         cache::Hdf5File co(dir + "/correspondences.h5");
@@ -134,6 +181,7 @@ static int workspace(const char* scene, const std::string& dir, const char* outP
         std::fprintf(out, "edge_with_cached_tiny_list %d\n", (int)(g.hasEdge(top_a, top_b) || g.hasEdge(top_b, top_a)));
     }
     std::fprintf(out, "edges_a %zu edges_b %zu identical %d\n", ea.size() / 15, eb.size() / 15, (int)(ea == eb));
+    std::fprintf(out, "reference_call_shape identical %d reconstruction_and_statistics %d\n", (int)(ed == eb), shape_ok);
     std::fprintf(out, "stats_a %zu %zu %zu %zu\n", sa.pairsProcessed, sa.edgesAdded, sa.matchingRuns, sa.quickMatchingRuns);
     std::fprintf(out, "stats_b %zu %zu %zu %zu\n", sb.pairsProcessed, sb.edgesAdded, sb.matchingRuns, sb.quickMatchingRuns);
     std::fprintf(out, "stats_c %zu %zu cached %zu toofew %zu\n", sc.pairsProcessed, sc.edgesAdded, sc.cachedMatchLoads, sc.tooFewMatches);

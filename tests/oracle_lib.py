@@ -275,3 +275,58 @@ def guided_match(F, kp1, kp2, d1, d2):
     m = lib().pgo_guided_match(_p(f64(F).ravel()), _p(kp1), C.c_uint32(n1), _p(kp2), C.c_uint32(n2), _p(d1), _p(d2),
                                C.c_uint32(d1.shape[1] if n1 else 128), _p(oi), _p(oj), _p(orr))
     return oi[:m], oj[:m], orr[:m]
+
+
+def ref_pose_from_essential(E, corr_aos):
+    """LITERAL pose_utils.h:172-252 (+144-169, 491-506) in the three null-vector sign conventions:
+    index 0 raw, 1 w >= 0, 2 w <= 0  ->  (R[3,3,3], t[3,3], votes[3,4], cand[3])."""
+    E = f64(E).ravel()
+    c = f64(corr_aos).reshape(-1, 4)
+    R, t = np.zeros((3, 9)), np.zeros((3, 3))
+    votes, cand = np.zeros((3, 4), np.uint32), np.zeros(3, np.uint32)
+    lib().pgo_ref_pose_from_essential(_p(E), _p(c), C.c_uint32(len(c)), _p(R), _p(t), _p(votes), _p(cand))
+    return R.reshape(3, 3, 3), t, votes, cand
+
+
+def ref_linear_triangulation(P1, P2, pt):
+    X = np.zeros(4)
+    lib().pgo_ref_linear_triangulation(_p(f64(P1).ravel()), _p(f64(P2).ravel()), _p(f64(pt).ravel()), _p(X))
+    return X
+
+
+def ref_decompose_essential(E):
+    R1, R2, t = np.zeros(9), np.zeros(9), np.zeros(3)
+    lib().pgo_ref_decompose_essential(_p(f64(E).ravel()), _p(R1), _p(R2), _p(t))
+    return R1.reshape(3, 3), R2.reshape(3, 3), t
+
+
+def candidate_agreement_batch(x1, y1, x2, y2, offsets, edges, masks, t_gt=None, threads=0):
+    """uint16 flags per pair (oracle/pgi_oracle.c: pgo_candidate_agreement_batch)."""
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    P = len(offsets) - 1
+    flags = np.zeros(P, np.uint16)
+    g = f64(t_gt).reshape(P, 3) if t_gt is not None else None
+    lib().pgo_candidate_agreement_batch(_p(x1), _p(y1), _p(x2), _p(y2), _p(offsets), C.c_uint32(P), _p(edges), _p(masks),
+                                        _p(g), _p(flags), C.c_int(threads))
+    return flags
+
+
+def ref_guided_match_binned(F, kp1, kp2, d1, d2, size_src, size_dst, n_bins=45):
+    """LITERAL matcher.h:199-405 with the epipolar bins -> (src idx, dst idx, adapted ratio, fragile[n1])."""
+    kp1, kp2, d1, d2 = f32(kp1), f32(kp2), f32(d1), f32(d2)
+    n1, n2 = len(kp1), len(kp2)
+    oi, oj, orr = np.zeros(max(n1, 1), np.uint32), np.zeros(max(n1, 1), np.uint32), np.zeros(max(n1, 1))
+    frag = np.zeros(max(n1, 1), np.uint8)
+    ss, sd = np.array(size_src, np.int32), np.array(size_dst, np.int32)
+    lib().pgo_ref_guided_match_binned.restype = C.c_uint32
+    m = lib().pgo_ref_guided_match_binned(_p(f64(F).ravel()), _p(kp1), C.c_uint32(n1), _p(kp2), C.c_uint32(n2), _p(d1), _p(d2),
+                                          C.c_uint32(d1.shape[1] if n1 else 128), _p(ss), _p(sd), C.c_int(n_bins), _p(oi), _p(oj),
+                                          _p(orr), _p(frag))
+    return oi[:m], oj[:m], orr[:m], frag[:n1]
+
+
+def model_from_essential(E):
+    """f64 E -> unit-norm f32 model exactly as K2 (pgi_score_pose_batch) prepares it."""
+    out = np.zeros(9, np.float32)
+    lib().pgo_model_from_essential(_p(f64(E).ravel()), _p(out))
+    return out

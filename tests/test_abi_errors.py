@@ -22,7 +22,7 @@ def test_null_context_is_rejected_everywhere():
         lambda: lib.pgi_desc_prepare(z, z, 0, z, z),
         lambda: lib.pgi_match_descriptors_batch(z, None, None, 1, 1, z, z, z, z),
         lambda: lib.pgi_build_correspondences(z, None, None, 1, 1, z, z, z, 0, 1.0, 0, z, z, z, z, z, z),
-        lambda: lib.pgi_guided_match_batch(z, None, None, 1, z, 0, 1, z, z, z, z),
+        lambda: lib.pgi_guided_match_batch(z, None, None, 1, z, 0, 0, 1, z, z, z, z),
         lambda: lib.pgi_get_params(z, None), lambda: lib.pgi_comm_destroy(z), lambda: lib.pgi_comm_info(z, None, None, None),
         lambda: lib.pgi_comm_init_rccl(z, 2, 0, z), lambda: lib.pgi_comm_init_host(z, 2, 0, L.ALLGATHERV_FN(0), z),
         lambda: lib.pgi_allgather_edges(z, z, z, z), lambda: lib.pgi_allgatherv(z, z, z, z),

@@ -57,5 +57,8 @@ def test_workspace_run_equals_in_memory_run(tmp_path):
     assert rows["edges_a"][0] == rows["edges_a"][2] and rows["edges_a"][4] == "1"     # same edges, bit for bit
     assert int(rows["edges_a"][0]) >= 0.95 * n
     assert rows["stats_a"] == rows["stats_b"] and int(rows["stats_a"][0]) == n and int(rows["stats_a"][3]) > 0
+    # the reference's own call shape -- PoseGraphBuilder(17 args).run(reconstruction, poseGraph) -- gives the same graph,
+    # fills the Reconstruction and emits the reference's RunningStatistics keys
+    assert rows["reference_call_shape"] == ["identical", "1", "reconstruction_and_statistics", "1"]
     # a cached two-row match list for the top pair is used instead of matching, is too short, and the pair yields no edge
     assert rows["stats_c"][3] == "1" and int(rows["stats_c"][5]) >= 1 and rows["edge_with_cached_tiny_list"] == ["0"]

@@ -85,7 +85,7 @@ def run_ranks(cmd, world, timeout=1500):
 SCENES = {
     # name: (V, k, make_scene_graph overrides, wave size)
     "v340": (340, 12, dict(median_corr=500, max_corr=3000), 512),
-    "v5000": (5000, 4, dict(median_corr=120, min_corr=60, max_corr=500), 4096),
+    "v5000": (5000, 6, dict(median_corr=100, min_corr=60, max_corr=400), 4096),  # k = 6: the ring stays connected when pairs fail
 }
 
 

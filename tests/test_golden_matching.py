@@ -42,7 +42,7 @@ def test_gpu_reproduces_matching_goldens():
             feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
             R = poses[1][0] @ poses[0][0].T
             t = poses[1][1] - R @ poses[0][1]
-            hi, hj, hr = eng.guided_match_batch(feats, [(0, 1)], np.r_[R.ravel(), t][None], max_n=0)[0]
+            hi, hj, hr = eng.guided_match_batch(feats, [(0, 1)], np.r_[R.ravel(), t][None], max_n=0, n_bins=0)[0]
             assert np.array_equal(hi, GOLD["g%d_i" % k]) and np.array_equal(hj, GOLD["g%d_j" % k]) and np.array_equal(hr, GOLD["g%d_ratio" % k])
     finally:
         eng.close()

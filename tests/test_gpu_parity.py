@@ -94,14 +94,30 @@ def test_score_pose_batch_matches_oracle(eng):
         counts, masks = counts.cpu().numpy(), masks.cpu().numpy()
         for i in range(10):
             a, z = int(b["offsets"][i]), int(b["offsets"][i + 1])
-            En = (E[i] / np.sqrt(np.sum(E[i] ** 2))).astype(np.float32)
-            # the kernel normalises E in f64 with an fma chain, then rounds to f32
-            n2 = 0.0
-            for v in E[i]:
-                n2 = float(np.float64(v) * np.float64(v) + n2)  # not bit-faithful to fma; compare masks loosely below
+            En = O.model_from_essential(E[i])  # the kernel's own normalisation: f64 fma chain, then rounded to f32
             m, c = O.mask_model(En, b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z], np.float32(tau2))
-            assert abs(int(counts[i]) - c) <= 1 and (masks[a:z] != m).sum() <= 1
+            assert int(counts[i]) == c and np.array_equal(masks[a:z], m)   # exact: mask for mask
             assert counts[i] == masks[a:z].sum()
+
+
+def test_score_pose_batch_accepts_unaligned_slices(eng):
+    """The SoA arrays may be slices of larger tensors: streams whose 16-byte phase differs between the four arrays (or a
+    mask base that is not 4-byte aligned) must take the scalar path and give the same masks as aligned inputs."""
+    import torch
+    b = S.make_batch(range(140, 146), [700, 64, 5, 1999, 130, 1024])
+    E = np.stack([O.ref_essential_from_pose(b["R"][i], b["t"][i]).ravel() for i in range(6)])
+    thr = 7.5e-4
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr)
+    ref_counts, ref_masks = eng.score_pose_batch(db, E, thr * thr)
+    rows = db["x1"].numel()
+    for shifts in ((1, 0, 0, 0), (0, 1, 2, 3), (3, 3, 3, 3), (2, 2, 1, 1)):
+        d2 = dict(db)
+        for key, sh in zip(("x1", "y1", "x2", "y2"), shifts):
+            big = torch.zeros(rows + 8, dtype=torch.float32, device=eng.device)
+            big[sh:sh + rows] = db[key]
+            d2[key] = big[sh:sh + rows]
+        counts, masks = eng.score_pose_batch(d2, E, thr * thr)
+        assert torch.equal(counts, ref_counts) and torch.equal(masks, ref_masks), shifts
 
 
 def test_score_pose_f64_is_bit_identical_to_reference_formula(eng):

@@ -68,7 +68,7 @@ def test_gpu_guided_match_bit_exact(eng, max_n):
     feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
     pairs = [(0, 1), (1, 0), (0, 2), (2, 1)]
     rt = np.array([np.r_[rel_pose(poses, s, d)[0].ravel(), rel_pose(poses, s, d)[1]] for s, d in pairs])
-    got = eng.guided_match_batch(feats, pairs, rt, max_n=max_n)
+    got = eng.guided_match_batch(feats, pairs, rt, max_n=max_n, n_bins=0)
     for (s, d), (gi, gj, gr) in zip(pairs, got):
         oi, oj, orr, _ = oracle_matches(views, poses, cam, s, d, max_n)
         assert len(oi) > (50 if max_n else 300)
@@ -86,7 +86,7 @@ def test_gpu_guided_match_degenerate_inputs(eng):
     pairs = [(0, 3), (3, 0), (0, 1), (1, 2)]
     rt = np.zeros((4, 12))
     rt[3, :9] = np.eye(3).ravel()
-    got = eng.guided_match_batch(feats, pairs, rt, max_n=0)
+    got = eng.guided_match_batch(feats, pairs, rt, max_n=0, n_bins=0)
     assert len(got[0][0]) == 0 and len(got[1][0]) == 0
     for p in (2, 3):
         s, d = pairs[p]
@@ -97,3 +97,73 @@ def test_gpu_guided_match_degenerate_inputs(eng):
         oi, oj, orr = O.guided_match(O.fundamental_from_essential(E, k, k), views[s]["xy"], views[d]["xy"],
                                      views[s]["desc"], views[d]["desc"])
         assert np.array_equal(got[p][0], oi) and np.array_equal(got[p][1], oj) and np.array_equal(got[p][2], orr)
+
+
+def oracle_matches_binned(views, poses, cam, s, d, max_n):
+    R, t = rel_pose(poses, s, d)
+    E = np.zeros(9)
+    O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+    k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+    F = O.fundamental_from_essential(E, k, k)
+    size = (int(cam[1]), int(cam[2]))
+    oi, oj, orr, frag = O.ref_guided_match_binned(F, views[s]["xy"], views[d]["xy"], views[s]["desc"], views[d]["desc"], size, size)
+    return oi, oj, orr, frag
+
+
+def test_oracle_binned_is_a_restriction_of_the_exhaustive_loop():
+    """CPU: the literal epipolar hashing (matcher.h:218-331) only REMOVES candidates from the exhaustive loop: every
+    binned match whose source point met all of its gate-passing candidates is the exhaustive match; a percent or so of
+    the matches differ (a gate-passing destination keypoint fell into a neighbouring bin)."""
+    views, poses, cam = scene(32)
+    tot = same = 0
+    for s, d in [(0, 1), (1, 0), (0, 2)]:
+        oi, oj, orr, _ = oracle_matches(views, poses, cam, s, d, 0)
+        bi, bj, br, frag = oracle_matches_binned(views, poses, cam, s, d, 0)
+        ex = dict(zip(oi.tolist(), zip(oj.tolist(), orr.tolist())))
+        bn = dict(zip(bi.tolist(), zip(bj.tolist(), br.tolist())))
+        tot += len(ex)
+        same += sum(1 for k in ex if bn.get(k) == ex[k])
+        assert len(bn) > 0.95 * len(ex) and frag.sum() == 0
+    assert 0.95 < same / tot < 1.0   # close, but NOT identical: hence the binned mode on the device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_n", [0, 100])
+def test_gpu_guided_match_binned_equals_literal_restatement(eng, max_n):
+    """pgi_guided_match_batch(n_bins = 45) == pgo_ref_guided_match_binned (the reference's epipolar hashing, restated
+    literally with libm atan2 / round) for every source keypoint outside the don't-care band: a source point is
+    'fragile' when its own bin, or the bin of a destination keypoint passing its gate, lies within 1e-7 of a rounding
+    boundary -- there the device's atan2 may legitimately round the other way.  Also reports how many matches differ
+    from the exhaustive kernel."""
+    differ = total = 0
+    for seed in (32, 34):
+        views, poses, cam = scene(seed)
+        feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+        pairs = [(0, 1), (1, 0), (0, 2), (2, 1)]
+        rt = np.array([np.r_[rel_pose(poses, s, d)[0].ravel(), rel_pose(poses, s, d)[1]] for s, d in pairs])
+        got = eng.guided_match_batch(feats, pairs, rt, max_n=max_n, n_bins=45)
+        exh = eng.guided_match_batch(feats, pairs, rt, max_n=0, n_bins=0)
+        for (s, d), (gi, gj, gr), (xi, xj, xr) in zip(pairs, got, exh):
+            oi, oj, orr, frag = oracle_matches_binned(views, poses, cam, s, d, 0)
+            assert len(oi) > 300
+            if frag.any():   # compare only the rows outside the don't-care band
+                keep_o = ~frag[oi].astype(bool)
+                oi, oj, orr = oi[keep_o], oj[keep_o], orr[keep_o]
+            if max_n and len(oi) > max_n:
+                order = np.lexsort((np.arange(len(oi)), orr))[:max_n]
+                oi, oj, orr = oi[order], oj[order], orr[order]
+            if frag.any():
+                keep_g = ~frag[gi].astype(bool)
+                gi, gj, gr = gi[keep_g], gj[keep_g], gr[keep_g]
+                if max_n:      # the cut may have been taken over a slightly different set: compare the common prefix
+                    n = min(len(gi), len(oi)) - int(frag.sum())
+                    gi, gj, gr, oi, oj, orr = gi[:n], gj[:n], gr[:n], oi[:n], oj[:n], orr[:n]
+            assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gr, orr), (seed, s, d)
+            if not max_n:
+                ex = dict(zip(xi.tolist(), zip(xj.tolist(), xr.tolist())))
+                bn = dict(zip(gi.tolist(), zip(gj.tolist(), gr.tolist())))
+                total += len(ex)
+                differ += sum(1 for k in ex if bn.get(k) != ex[k])
+    if not max_n:
+        print("binned vs exhaustive kernel: %d of %d matches differ (%.2f %%)" % (differ, total, 100.0 * differ / max(total, 1)))
+        assert 0 < differ < 0.05 * total

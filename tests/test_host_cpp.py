@@ -30,6 +30,26 @@ def test_host_library_exports_and_header_symbols():
         assert b"no HIP device" in lib.pgi_last_error()
 
 
+def test_reference_adapter_header_preprocesses(tmp_path):
+    """CPU: include/pgi_reference_adapter.h is a real header; without OpenCV / Eigen / Sophus on the image
+    it must compile to nothing and say so, in C++17 and as plain C (it includes pgi.h)."""
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "probe.cpp"
+    src.write_text('#include "pgi_reference_adapter.h"\n#include <cstdio>\nint main() { std::printf("%d %d\\n", '
+                   'PGI_REFERENCE_ADAPTER_AVAILABLE, PGI_VERSION); return 0; }\n')
+    exe = tmp_path / "probe"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], check=True, timeout=120)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=30).stdout.split()
+    have = all(os.path.exists(p) for p in ("/usr/include/opencv4/opencv2/core.hpp", "/usr/include/eigen3/Eigen/Core"))
+    assert out[1] == "2" and (out[0] == "0" or have)
+    csrc = tmp_path / "probe.c"
+    csrc.write_text('#include "pgi_reference_adapter.h"\nint main(void) { return PGI_REFERENCE_ADAPTER_AVAILABLE; }\n')
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", inc, str(csrc), "-o", str(tmp_path / "probe_c")], check=True, timeout=120)
+    text = open(os.path.join(inc, "pgi_reference_adapter.h")).read()
+    for cite in ("pose_graph_builder.h:940-1078", "graph_traversal.h:136-168", "graph_traversal.h:194-233", "pgi_estimate_pose("):
+        assert cite in text
+
+
 @pytest.mark.gpu
 def test_cpp_host_api(tmp_path):
     sizes = [400, 800, 120, 1500, 60, 300]
