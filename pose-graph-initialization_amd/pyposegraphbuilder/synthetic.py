@@ -143,8 +143,10 @@ def make_pair_from_pose(pair_id, n, R, t, inlier_ratio=0.5, noise_px=0.25, seed_
 
 
 def make_scene_graph(n_views, k=8, seed=0, median_corr=600, min_corr=60, max_corr=4000, inlier_lo=0.35,
-                     inlier_hi=0.8, outlier_pair_frac=0.05):
-    """Cameras on a jittered ring looking at the scene centre; candidate pairs = k nearest views.
+                     inlier_hi=0.8, outlier_pair_frac=0.05, ring=0):
+    """Cameras on a jittered ring looking at the scene centre; candidate pairs = k nearest views (+ with ring = r the
+    pairs (i, i+1) ... (i, i+r) along the ring: nearest-neighbour sets alone leave gaps between clusters of views, which
+    disconnects large graphs).
 
     Returns dict(R_gt[V,3,3] world->camera, pairs=(src,dst)[E,2], sizes[E], batch=<make_batch-like SoA>,
     wrong[E] bool (pairs whose correspondences are all outliers: a wrongly retrieved image pair))."""
@@ -165,6 +167,11 @@ def make_scene_graph(n_views, k=8, seed=0, median_corr=600, min_corr=60, max_cor
         d = np.abs(np.angle(np.exp(1j * (ang - ang[i]))))
         for j in np.argsort(d)[1:k + 1]:
             pairs.add((min(i, int(j)), max(i, int(j))))
+    for r in range(1, ring + 1):
+        for i in range(n_views):
+            j = (i + r) % n_views
+            if i != j:
+                pairs.add((min(i, j), max(i, j)))
     pairs = np.array(sorted(pairs), np.int64)
     E = len(pairs)
     sizes = np.clip(rng.lognormal(np.log(median_corr), 0.6, E), min_corr, max_corr).astype(np.int64)
