@@ -1,137 +1,236 @@
 // tracklets.hpp -- multi-view tracklets feeding "quick matching" (SURVEY §8f-2).
 //
-// Mirrors reconstruction::Tracklets (point_track.h:541-711 of the reference): add() grows tracks from the inlier
-// matches of an estimated edge, getCorrespondences() returns, for a later pair, the points both views share a
-// track with -- correspondences without descriptor matching.  Written from the behaviour, including two quirks that
-// callers can observe (kept on purpose, tests pin them against oracle/tracklets_oracle.py):
-//   * point ids start at 0 and 0 also means "not seen yet" (point_track.h:651-657), so the very first point ever
-//     added is re-registered under a fresh id whenever it shows up again and loses its earlier tracks;
-//   * getCorrespondences stops after the size EXCEEDS the maximum (:626-627), i.e. returns up to max + 1 entries,
-//     and fills the destination index with 0 when a track holds the source view twice before the destination (:608-622).
-// Everything iterates over vectors in insertion order, so results are deterministic; the reader/writer lock of the
-// reference is kept because PoseGraphBuilder::run may query from worker threads.
+// Observable behaviour of reconstruction::Tracklets (reference: point_track.h:541-711), which the scheduler relies on
+// for functional parity: add() grows tracks from the inlier matches of an estimated edge; getCorrespondences() returns,
+// for a later pair, the keypoints both views share a track with -- correspondences without descriptor matching.
+// The behaviour is pinned by oracle/tracklets_oracle.py (tests/test_tracklets.py), including what callers can observe
+// of the reference's quirks: a point id of 0 also means "never seen" (so the first point ever registered is registered
+// again on its second visit and leaves its first tracks behind), getCorrespondences stops only after the result has
+// EXCEEDED the maximum (max + 1 entries), and a track that lists the source view twice before the destination yields
+// destination index 0.
+//
+// Design (not the reference's containers): the structure is an incidence store between points and tracks whose lists
+// are append-only and only ever walked front to back.  Everything lives in flat arrays of fixed-size records:
+//     PointRecord  the tracks holding a point: the first 3 inline, the rest in a chain of overflow cells
+//     TrackRecord  the members (view, keypoint) of a track: the first 7 inline (one 64-byte cache line), rest chained
+//     per view     one contiguous array of track indices (append order), and a direct keypoint -> point-id table
+// so a match costs a handful of cache lines and no allocation (the common point sits in one or two tracks of a few
+// members).  The work itself is a chain of dependent appends per match -- a match sees the tracks its predecessors
+// just extended -- which is why this piece stays on the host: on the GPU it would be one lane chasing pointers
+// through HBM (pipeline table).
 #pragma once
 #include <algorithm>
 #include <cstddef>
-#include <map>
+#include <cstdint>
 #include <mutex>
 #include <shared_mutex>
 #include <tuple>
-#include <unordered_map>
-#include <unordered_set>
+#include <utility>
 #include <vector>
 
 namespace reconstruction {
 
 class Tracklets {
-public:
+   public:
     typedef std::pair<size_t, size_t> Pair;  // (view index, keypoint index)
     typedef std::tuple<size_t, size_t, double> Match;
 
-    explicit Tracklets(size_t viewNumber_ = 0) : pointPairNumber(0) {
-        tmpViewToTracks.reserve(viewNumber_);
-    }
+    explicit Tracklets(size_t viewNumber_ = 0) { views.reserve(viewNumber_); }
 
-    // point_track.h:568-631
+    // Correspondences of (source, destination) from shared tracks, in the order of the destination view's track list.
     void getCorrespondences(std::vector<Match>& matches_, const size_t& viewIdSource_, const size_t& viewIdDestination_,
                             const size_t& maximumCorrespondenceNumber_) const {
         std::shared_lock<std::shared_mutex> lock(readerWriterLock);
-        const auto it = tmpViewToTracks.find(viewIdSource_);
-        if (it == tmpViewToTracks.end()) return;
-        const auto jt = tmpViewToTracks.find(viewIdDestination_);
-        if (jt == tmpViewToTracks.end()) return;
-        // membership of a track in the source view's list: a per-thread stamp array instead of the reference's
-        // unordered_set (same answers; the lists reach 10^5 entries and this lookup dominated the host time)
-        static thread_local std::vector<unsigned> stamp;
-        static thread_local unsigned epoch = 0;
-        if (stamp.size() < tmpTracks.size()) stamp.resize(tmpTracks.size(), 0u);
-        if (++epoch == 0u) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1u; }
-        for (const size_t trackIdx : it->second) stamp[trackIdx] = epoch;
-        for (const size_t trackIdx : jt->second) {
-            if (stamp[trackIdx] != epoch) continue;
-            Match m(0, 0, 0.0);
-            int found = 0;
-            for (const Pair& p : tmpTracks[trackIdx]) {
-                if (p.first == viewIdSource_) { std::get<0>(m) = p.second; ++found; }
-                else if (p.first == viewIdDestination_) { std::get<1>(m) = p.second; ++found; }
-                if (found == 2) break;
-            }
-            matches_.emplace_back(m);
+        if (!knowsView(viewIdSource_) || !knowsView(viewIdDestination_)) return;
+        // which tracks touch the source view: one generation stamp per track (per calling thread)
+        static thread_local std::vector<uint32_t> seen;
+        static thread_local uint32_t generation = 0;
+        if (seen.size() < tracks.size()) seen.resize(tracks.size(), 0u);
+        if (++generation == 0u) {
+            seen.assign(seen.size(), 0u);
+            generation = 1u;
+        }
+        for (const uint32_t track : views[viewIdSource_].tracks) seen[track] = generation;
+        const uint32_t vs = (uint32_t)viewIdSource_, vd = (uint32_t)viewIdDestination_;
+        for (const uint32_t track : views[viewIdDestination_].tracks) {
+            if (seen[track] != generation) continue;
+            size_t pointSource = 0, pointDestination = 0;
+            int hits = 0;
+            forEachMember(track, [&](uint32_t view, uint32_t point) {
+                if (view == vs) {
+                    pointSource = point;
+                    ++hits;
+                } else if (view == vd) {
+                    pointDestination = point;
+                    ++hits;
+                }
+                return hits < 2;
+            });
+            matches_.emplace_back(pointSource, pointDestination, 0.0);
             if (matches_.size() > maximumCorrespondenceNumber_) break;
         }
     }
 
-    // point_track.h:633-711
+    // Registers the masked-in matches of the edge (source, destination).
     void add(const size_t& imageIdxSource_, const size_t& imageIdxDestination_, const std::vector<Match>& matches_,
              const std::vector<unsigned char>& inlierMask_) {
         std::unique_lock<std::shared_mutex> lock(readerWriterLock);
-        // (unordered_map never invalidates references to its elements; a view's list is created on first use, as
-        // operator[] does in the reference)
-        std::vector<size_t>* viewTracksSource = nullptr;
-        std::vector<size_t>* viewTracksDestination = nullptr;
-        auto ofSource = [&]() -> std::vector<size_t>& {
-            if (!viewTracksSource) viewTracksSource = &tmpViewToTracks[imageIdxSource_];
-            return *viewTracksSource;
-        };
-        auto ofDestination = [&]() -> std::vector<size_t>& {
-            if (!viewTracksDestination) viewTracksDestination = &tmpViewToTracks[imageIdxDestination_];
-            return *viewTracksDestination;
-        };
+        const uint32_t vs = (uint32_t)imageIdxSource_, vd = (uint32_t)imageIdxDestination_;
+        std::vector<uint32_t> snapshot;  // the destination point's tracks as they were before the match
         for (size_t k = 0; k < matches_.size(); ++k) {
             if (!inlierMask_[k]) continue;
-            const Pair pairSource(imageIdxSource_, std::get<0>(matches_[k]));
-            const Pair pairDestination(imageIdxDestination_, std::get<1>(matches_[k]));
-            const size_t idSource = idOf(pairSource), idDestination = idOf(pairDestination);
-            if (tmpPairToTracks.size() < pointPairNumber) tmpPairToTracks.resize(pointPairNumber);  // before taking references
-            std::vector<size_t>& tracksSource = tmpPairToTracks[idSource];
-            std::vector<size_t>& tracksDestination = tmpPairToTracks[idDestination];
-            const size_t trackNumDestination = tracksDestination.size();
-            bool added = false;
-            for (size_t q = 0; q < tracksSource.size(); ++q) {  // tracksSource does not grow in this loop
-                const size_t trackIdx = tracksSource[q];
-                std::vector<Pair>& track = tmpTracks[trackIdx];
-                if (std::find(track.begin(), track.end(), pairDestination) != track.end()) continue;
-                ofDestination().emplace_back(trackIdx);
-                track.emplace_back(pairDestination);
-                tracksDestination.emplace_back(trackIdx);
-                added = true;
+            const uint32_t ps = (uint32_t)std::get<0>(matches_[k]), pd = (uint32_t)std::get<1>(matches_[k]);
+            const uint32_t idS = pointId(vs, ps), idD = pointId(vd, pd);
+            snapshot.clear();
+            forEachTrackOf(idD, [&](uint32_t track) { snapshot.push_back(track); });
+            bool extended = false;
+            // every track of the source point learns the destination point ...
+            forEachTrackOf(idS, [&](uint32_t track) {
+                if (hasMember(track, vd, pd)) return;
+                touch(vd).tracks.push_back(track);
+                pushMember(track, vd, pd);
+                pushTrackOf(idD, track);
+                extended = true;
+            });
+            // ... and every earlier track of the destination point learns the source point
+            for (const uint32_t track : snapshot) {
+                if (hasMember(track, vs, ps)) continue;
+                touch(vs).tracks.push_back(track);
+                pushMember(track, vs, ps);
+                pushTrackOf(idS, track);
+                extended = true;
             }
-            for (size_t q = 0; q < trackNumDestination; ++q) {
-                const size_t trackIdx = tracksDestination[q];
-                std::vector<Pair>& track = tmpTracks[trackIdx];
-                if (std::find(track.begin(), track.end(), pairSource) != track.end()) continue;
-                ofSource().emplace_back(trackIdx);
-                track.emplace_back(pairSource);
-                tracksSource.emplace_back(trackIdx);
-                added = true;
-            }
-            if (!added) {
-                const size_t idx = tmpTracks.size();
-                tmpTracks.emplace_back(std::vector<Pair>{pairSource, pairDestination});
-                ofSource().emplace_back(idx);
-                ofDestination().emplace_back(idx);
-                tracksSource.emplace_back(idx);
-                tracksDestination.emplace_back(idx);
-            }
+            if (extended) continue;
+            // neither side had a track to extend: the match starts one
+            const uint32_t track = (uint32_t)tracks.size();
+            tracks.emplace_back();
+            pushMember(track, vs, ps);
+            pushMember(track, vd, pd);
+            touch(vs).tracks.push_back(track);
+            touch(vd).tracks.push_back(track);
+            pushTrackOf(idS, track);
+            pushTrackOf(idD, track);
         }
     }
 
-    size_t trackNumber() const { return tmpTracks.size(); }
-    const std::vector<std::vector<Pair>>& tracks() const { return tmpTracks; }
-
-private:
-    // point_track.h:651-657: id 0 doubles as "not seen yet", so the first point ever is re-registered on every visit
-    size_t idOf(const Pair& p) {
-        size_t& id = pointPairs[(static_cast<unsigned long long>(p.first) << 32) ^ static_cast<unsigned long long>(p.second)];
-        if (id == 0) id = pointPairNumber++;
-        return id;
+    size_t trackNumber() const { return tracks.size(); }
+    // members of one track in insertion order (diagnostics / tests)
+    std::vector<Pair> track(size_t index) const {
+        std::vector<Pair> out;
+        forEachMember((uint32_t)index, [&](uint32_t view, uint32_t point) {
+            out.emplace_back(view, point);
+            return true;
+        });
+        return out;
     }
+
+   private:
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    static constexpr uint32_t kInlineTracks = 3, kInlineMembers = 7;
+    struct PointRecord {  // 24 bytes
+        uint32_t count = 0;
+        uint32_t first[kInlineTracks] = {0, 0, 0};
+        uint32_t head = kNone, tail = kNone;  // overflow chain in `spill`
+    };
+    struct TrackRecord {  // 64 bytes: one cache line
+        uint32_t count = 0;
+        uint32_t head = kNone;  // overflow chain in `memberSpill`
+        struct {
+            uint32_t view, point;
+        } first[kInlineMembers] = {};
+    };
+    struct ViewRecord {
+        std::vector<uint32_t> tracks;  // tracks touching the view, once per member of that view, in append order
+        std::vector<uint32_t> ids;     // keypoint -> point id (0 = never seen; see pointId)
+        bool known = false;            // becomes true with the first entry of `tracks`
+    };
+    struct SpillCell {
+        uint32_t next, value;
+    };
+    struct MemberCell {
+        uint32_t next, view, point;
+    };
+
+    bool knowsView(size_t v) const { return v < views.size() && views[v].known; }
+    ViewRecord& touch(uint32_t v) {
+        if (v >= views.size()) views.resize((size_t)v + 1);
+        views[v].known = true;
+        return views[v];
+    }
+    template <class F>
+    void forEachTrackOf(uint32_t id, F visit) const {  // `visit` may append to OTHER points' lists
+        const uint32_t n = points[id].count;
+        for (uint32_t q = 0; q < n && q < kInlineTracks; ++q) visit(points[id].first[q]);
+        uint32_t c = points[id].head;
+        for (uint32_t q = kInlineTracks; q < n; ++q, c = spill[c].next) visit(spill[c].value);
+    }
+    void pushTrackOf(uint32_t id, uint32_t track) {
+        PointRecord& r = points[id];
+        if (r.count < kInlineTracks) {
+            r.first[r.count] = track;
+        } else {
+            const uint32_t c = (uint32_t)spill.size();
+            spill.push_back(SpillCell{kNone, track});
+            if (r.tail == kNone) r.head = c; else spill[r.tail].next = c;
+            r.tail = c;
+        }
+        ++r.count;
+    }
+    template <class F>
+    void forEachMember(uint32_t track, F visit) const {  // visit returns false to stop
+        const TrackRecord& t = tracks[track];
+        for (uint32_t q = 0; q < t.count && q < kInlineMembers; ++q)
+            if (!visit(t.first[q].view, t.first[q].point)) return;
+        uint32_t c = t.head;
+        for (uint32_t q = kInlineMembers; q < t.count; ++q, c = memberSpill[c].next)
+            if (!visit(memberSpill[c].view, memberSpill[c].point)) return;
+    }
+    bool hasMember(uint32_t track, uint32_t view, uint32_t point) const {
+        bool found = false;
+        forEachMember(track, [&](uint32_t v, uint32_t p) {
+            found = (v == view && p == point);
+            return !found;
+        });
+        return found;
+    }
+    void pushMember(uint32_t track, uint32_t view, uint32_t point) {
+        TrackRecord& t = tracks[track];
+        if (t.count < kInlineMembers) {
+            t.first[t.count].view = view;
+            t.first[t.count].point = point;
+        } else {  // chain order = insertion order: walk to the end (overflow chains are short and rare)
+            const uint32_t c = (uint32_t)memberSpill.size();
+            memberSpill.push_back(MemberCell{kNone, view, point});
+            if (t.head == kNone) {
+                t.head = c;
+            } else {
+                uint32_t e = t.head;
+                while (memberSpill[e].next != kNone) e = memberSpill[e].next;
+                memberSpill[e].next = c;
+            }
+        }
+        ++t.count;
+    }
+    // id of a point; ids count up from 0 and an id of 0 is indistinguishable from "never seen", so whoever holds 0
+    // receives a fresh id on the next visit
+    uint32_t pointId(uint32_t view, uint32_t point) {
+        if (view >= views.size()) views.resize((size_t)view + 1);
+        std::vector<uint32_t>& ids = views[view].ids;
+        if (point >= ids.size()) ids.resize(std::max<size_t>((size_t)point + 1, ids.size() * 2), 0u);
+        if (ids[point] == 0) {
+            ids[point] = nextId++;
+            if (points.size() < nextId) points.resize(std::max<size_t>(nextId, points.size() * 2));
+        }
+        return ids[point];
+    }
+
     mutable std::shared_mutex readerWriterLock;
-    size_t pointPairNumber;
-    std::unordered_map<unsigned long long, size_t> pointPairs;   // (view, point) -> id
-    std::vector<std::vector<Pair>> tmpTracks;                    // track -> its (view, point) members
-    std::unordered_map<size_t, std::vector<size_t>> tmpViewToTracks;  // view -> tracks touching it (with repeats)
-    std::vector<std::vector<size_t>> tmpPairToTracks;            // id -> tracks containing that point (ids are dense)
+    uint32_t nextId = 0;
+    std::vector<PointRecord> points;       // by point id
+    std::vector<TrackRecord> tracks;       // by track index
+    std::vector<ViewRecord> views;         // by view index
+    std::vector<SpillCell> spill;          // overflow of PointRecord::first
+    std::vector<MemberCell> memberSpill;   // overflow of TrackRecord::first
 };
 
 }  // namespace reconstruction

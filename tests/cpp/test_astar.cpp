@@ -1,5 +1,6 @@
 // Host-only test driver for host/graph_traversal.hpp: reads a pose graph + similarity matrix + queries,
 // writes path, chained pose and touched-node count per query (compared with oracle/astar_oracle.py).
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 
@@ -75,6 +76,30 @@ static int tracklets(char** argv) {
     return 0;
 }
 
+// mode "trackbench": <views> <points per view> <pairs>: nanoseconds per registered match of Tracklets::add on a
+// consistent scene (keypoint p of every view sees 3-D point p): the host-side cost processFeatures pays per inlier
+static int trackbench(char** argv) {
+    const size_t V = (size_t)std::atoi(argv[2]), K = (size_t)std::atoi(argv[3]), pairs = (size_t)std::atoi(argv[4]);
+    Tracklets tr(V);
+    std::vector<Tracklets::Match> matches(K);
+    std::vector<unsigned char> mask(K, 1);
+    size_t total = 0, got = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t e = 0; e < pairs; ++e) {
+        const size_t s = (e * 7) % V, d = (s + 1 + (e * 13) % (V - 1)) % V;
+        for (size_t k = 0; k < K; ++k) matches[k] = Tracklets::Match((k * 31 + e) % K, (k * 31 + e) % K, 0.0);
+        tr.add(s, d, matches, mask);
+        total += K;
+        std::vector<Tracklets::Match> q;
+        tr.getCorrespondences(q, d, (s + 2) % V, 5000);
+        got += q.size();
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("trackbench: %zu matches in %.3f s = %.1f ns per match; %zu tracks, %zu correspondences returned\n", total, sec,
+                1e9 * sec / (double)total, tr.trackNumber(), got);
+    return 0;
+}
+
 // mode "hostcomm": <out prefix>; RANK / WORLD_SIZE / MASTER_* from the environment.  Exercises the TCP star that
 // bootstraps the multi-GPU path (host/distributed.hpp): broadcast, uneven all-gather-v, fixed-size all-gather, barrier.
 static int hostcomm(char** argv) {
@@ -125,6 +150,7 @@ int main(int argc, char** argv) {
         }
     }
     if (argc >= 5 && std::string(argv[1]) == "shards") return shards(argv);
+    if (argc >= 5 && std::string(argv[1]) == "trackbench") return trackbench(argv);
     if (argc < 3) return 2;
     std::ifstream in(argv[1], std::ios::binary);
     uint32_t V, E, Q;

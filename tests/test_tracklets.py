@@ -74,3 +74,25 @@ def test_tracklets_random_sequences_match_oracle(tmp_path):
             else:
                 cmds.append(("get", int(s), int(d), int(rng.integers(0, 30))))
         assert run_cpp(cmds, str(tmp_path)) == run_oracle(cmds), trial
+
+
+def test_tracklets_dense_sequences_with_repeated_points(tmp_path):
+    """Harder mixes: many-to-one matches inside one add() (guided matching returns the best destination per source, so
+    destination keypoints repeat), the first-ever point coming back (id 0 == "unseen"), queries between every add."""
+    rng = np.random.default_rng(23)
+    for trial in range(4):
+        cmds = []
+        views, pts = 12, 60
+        for step in range(150):
+            s, d = (int(v) for v in rng.choice(views, 2, replace=False))
+            m = int(rng.integers(1, 40))
+            src_pts = rng.permutation(pts)[:m]
+            dst_pts = rng.integers(0, pts // (1 + trial), m)          # repeats, heavier in later trials
+            matches = [(int(a), int(b)) for a, b in zip(src_pts, dst_pts)]
+            if step % 17 == 3 and cmds:
+                first = next(c for c in cmds if c[0] == "add" and len(c[3]))
+                matches.insert(0, first[3][0]) if (s, d) == (first[1], first[2]) else None
+            cmds.append(("add", s, d, matches, [int(v) for v in rng.random(len(matches)) < 0.9]))
+            a, b = (int(v) for v in rng.choice(views, 2, replace=False))
+            cmds.append(("get", a, b, int(rng.integers(0, 200))))
+        assert run_cpp(cmds, str(tmp_path)) == run_oracle(cmds), trial
