@@ -116,12 +116,20 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_ed
                             uint8_t* d_masks);
 
 /* Host buffers in, host buffers out (synchronous).  Same result as pgi_estimate_pose_batch on the same rows, ids and
- * seed; internally the batch travels in chunks through two device slots on two streams, so PCIe copies overlap the
- * kernels.  h_guess_Rt / h_has_guess may both be NULL.  h_masks: one byte per row. */
+ * seed; internally the batch travels in chunks (a small first one, then multiples of the number of workgroups the
+ * device keeps resident) through three device slots on three streams, so PCIe copies overlap the kernels and the
+ * tail of one chunk's kernel overlaps the head of the next.  h_guess_Rt / h_has_guess may both be NULL.
+ * h_masks: one byte per row.  Fastest with page-locked buffers (pgi_host_register). */
 int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h_y1, const float* h_x2,
                                  const float* h_y2, const uint64_t* h_offsets, const double* h_thr,
                                  const double* h_guess_Rt, const uint8_t* h_has_guess, uint32_t n_pairs,
                                  uint64_t pair_id_base, uint64_t seed, pgi_edge* h_edges, uint8_t* h_masks);
+
+/* Page-locks a caller-owned host buffer (hipHostRegister) so that the host-pointer entry points move it by true
+ * asynchronous DMA at PCIe rate instead of through the runtime's pageable staging path; buffers that are not
+ * registered keep working, slower.  Register once, reuse across calls; unregister before freeing the memory. */
+int pgi_host_register(void* h_ptr, uint64_t bytes);
+int pgi_host_unregister(void* h_ptr);
 
 /* ---- estimatePose, literal drop-in (host pointers, synchronous, re-entrant)
  * corr_aos: n x 4 doubles [x1 y1 x2 y2] == cv::Mat N x 4 CV_64F (:946);

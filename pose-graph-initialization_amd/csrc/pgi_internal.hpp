@@ -53,7 +53,8 @@ struct pgi_ctx {
         uint32_t* d_bucket = nullptr;
         size_t bucket_bytes = 0;
         hipStream_t stream = nullptr;
-    } hslot[2];
+    } hslot[3];
+    int resident_wgs = 768;  // workgroups of K1 the device keeps resident (CUs x 3): the chunk quantum of the host path
     void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
     size_t match_ws_bytes = 0;
     uint32_t* d_match_cnt = nullptr;  // per-pair flagged-row counters of the last screened match (forward, then backward)

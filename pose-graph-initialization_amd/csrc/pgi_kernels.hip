@@ -1137,6 +1137,9 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     int lds = 0;
     (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     c->max_lds = lds > 0 ? lds : 65536;
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (cus > 0) c->resident_wgs = 3 * cus;
     // K1 may use the whole LDS of a CU for staged rows
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
@@ -1156,7 +1159,7 @@ void pgi_destroy(pgi_ctx* ctx) {
     }
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
         if (ctx->hslot[k].stream) (void)hipStreamDestroy(ctx->hslot[k].stream);
@@ -1300,14 +1303,16 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     const bool guesses = h_guess_Rt != nullptr;
-    // chunks of ~2.5 M rows (at least 256 pairs): big enough to fill the chip, small enough to pipeline
-    const uint64_t rows_total = h_offsets[n_pairs] - h_offsets[0];
-    const uint64_t target = std::max<uint64_t>(2500000ull, rows_total / 64 + 1);
+    // Chunks: a small first one (the pipeline starts after one short copy), then multiples of the number of resident
+    // workgroups so that no chunk ends in a mostly empty last wave of workgroups; huge pairs cap a chunk at ~8 M rows.
+    const uint32_t quantum = (uint32_t)std::max(64, ctx->resident_wgs);
     std::vector<uint32_t> cuts(1, 0u);
     for (uint32_t p = 0; p < n_pairs;) {
+        const uint32_t want = cuts.size() == 1 ? quantum : 3u * quantum;
         uint32_t q = p;
         const uint64_t r0 = h_offsets[p];
-        while (q < n_pairs && (q - p < 256u || h_offsets[q + 1] - r0 <= target)) ++q;
+        while (q < n_pairs && q - p < want && (q == p || h_offsets[q + 1] - r0 <= 8000000ull)) ++q;
+        if (n_pairs - q < quantum / 2) q = n_pairs;  // no tiny last chunk
         cuts.push_back(q);
         p = q;
     }
@@ -1324,26 +1329,27 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         L.total = o;
         return L;
     };
-    for (int k = 0; k < 2; ++k)
+    constexpr size_t kSlots = 3;
+    for (size_t k = 0; k < kSlots; ++k)
         if (!ctx->hslot[k].stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->hslot[k].stream, hipStreamNonBlocking));
-    std::vector<uint64_t> off_local[2];
-    Lay lay[2];
+    std::vector<uint64_t> off_local[kSlots];
+    Lay lay[kSlots];
     auto drain = [&](size_t c) -> int {  // results of chunk c back to the host (blocks until its kernel is done)
-        pgi_ctx::HostSlot& S = ctx->hslot[c & 1];
+        pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t r0 = h_offsets[p0] - h_offsets[0], rows = h_offsets[p0 + np] - h_offsets[p0];
         char* d = (char*)S.d;
-        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + lay[c & 1].edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, S.stream));
-        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + lay[c & 1].masks, rows, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + lay[c % kSlots].edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, S.stream));
+        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + lay[c % kSlots].masks, rows, hipMemcpyDeviceToHost, S.stream));
         HIP_TRY(hipStreamSynchronize(S.stream));
         return PGI_SUCCESS;
     };
     for (size_t c = 0; c < n_chunks; ++c) {
-        pgi_ctx::HostSlot& S = ctx->hslot[c & 1];
+        pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t rbase = h_offsets[p0], rows = h_offsets[p0 + np] - rbase, r0 = rbase - h_offsets[0];
         const Lay L = layout(rows, np);
-        lay[c & 1] = L;
+        lay[c % kSlots] = L;
         if (L.total > S.bytes) {
             if (S.d) (void)hipFree(S.d);
             S.d = nullptr; S.bytes = 0;
@@ -1351,7 +1357,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             S.bytes = L.total + L.total / 4;
         }
         char* d = (char*)S.d;
-        std::vector<uint64_t>& ol = off_local[c & 1];
+        std::vector<uint64_t>& ol = off_local[c % kSlots];
         ol.resize((size_t)np + 1);
         uint32_t max_corr = 0;
         for (uint32_t k = 0; k <= np; ++k) ol[k] = h_offsets[p0 + k] - rbase;
@@ -1376,10 +1382,14 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
         const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
         if (rc < 0) return rc;
-        // results of the previous chunk come back while this chunk's kernel runs; its slot is free again afterwards
-        if (c >= 1) { const int rc2 = drain(c - 1); if (rc2 < 0) return rc2; }
+        // results come back two chunks behind the launch front: that chunk's slot is the one the next chunk reuses
+        if (c + 1 >= kSlots) { const int rc2 = drain(c + 1 - kSlots); if (rc2 < 0) return rc2; }
     }
-    return drain(n_chunks - 1);
+    for (size_t c = n_chunks >= kSlots - 1 ? n_chunks - (kSlots - 1) : 0; c < n_chunks; ++c) {
+        const int rc2 = drain(c);
+        if (rc2 < 0) return rc2;
+    }
+    return PGI_SUCCESS;
 }
 
 
@@ -1475,6 +1485,18 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
     memcpy(h_edge, h + o_edge, sizeof(pgi_edge));
     if (n) memcpy(h_mask, h + o_mask, n);
     return h_edge->status == PGI_EDGE_OK ? 1 : 0;
+}
+
+int pgi_host_register(void* h_ptr, uint64_t bytes) {
+    if (!h_ptr || !bytes) return fail(PGI_ERR_INVALID, "null argument");
+    HIP_TRY(hipHostRegister(h_ptr, (size_t)bytes, hipHostRegisterDefault));
+    return PGI_SUCCESS;
+}
+
+int pgi_host_unregister(void* h_ptr) {
+    if (!h_ptr) return fail(PGI_ERR_INVALID, "null argument");
+    HIP_TRY(hipHostUnregister(h_ptr));
+    return PGI_SUCCESS;
 }
 
 int pgi_score_pose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, const double* d_tau2,

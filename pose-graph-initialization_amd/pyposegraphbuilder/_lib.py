@@ -53,7 +53,7 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
            "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch",
            "pgi_get_params", "pgi_rotation_average_edges", "pgi_comm_unique_id", "pgi_comm_init_rccl", "pgi_comm_init_host",
-           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv"]
+           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv", "pgi_host_register", "pgi_host_unregister"]
 COMM_ID_BYTES = 128
 # pgi_allgatherv_fn: int (*)(void* user, const void* send, uint64 send_bytes, void* recv, const uint64* recv_bytes, uint32 world)
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
@@ -116,6 +116,8 @@ def load():
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]
     lib.pgi_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.pgi_host_register.argtypes = [C.c_void_p, C.c_uint64]
+    lib.pgi_host_unregister.argtypes = [C.c_void_p]
     lib.pgi_rotation_average_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.POINTER(RotAvgParams), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_comm_unique_id.argtypes = [C.c_void_p]

@@ -89,8 +89,10 @@ class Engine:
         L.check(self._lib.pgi_estimate_pose_batch(self._ctx, C.byref(s), _ptr(edges), _ptr(masks)))
         return edges, masks[:rows]
 
-    def estimate_pose_batch_host(self, x1, y1, x2, y2, offsets, thr, guesses=None, has_guess=None, seed=0, pair_id_base=0):
-        """Host (numpy) SoA in, (edges structured array, masks) out; copies are pipelined against the kernels."""
+    def estimate_pose_batch_host(self, x1, y1, x2, y2, offsets, thr, guesses=None, has_guess=None, seed=0, pair_id_base=0,
+                                 out=None):
+        """Host (numpy) SoA in, (edges structured array, masks) out; copies are pipelined against the kernels.
+        out = (edges, masks): caller-provided (e.g. pinned) result arrays."""
         f = lambda a: np.ascontiguousarray(a, np.float32)
         x1, y1, x2, y2 = f(x1), f(y1), f(x2), f(y2)
         off = np.ascontiguousarray(offsets, np.uint64)
@@ -100,12 +102,28 @@ class Engine:
         if guesses is not None:
             g = np.ascontiguousarray(guesses, np.float64).reshape(P, 12)
             hg = np.ones(P, np.uint8) if has_guess is None else np.ascontiguousarray(has_guess, np.uint8)
-        edges = np.zeros(P, L.EDGE_DTYPE)
-        masks = np.zeros(max(int(off[-1] - off[0]), 1), np.uint8)
+        if out is None:
+            edges = np.zeros(P, L.EDGE_DTYPE)
+            masks = np.zeros(max(int(off[-1] - off[0]), 1), np.uint8)
+        else:
+            edges, masks = out
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         L.check(self._lib.pgi_estimate_pose_batch_host(self._ctx, p(x1), p(y1), p(x2), p(y2), p(off), p(thr), p(g), p(hg), P,
                                                        int(pair_id_base), int(seed), p(edges), p(masks)))
         return edges, masks[:int(off[-1] - off[0])]
+
+    def pin(self, *arrays):
+        """Page-locks numpy arrays (pgi_host_register) so estimate_pose_batch_host moves them by asynchronous DMA; returns
+        them.  Call unpin() on the same arrays before they are freed."""
+        for a in arrays:
+            if a.nbytes:
+                L.check(self._lib.pgi_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return arrays
+
+    def unpin(self, *arrays):
+        for a in arrays:
+            if a.nbytes:
+                L.check(self._lib.pgi_host_unregister(a.ctypes.data_as(C.c_void_p)))
 
     @staticmethod
     def edges_to_numpy(edges):

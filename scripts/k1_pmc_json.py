@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 PMC summaries of scripts/profile_k1_r02.sh (gpurun_out/r02_k1_*_summary.txt) into
+profiles/r02_k1_pmc.json: HBM traffic (with the gfx950 FETCH_SIZE correction), the wave-lifetime split, and the
+EXECUTED floating-point work per launch for an honest compute roofline next to the (nominated) HBM one.
+
+flop counting: SQ_INSTS_VALU_{ADD,MUL,TRANS}_Fxx count wave-instructions (1 flop per lane), SQ_INSTS_VALU_FMA_Fxx 2 flop
+per lane; 64 lanes per wave-instruction are charged although EXEC masks part of them (the solver keeps 10-16 of every
+16 lanes busy), so the figure is an UPPER bound on useful flop and exact for issue-slot occupancy."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PEAK_F32, PEAK_F64 = 157.3e12, 78.6e12
+
+
+def read(tag, kernel="estimate_pose_kernel<true, false>"):
+    vals, avg_us, calls = {}, None, None
+    for line in open(os.path.join(OUT, "r02_k1_%s_summary.txt" % tag)):
+        if kernel not in line:
+            continue
+        m = re.search(r"(\S+)\s+n=(\d+)\s+sum=(\S+)", line)
+        if m:
+            vals[m.group(1)] = (float(m.group(3)), int(m.group(2)))
+        else:
+            f = line.split(")")[-1].split()
+            calls, avg_us = int(f[0]), float(f[2])
+    return vals, avg_us, calls
+
+
+def main():
+    trace, avg_us, calls = read("trace")
+    c = {}
+    for tag in ("flops", "mix", "wait", "lds", "fetch", "write"):
+        v, a, n = read(tag)
+        for k, (s, cnt) in v.items():
+            c[k] = s / cnt          # per launch
+        c["_avg_us_" + tag] = a
+    flop32 = 64 * (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_TRANS_F32"] + 2 * c["SQ_INSTS_VALU_FMA_F32"])
+    flop64 = 64 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"])
+    sec = avg_us * 1e-6
+    fetch_b = c["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE tallies 64 B per 128-B request (MI355X_MICROARCH.md, HBM)
+    write_b = c["WRITE_SIZE"] * 1024
+    wc = c["SQ_WAVE_CYCLES"]
+    out = {
+        "kernel": "pgi::estimate_pose_kernel<true, false>", "pairs": 10000, "corrs": 2000,
+        "source": "rocprofv3 --kernel-trace --pmc ... (separate passes, scripts/profile_k1_r02.sh); sums / dispatches; "
+                  "summaries in profiles/r02_k1_rocprofv3_summary.txt",
+        "kernel_us_trace_avg": avg_us, "dispatches": calls,
+        "hbm_bytes_per_launch": round(fetch_b + write_b), "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]),
+        "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
+        "correction": "FETCH_SIZE x2 on gfx950 (64 B tallied per 128-B request); WRITE_SIZE as reported",
+        "algorithmic_bytes_per_launch": 10000 * (17 * 2000 + 200),
+        "executed_flop_per_launch": {"f32": round(flop32), "f64": round(flop64),
+                                     "note": "wave-instructions x 64 lanes (EXEC masks not subtracted): upper bound on useful flop"},
+        "roofline_compute": {
+            "f32_tflops": round(flop32 / sec / 1e12, 2), "f32_frac_of_157.3": round(flop32 / sec / PEAK_F32, 4),
+            "f64_tflops": round(flop64 / sec / 1e12, 2), "f64_frac_of_78.6": round(flop64 / sec / PEAK_F64, 4),
+            "valu_time_frac": round(flop32 / sec / PEAK_F32 + flop64 / sec / PEAK_F64, 4),
+            "note": "valu_time_frac = share of the chip's VALU issue time the executed FP instructions need at peak rate "
+                    "(f32 and f64 share the pipes); integer / move / compare / DPP instructions are extra"},
+        "valu_instruction_mix_per_launch": {k: round(c[k]) for k in sorted(c) if k.startswith("SQ_INSTS_")},
+        "mfma_instructions": round(c.get("SQ_INSTS_MFMA", 0)),
+        "wave_lifetime_split": {"waiting_on_waitcnt_or_barrier": round(c["SQ_WAIT_ANY"] / wc, 3),
+                                "issue_stalled": round(c["SQ_WAIT_INST_ANY"] / wc, 3),
+                                "issuing": round(c["SQ_ACTIVE_INST_ANY"] / wc, 3)},
+        "lds_bank_conflict_frac_of_lds_active": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4),
+        "thread_cycles_valu_per_valu_instruction": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 2),
+        "grbm_gui_active_per_launch": round(c["GRBM_GUI_ACTIVE"]),
+        "shader_clock_ghz_est": round(c["GRBM_GUI_ACTIVE"] / 8 / (c["_avg_us_lds"] * 1e-6) / 1e9, 3),  # summed over the 8 XCDs
+    }
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
+    json.dump(out, open(dst, "w"), indent=2)
+    print(json.dumps(out, indent=2))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,7 @@ def main():
         db = sqlite3.connect(path)
         cur = db.cursor()
         print("==", path)
-        print("%-60s %6s %12s %12s %7s  vgpr agpr sgpr lds" % ("kernel", "calls", "total_us", "avg_us", "%"))
+        print("%-60s %6s %12s %12s %7s  vgpr* agpr sgpr lds   (* rocpd field as recorded, not the code-object count: see profiles/r02_kernel_resources.txt)" % ("kernel", "calls", "total_us", "avg_us", "%"))
         rows = cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()  # view is in us
         meta = {r[0]: r[1:] for r in cur.execute(
             "select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name")}
