@@ -1159,11 +1159,16 @@ void pgi_destroy(pgi_ctx* ctx) {
     }
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
         if (ctx->hslot[k].stream) (void)hipStreamDestroy(ctx->hslot[k].stream);
+        if (ctx->hslot[k].in_done) (void)hipEventDestroy(ctx->hslot[k].in_done);
+        if (ctx->hslot[k].k_done) (void)hipEventDestroy(ctx->hslot[k].k_done);
+        if (ctx->hslot[k].out_done) (void)hipEventDestroy(ctx->hslot[k].out_done);
     }
+    if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+    if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     delete ctx;
 }
 
@@ -1303,12 +1308,31 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     const bool guesses = h_guess_Rt != nullptr;
-    // Chunks: a small first one (the pipeline starts after one short copy), then multiples of the number of resident
-    // workgroups so that no chunk ends in a mostly empty last wave of workgroups; huge pairs cap a chunk at ~8 M rows.
+    // Are the caller's buffers page-locked (pgi_host_register / hipHostMalloc)?  Then copies are true asynchronous DMA.
+    auto page_locked = [](const void* p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();  // unregistered host memory: not an error for us
+            return false;
+        }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool pin_in = page_locked(h_x1) && page_locked(h_y1) && page_locked(h_x2) && page_locked(h_y2);
+    const bool pin_out = page_locked(h_edges) && page_locked(h_masks);
+    const bool pinned = pin_in;
+    // Chunks are multiples of the number of resident workgroups (no chunk ends in a mostly empty last wave of
+    // workgroups).  Page-locked: PCIe (~57 GB/s) is only ~1.3x faster than K1 consumes rows, so equal, small chunks keep
+    // the copy front just ahead of the kernels and expose only the first chunk's copy.  Pageable: the runtime stages
+    // every copy on the calling thread, so fewer, larger chunks (a small first one) amortise that better.
     const uint32_t quantum = (uint32_t)std::max(64, ctx->resident_wgs);
+    uint32_t first_q = pinned ? 2 : 1, rest_q = pinned ? 2 : 3;
+    if (const char* e = getenv("PGI_HOST_CHUNKS")) {  // "first,rest" in quanta (experiments)
+        unsigned a = 0, b2 = 0;
+        if (sscanf(e, "%u,%u", &a, &b2) == 2 && a && b2) { first_q = a; rest_q = b2; }
+    }
     std::vector<uint32_t> cuts(1, 0u);
     for (uint32_t p = 0; p < n_pairs;) {
-        const uint32_t want = cuts.size() == 1 ? quantum : 3u * quantum;
+        const uint32_t want = (cuts.size() == 1 ? first_q : rest_q) * quantum;
         uint32_t q = p;
         const uint64_t r0 = h_offsets[p];
         while (q < n_pairs && q - p < want && (q == p || h_offsets[q + 1] - r0 <= 8000000ull)) ++q;
@@ -1329,19 +1353,39 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         L.total = o;
         return L;
     };
-    constexpr size_t kSlots = 3;
-    for (size_t k = 0; k < kSlots; ++k)
-        if (!ctx->hslot[k].stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->hslot[k].stream, hipStreamNonBlocking));
+    // Streams: copies travel on two dedicated HIGH-PRIORITY streams (in / out), kernels on one stream per slot.  A copy
+    // that shares a stream -- or a priority -- with K1 is starved by the ten thousand workgroups K1 keeps queued
+    // (measured: page-locked buffers were SLOWER than pageable ones that way); events carry the dependencies.
+    constexpr size_t kSlots = 4;
+    if (!ctx->copy_in) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_in, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_out, hipStreamNonBlocking, hi));
+    }
+    for (size_t k = 0; k < kSlots; ++k) {
+        pgi_ctx::HostSlot& S = ctx->hslot[k];
+        if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        if (!S.in_done) {
+            HIP_TRY(hipEventCreateWithFlags(&S.in_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.k_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.out_done, hipEventDisableTiming));
+        }
+        S.used = false;
+    }
     std::vector<uint64_t> off_local[kSlots];
     Lay lay[kSlots];
-    auto drain = [&](size_t c) -> int {  // results of chunk c back to the host (blocks until its kernel is done)
+    auto fetch = [&](size_t c) -> int {  // edge records and masks of chunk c back to the caller's buffers
         pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
+        const Lay& L = lay[c % kSlots];
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t r0 = h_offsets[p0] - h_offsets[0], rows = h_offsets[p0 + np] - h_offsets[p0];
         char* d = (char*)S.d;
-        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + lay[c % kSlots].edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, S.stream));
-        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + lay[c % kSlots].masks, rows, hipMemcpyDeviceToHost, S.stream));
-        HIP_TRY(hipStreamSynchronize(S.stream));
+        hipStream_t out = pin_out ? ctx->copy_out : S.stream;
+        HIP_TRY(hipStreamWaitEvent(out, S.k_done, 0));
+        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + L.edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, out));
+        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + L.masks, rows, hipMemcpyDeviceToHost, out));
+        HIP_TRY(hipEventRecord(S.out_done, out));
         return PGI_SUCCESS;
     };
     for (size_t c = 0; c < n_chunks; ++c) {
@@ -1349,7 +1393,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t rbase = h_offsets[p0], rows = h_offsets[p0 + np] - rbase, r0 = rbase - h_offsets[0];
         const Lay L = layout(rows, np);
-        lay[c % kSlots] = L;
+        if (S.used) HIP_TRY(hipEventSynchronize(S.out_done));  // the slot's previous chunk has left the device
         if (L.total > S.bytes) {
             if (S.d) (void)hipFree(S.d);
             S.d = nullptr; S.bytes = 0;
@@ -1362,18 +1406,23 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         uint32_t max_corr = 0;
         for (uint32_t k = 0; k <= np; ++k) ol[k] = h_offsets[p0 + k] - rbase;
         for (uint32_t k = 0; k < np; ++k) max_corr = std::max(max_corr, (uint32_t)(ol[k + 1] - ol[k]));
+        // pageable buffers: every copy is staged by the runtime on this thread; keep them on the slot's own stream so
+        // that the copies of neighbouring chunks still overlap (one shared copy stream would serialise them)
+        hipStream_t in = pinned ? ctx->copy_in : S.stream;
         if (rows) {
-            HIP_TRY(hipMemcpyAsync(d + L.x1, h_x1 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
-            HIP_TRY(hipMemcpyAsync(d + L.y1, h_y1 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
-            HIP_TRY(hipMemcpyAsync(d + L.x2, h_x2 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
-            HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.x1, h_x1 + r0, rows * 4, hipMemcpyHostToDevice, in));
+            HIP_TRY(hipMemcpyAsync(d + L.y1, h_y1 + r0, rows * 4, hipMemcpyHostToDevice, in));
+            HIP_TRY(hipMemcpyAsync(d + L.x2, h_x2 + r0, rows * 4, hipMemcpyHostToDevice, in));
+            HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, in));
         }
-        HIP_TRY(hipMemcpyAsync(d + L.off, ol.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, S.stream));
-        HIP_TRY(hipMemcpyAsync(d + L.thr, h_thr + p0, (size_t)np * 8, hipMemcpyHostToDevice, S.stream));
+        HIP_TRY(hipMemcpyAsync(d + L.off, ol.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, in));
+        HIP_TRY(hipMemcpyAsync(d + L.thr, h_thr + p0, (size_t)np * 8, hipMemcpyHostToDevice, in));
         if (guesses) {
-            HIP_TRY(hipMemcpyAsync(d + L.guess, h_guess_Rt + 12 * (size_t)p0, (size_t)np * 96, hipMemcpyHostToDevice, S.stream));
-            HIP_TRY(hipMemcpyAsync(d + L.has, h_has_guess + p0, np, hipMemcpyHostToDevice, S.stream));
+            HIP_TRY(hipMemcpyAsync(d + L.guess, h_guess_Rt + 12 * (size_t)p0, (size_t)np * 96, hipMemcpyHostToDevice, in));
+            HIP_TRY(hipMemcpyAsync(d + L.has, h_has_guess + p0, np, hipMemcpyHostToDevice, in));
         }
+        HIP_TRY(hipEventRecord(S.in_done, in));
+        HIP_TRY(hipStreamWaitEvent(S.stream, S.in_done, 0));
         pgi_batch b{};
         b.d_x1 = (const float*)(d + L.x1); b.d_y1 = (const float*)(d + L.y1); b.d_x2 = (const float*)(d + L.x2); b.d_y2 = (const float*)(d + L.y2);
         b.d_offsets = (const uint64_t*)(d + L.off); b.d_thr = (const double*)(d + L.thr);
@@ -1382,16 +1431,28 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
         const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
         if (rc < 0) return rc;
-        // results come back two chunks behind the launch front: that chunk's slot is the one the next chunk reuses
-        if (c + 1 >= kSlots) { const int rc2 = drain(c + 1 - kSlots); if (rc2 < 0) return rc2; }
+        HIP_TRY(hipEventRecord(S.k_done, S.stream));
+        lay[c % kSlots] = L;
+        S.used = true;
+        // Results: page-locked -> enqueue the device-to-host copies right away (asynchronous).  Pageable -> a copy to
+        // pageable memory blocks this thread until the kernel is done, so fetch a chunk only two launches later.
+        if (pin_out) {
+            const int rc2 = fetch(c);
+            if (rc2 < 0) return rc2;
+        } else if (c >= 2) {
+            const int rc2 = fetch(c - 2);
+            if (rc2 < 0) return rc2;
+        }
     }
-    for (size_t c = n_chunks >= kSlots - 1 ? n_chunks - (kSlots - 1) : 0; c < n_chunks; ++c) {
-        const int rc2 = drain(c);
-        if (rc2 < 0) return rc2;
-    }
+    if (!pin_out)
+        for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c) {
+            const int rc2 = fetch(c);
+            if (rc2 < 0) return rc2;
+        }
+    for (size_t k = 0; k < kSlots; ++k)
+        if (ctx->hslot[k].used) HIP_TRY(hipEventSynchronize(ctx->hslot[k].out_done));
     return PGI_SUCCESS;
 }
-
 
 namespace {
 // takes a free slot of the pool (blocks while all PGI_PAIR_SLOTS are busy); released by the destructor
