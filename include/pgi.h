@@ -57,7 +57,12 @@ typedef struct {
     uint32_t fixed_budget;  /* 0 = adaptive; else exactly this many hypotheses     */
     uint32_t guess_quirk;   /* 1 = reproduce graph_traversal.h:164 (s^2 < 1.5*thr) */
     uint32_t vote_all_rows; /* 1 = cheirality vote over all rows (pose_utils.h:203) */
-    uint32_t reserved;
+    uint32_t guess_mode;    /* what a pose guess is used for.  0 = the reference's path: score the chained pose,
+                               refit its inliers (pose_graph_builder.h:974-1029).  1 = rotation-guided (BASELINE
+                               config 5): keep the guess's ROTATION (the only metrically meaningful
+                               part of a chained pose), re-estimate the translation direction from 32 two-point
+                               hypotheses (t . (p2 x R p1) = 0), local optimisation, accept at min_inliers,
+                               otherwise the full robust fit */
 } pgi_params;
 
 /* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.

@@ -122,7 +122,7 @@ void pgo_default_params(pgo_params* p) {
     p->fixed_budget = 0;
     p->guess_quirk = 1;
     p->vote_all_rows = 0;
-    p->reserved = 0;
+    p->guess_mode = 0;
 }
 
 uint64_t pgo_mix64(uint64_t z) {
@@ -1123,7 +1123,59 @@ void pgo_estimate_pose(const float* x1, const float* y1, const float* x2, const 
     memset(out, 0, sizeof *out);
     int success = 0;
     float Ebest[9];
-    if (guess && n >= 5) { /* :974-1029 */
+    if (guess && n >= 5 && prm->guess_mode == 1) {
+        /* Rotation-guided re-estimation (BASELINE config 5): the rotation of a chained pose is
+         * metrically meaningful, its translation is not (unit per-edge baselines are composed), so keep R and
+         * re-estimate the translation direction: every correspondence gives t . (p2 x R p1) = 0, two rows fix t.
+         * One round of PGO_GUIDED_HYPS two-point hypotheses, scored like any model; the best one seeds the usual
+         * local optimisation; accepted when it reaches min_inliers, otherwise the full robust fit runs from scratch. */
+        const double* R = guess;
+        const uint64_t base = pgo_mix64(seed ^ pgo_mix64(pair_id));
+        best_t best;
+        memset(&best, 0, sizeof best);
+        for (uint32_t h = 0; h < PGO_GUIDED_HYPS; ++h) {
+            const uint32_t i0 = pgo_draw_index(base, 0x40000000u + h, 0, n);
+            uint32_t i1 = i0;
+            for (uint32_t k = 1; k < 64 && i1 == i0; ++k) i1 = pgo_draw_index(base, 0x40000000u + h, k, n);
+            double nv[2][3];
+            const uint32_t id[2] = {i0, i1};
+            for (int q = 0; q < 2; ++q) {
+                const double X1[3] = {x1[id[q]], y1[id[q]], 1.0}, X2[3] = {x2[id[q]], y2[id[q]], 1.0};
+                double a[3];
+                for (int i = 0; i < 3; ++i) a[i] = fma(R[3 * i], X1[0], fma(R[3 * i + 1], X1[1], R[3 * i + 2]));
+                cross3(X2, a, nv[q]);
+            }
+            double t[3];
+            cross3(nv[0], nv[1], t);
+            const double t2 = fma(t[0], t[0], fma(t[1], t[1], t[2] * t[2]));
+            if (!(t2 > 1e-30)) continue;
+            double Eg[9], n2 = 0.0;
+            pgo_ref_essential_from_pose(R, t, Eg);
+            for (int m = 0; m < 9; ++m) n2 = fma(Eg[m], Eg[m], n2);
+            if (!(n2 > 0.0)) continue;
+            const double inv = 1.0 / sqrt(n2);
+            float Ef[9];
+            for (int m = 0; m < 9; ++m) Ef[m] = (float)(Eg[m] * inv);
+            uint32_t sc, c;
+            pgo_score_model(Ef, x1, y1, x2, y2, n, thr, &sc, &c);
+            if (!best.valid || sc > best.score) {
+                memcpy(best.E, Ef, sizeof best.E);
+                best.score = sc; best.n_inl = c; best.valid = 1;
+            }
+        }
+        uint32_t lo_runs = 0;
+        if (best.valid) local_optimise(x1, y1, x2, y2, n, thr, prm, &best, mask, &lo_runs);
+        if (best.valid && best.n_inl >= prm->min_inliers) {
+            const float thr2 = (float)(thr * thr);
+            success = 2;
+            out->n_inl = pgo_mask_model(best.E, x1, y1, x2, y2, n, thr2, mask);
+            out->score = best.score;
+            out->used_guess = 1;
+            out->iters = PGO_GUIDED_HYPS;
+            out->lo_runs = lo_runs;
+            for (int m = 0; m < 9; ++m) out->E[m] = (double)best.E[m];
+        }
+    } else if (guess && n >= 5) { /* :974-1029 */
         double Eg[9], n2 = 0.0;
         pgo_ref_essential_from_pose(guess, guess + 9, Eg);
         for (int m = 0; m < 9; ++m) n2 = fma(Eg[m], Eg[m], n2);

@@ -41,6 +41,7 @@ extern "C" {
 #ifndef PGO_JACOBI9_SWEEPS
 #define PGO_JACOBI9_SWEEPS 6   /* cyclic (tournament-ordered) Jacobi sweeps, 9x9  */
 #endif
+#define PGO_GUIDED_HYPS 32     /* two-point translation hypotheses of the rotation-guided guess path */
 #ifndef PGO_SVD3_SWEEPS
 #define PGO_SVD3_SWEEPS 4      /* one-sided Jacobi sweeps, 3x3                    */
 #endif
@@ -60,7 +61,8 @@ typedef struct {
     uint32_t fixed_budget;   /* 0 = adaptive; else exactly this many hypotheses         */
     uint32_t guess_quirk;    /* 1 = getInliers compares s^2 < 1.5*thr (graph_traversal.h:164) */
     uint32_t vote_all_rows;  /* 1 = cheirality vote over all rows (pose_utils.h:203)    */
-    uint32_t reserved;
+    uint32_t guess_mode;     /* 0 = the reference's guess path (score -> all-inlier refit, :974-1029);
+                                1 = rotation-guided: keep R of the guess, re-estimate t (BASELINE config 5) */
 } pgo_params;
 
 typedef struct {

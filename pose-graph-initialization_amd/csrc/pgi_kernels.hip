@@ -497,8 +497,154 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     bool success = false, have_model = false;
     uint32_t guess_ninl = 0;
 
+    bool guided_done = false;  // the rotation-guided path delivered the model: skip the robust fit
+    // Local optimisation of the current best (sh->bestE): up to lo_iters n-point refits while they improve.  Called by
+    // ALL threads right after a merge (the first normal matrix is built by the whole workgroup); the refits themselves
+    // run on wave 0, which is the only writer of the best until the next workgroup barrier.
+    auto local_optimise = [&]() {
+        if constexpr (!GUESS) return;  // only the guess variants call it (keeps the plain kernel's code unchanged)
+        int ni_first = -1;
+        if (prm.lo_iters) {
+            float bE0[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
+            int td = tid;
+            asm volatile("" : "+v"(td));
+            ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ, wscr_all + W_DOUBLES, sh, td);
+        }
+        if (w == 0) {
+            for (uint32_t it = 0; it < prm.lo_iters; ++it) {
+                float bE[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
+                const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
+                const uint32_t cur_ninl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->best_ninl);
+                int r_score;
+                uint32_t r_ninl;
+                float rE[9];
+                int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
+                asm volatile("" : "+v"(ln));
+                const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best, cur_ninl, r_score,
+                                                         r_ninl, rE, prof, it == 0 ? ni_first : -1);
+                if (ni < 5) break;
+                if (lane == 0) sh->lo_runs += 1;
+                if (!(r_score > cur_best)) break;
+                if (lane == 0) {
+                    sh->best_score = r_score;
+                    sh->best_ninl = r_ninl;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
+                }
+                wave_sync();
+            }
+        }
+    };
+    // ---- rotation-guided re-estimation of a guessed pose (guess_mode 1; BASELINE config 5) ----
+    // The rotation of a chained pose is metrically meaningful, its translation is not: keep R, re-estimate t.  Every
+    // row gives t . (p2 x R p1) = 0, so two rows fix the direction.  32 two-point hypotheses -- eight per wavefront, one
+    // per lane -- are scored like any other model, the best seeds the usual local optimisation, and the result is
+    // accepted at min_inliers; otherwise the robust fit below runs from scratch.
+    if (GUESS && a.has_guess[pair] && prm.guess_mode == 1u) {
+        const double* G = a.guess + 12 * (size_t)pair;
+        const double R[9] = {G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7], G[8]};
+        const uint64_t rng_g = mix64(a.seed ^ mix64(a.pair_id_base + pair));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bool mine = ln < 8;
+        const uint32_t h = (uint32_t)(w * 8 + (mine ? ln : 0));
+        const uint32_t i0 = draw_index(rng_g, 0x40000000u + h, 0u, n);
+        uint32_t i1 = i0;
+        for (uint32_t k = 1; k < 64u && i1 == i0; ++k) i1 = draw_index(rng_g, 0x40000000u + h, k, n);
+        double nv[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 p = rows.get(q == 0 ? i0 : i1);
+            const double X1[3] = {(double)p.x, (double)p.y, 1.0}, X2[3] = {(double)p.z, (double)p.w, 1.0};
+            double av[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[i] = fma(R[3 * i], X1[0], fma(R[3 * i + 1], X1[1], R[3 * i + 2]));
+            cross3(X2, av, nv[q]);
+        }
+        double t[3];
+        cross3(nv[0], nv[1], t);
+        const double t2 = fma(t[0], t[0], fma(t[1], t[1], t[2] * t[2]));
+        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        double Eg[9], n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sacc += tx[3 * i + k] * R[3 * k + j];
+                Eg[3 * i + j] = sacc;
+            }
+#pragma unroll
+        for (int m = 0; m < 9; ++m) n2 = fma(Eg[m], Eg[m], n2);
+        const double inv = 1.0 / sqrt(n2);
+        float E32[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) E32[m] = (float)(Eg[m] * inv);
+        const bool valid = mine && (t2 > 1e-30) && (n2 > 0.0);
+        const int cnt = enqueue_models(valid, E32, h, queue, sh->q_hyp[w], ln);
+        wave_sync();
+        int gb_score = -1, gb_idx = -1;
+        uint32_t gb_ninl = 0, gb_hyp = 0;
+        score_queue<LDS_PTS>(rows, n, npad, queue, sh->q_hyp[w], 0, cnt, thr2, ln, -1, 0u, gb_score, gb_ninl, gb_hyp, gb_idx);
+        if (gb_idx >= 0 && ln < 9) sh->candE[w][ln] = queue[9 * gb_idx + ln];
+        if (lane == 0) {
+            sh->cand_score[w] = gb_score;
+            sh->cand_ninl[w] = gb_ninl;
+            sh->cand_hyp[w] = gb_hyp;
+        }
+        __syncthreads();
+        int rb = -1, rbw = -1;
+        uint32_t rbh = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {  // score desc, hypothesis index asc
+            const int cs = sh->cand_score[ww];
+            const uint32_t ch = sh->cand_hyp[ww];
+            if (cs > rb || (cs == rb && cs >= 0 && ch < rbh)) {
+                rb = cs;
+                rbw = ww;
+                rbh = ch;
+            }
+        }
+        __syncthreads();
+        if (rb >= 0) {  // workgroup-uniform
+            if (tid == 0) {
+                sh->best_score = rb;
+                sh->best_ninl = sh->cand_ninl[rbw];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sh->bestE[c] = sh->candE[rbw][c];
+            }
+            __syncthreads();
+            local_optimise();
+            __syncthreads();
+            if (sh->best_ninl >= prm.min_inliers) {
+                guided_done = true;
+                have_model = true;
+                out_used_guess = 1;
+                out_iters = 32;
+                out_lo = sh->lo_runs;
+                out_score = (uint32_t)sh->best_score;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) finalE[c] = sh->bestE[c];
+            }
+        }
+        if (!guided_done) {  // nothing usable: the robust fit starts from scratch
+            __syncthreads();
+            if (tid == 0) {
+                sh->best_score = -1;
+                sh->best_ninl = 0;
+                sh->lo_runs = 0;
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- pose guess (pose_graph_builder.h:974-1029) ----
-    if (GUESS && a.has_guess[pair]) {  // GUESS: the batch carries guesses (chosen at launch)
+    if (GUESS && a.has_guess[pair] && prm.guess_mode != 1u) {  // GUESS: the batch carries guesses (chosen at launch)
         const double* G = a.guess + 12 * (size_t)pair;
         const double R[9] = {G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7], G[8]};
         const double t[3] = {G[9], G[10], G[11]};
@@ -561,7 +707,7 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     }
 
     // ---- robust fit (pose_graph_builder.h:1031-1055) ----
-    if (!success) {
+    if (!success && !guided_done) {
         const uint64_t rng_base = mix64(a.seed ^ mix64(a.pair_id_base + pair));
         const uint32_t rs = prm.round_size ? prm.round_size : 32u;
         const uint32_t budget = prm.fixed_budget ? prm.fixed_budget : prm.max_iters;
@@ -676,6 +822,8 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
             floor_score = __builtin_amdgcn_readfirstlane(sh->best_score);
             n_bar = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->nbar);
             if (improve) {
+                // (same steps as local_optimise() above, spelled out: inside the round loop the compiler schedules the
+                // inline form measurably better than the shared lambda -- 2 % on BASELINE config 2)
                 int ni_first = -1;
                 if (prm.lo_iters) {  // every wavefront is here anyway: build the first refit's normal matrix together
                     float bE0[9];
@@ -1109,7 +1257,7 @@ void pgi_default_params(pgi_params* p) {
     p->fixed_budget = 0;
     p->guess_quirk = 1;
     p->vote_all_rows = 0;
-    p->reserved = 0;
+    p->guess_mode = 0;
 }
 
 pgi_ctx* pgi_create(int device, const pgi_params* params) {

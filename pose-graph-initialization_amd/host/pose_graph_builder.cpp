@@ -283,7 +283,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
             statistics.addCount("[A*] Paths tested", tally.found, tally.searched);
         }
         std::vector<pgi_edge> edges;
-        const size_t added = estimatePoses(wave, poseGraph_, seed++, &edges, /*screenGuesses*/ pathFinding);
+        const size_t added = estimatePoses(wave, poseGraph_, seed++, &edges, /*screenGuesses*/ pathFinding && !rotationGuidedGuesses);
         const Clock::time_point t1 = Clock::now();
         for (size_t i = 0; i < wave.size(); ++i) {
             st.hypotheses += edges[i].iters;

@@ -465,6 +465,17 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // the reference's `RunningStatistics statistics` (pose_graph_builder.h:385): filled by run / processFeatures with
     // the reference's key names, printed by run(Reconstruction&, PoseGraph&) like :712
     RunningStatistics& getStatistics() { return statistics; }
+    // BASELINE config 5: use the A* chain's ROTATION only and re-estimate the translation direction on the GPU
+    // (pgi_params.guess_mode = 1) instead of the reference's score -> refit of the chained pose (mode 0).  The chained
+    // translation is a sum of unit baselines and therefore meaningless; with this switch on, run() hands every chained
+    // pose to the estimator without the InTraversalPoseTester screen (which tests exactly that translation).
+    void setRotationGuidedGuesses(bool on) {
+        pgi_params p;
+        Engine::check(pgi_get_params(engine->get(), &p));
+        p.guess_mode = on ? 1u : 0u;
+        Engine::check(pgi_set_params(engine->get(), &p));
+        rotationGuidedGuesses = on;
+    }
     // one process per GPU: the host-side channel of this rank (also install the engine's transport: dist::attach)
     void setHostComm(dist::HostComm* comm) { hostComm = comm; }
     uint32_t worldSize() const;
@@ -473,6 +484,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
    protected:
     RunningStatistics statistics;
     dist::HostComm* hostComm = nullptr;
+    bool rotationGuidedGuesses = false;
     const size_t kCoreNumber, kMinimumInlierNumber, kMinimumPointNumber, kMaximumPointNumberForEpipolarHashing,
         kMaximumSearchDepth, kMaximumPathNumber, kMaximumTrackletNumber;
     const std::string kImagePath, kWorkspacePath, kSimilarityGraphPath, kFocalLengthPath;

@@ -3,6 +3,7 @@
 //                                                      rotation averaging (PoseGraphBuilder::estimateAndAverage)
 //   test_distributed <scene.bin> <out prefix> waves   config 5: A*-scheduled waves, every wave sharded over the ranks
 //                                                      (PoseGraphBuilder::run), then rotation averaging of the graph
+//   ... waves_guided  the same with rotation-guided re-estimation of the chained poses (pgi_params.guess_mode = 1)
 // RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT come from the environment (torch.distributed.run style).
 // Each rank writes <out prefix>.<rank>; tests/test_distributed_gpu.py demands that every rank's file equals the
 // single-process file byte for byte.  Scene format: tests/test_distributed_gpu.py (write_scene).
@@ -47,7 +48,9 @@ int main(int argc, char** argv) {
             if (simKind == 2) sim.setSimilarity(s, d, simv);
         }
         if (!in) return 3;
-        PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", mode == "waves", true, true);
+        const bool waves = mode == "waves" || mode == "waves_guided";
+        PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", waves, true, true);
+        if (mode == "waves_guided") builder.setRotationGuidedGuesses(true);  // config 5: rotation-guided re-estimation
         const dist::Transport tr = dist::attach(builder.getEngine(), comm);
         builder.setHostComm(&comm);
         std::ofstream out(std::string(argv[2]) + "." + std::to_string(env.rank), std::ios::binary);

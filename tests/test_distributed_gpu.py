@@ -152,6 +152,28 @@ def test_config5_wave_protocol_with_astar(scene):
 
 
 @pytest.mark.gpu
+def test_config5_rotation_guided_reestimation(scene):
+    """BASELINE config 5 as named: A*-scheduled edges + rotation-guided re-estimation (guess_mode 1): the chain's rotation
+    is kept, the translation direction re-estimated from two-point hypotheses.  Two ranks == one rank bit for bit, and --
+    unlike the reference's guess path -- the thin V = 5000 ring comes out right, with far fewer hypotheses drawn."""
+    import rotavg_oracle as RO
+    g, V, d = scene["g"], scene["V"], scene["dir"]
+    run_ranks([EXE, scene["path"], str(d / "guided_w1"), "waves_guided"], 1)
+    run_ranks([EXE, scene["path"], str(d / "guided_w2"), "waves_guided"], 2)
+    single = open(str(d / "guided_w1.0"), "rb").read()
+    assert open(str(d / "guided_w2.0"), "rb").read() == single and open(str(d / "guided_w2.1"), "rb").read() == single
+    st = struct.unpack_from("<12Q", single, 0)
+    err = RO.align_error_deg(_rotations(single, V), g["R_gt"])
+    print("config 5 guided %s: %d edges, %d from rotation-guided guesses of %d searched, %d hypotheses, rotation error mean %.3f deg" % (
+        scene["name"], st[8], st[5], st[2], st[6], err.mean()))
+    assert st[5] > 0.5 * st[3] > 0                     # most chained rotations lead to an accepted edge
+    assert err.mean() < (0.5 if V < 1000 else 1.5)
+    if os.path.exists(str(d / "waves_w1.0")):          # fewer hypotheses than the reference-style run of the same scene
+        ref = struct.unpack_from("<12Q", open(str(d / "waves_w1.0"), "rb").read(), 0)
+        assert st[6] < ref[6]
+
+
+@pytest.mark.gpu
 def test_python_ranks_over_gloo_match_single_process(tmp_path):
     """pyposegraphbuilder.distributed.Communicator (gloo bootstrap, host transport of pgi_allgather_edges): shard ->
     estimate -> gather -> pgi_rotation_average_edges from the device table, world 2 == world 1, bit for bit."""

@@ -436,3 +436,47 @@ def test_host_buffer_batch_equals_device_batch():
         assert np.array_equal(eng.edges_to_numpy(e2)["E"], got2["E"]) and np.array_equal(mm2.cpu().numpy(), m2)
     finally:
         eng.close()
+
+
+def test_rotation_guided_guess_mode_matches_oracle(eng):
+    """guess_mode = 1 (BASELINE config 5): keep the guess's rotation, re-estimate the translation direction
+    from 32 two-point hypotheses, local optimisation, accept at min_inliers, else the robust fit -- bit-identical to the
+    oracle, and a chained pose with a good rotation but a meaningless translation now yields the right edge (the
+    reference's own guess path, mode 0, accepts garbage there because of its un-squared inlier bound)."""
+    sizes = [300, 1000, 64, 2000, 150, 2500, 700, 90]
+    rhos = [0.5, 0.3, 0.6, 0.7, 0.2, 0.5, 0.1, 0.5]
+    ids = np.arange(9100, 9100 + len(sizes))
+    parts = [S.make_pair(int(i), n, inlier_ratio=r) for i, n, r in zip(ids, sizes, rhos)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    cat = lambda k: np.concatenate([p[k] for p in parts])
+    rng = np.random.default_rng(5)
+    guesses = np.zeros((len(sizes), 12))
+    has = np.ones(len(sizes), np.uint8)
+    for i, p in enumerate(parts):
+        Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(0.5)) @ p["R"]       # chained rotation: half a degree off
+        if i == 2:
+            Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(40.0)) @ p["R"]  # a wrong rotation: falls back to the robust fit
+        guesses[i] = np.r_[Rg.ravel(), rng.standard_normal(3)]                    # translation: meaningless
+    has[5] = 0                                                                    # one pair without a guess
+    thr = 7.5e-4
+    db = eng.upload(cat("x1"), cat("y1"), cat("x2"), cat("y2"), off, thr, guesses=guesses, has_guess=has, seed=21, pair_id_base=400)
+    try:
+        eng.set_params(guess_mode=1)
+        edges, masks = eng.estimate_pose_batch(db)
+        got, gm = eng.edges_to_numpy(edges), masks.cpu().numpy()
+        exp, em = O.estimate_pose_batch(cat("x1"), cat("y1"), cat("x2"), cat("y2"), off, thr, O.default_params(guess_mode=1), 21,
+                                        pair_id_base=400, guesses=guesses, has_guess=has)
+        assert np.array_equal(gm, em)
+        for f in ("E", "status", "n_inl", "score", "iters", "used_guess", "lo_runs", "cand", "votes"):
+            assert np.array_equal(got[f], exp[f]), f
+        np.testing.assert_allclose(got["R"], exp["R"], atol=1e-12)
+        assert list(got["used_guess"]) == [1, 1, 0, 1, 1, 0, got["used_guess"][6], 1] and got["iters"][0] == 32
+        for i in (0, 1, 3, 4, 7):
+            assert S.rot_err_deg(got["R"][i].reshape(3, 3), parts[i]["R"]) < 2.0   # pair 4 has ~30 inliers of 150 rows
+        # the reference's guess path on the same input accepts the chained pose's garbage
+        eng.set_params(guess_mode=0)
+        e0 = eng.edges_to_numpy(eng.estimate_pose_batch(db)[0])
+        bad = [S.rot_err_deg(e0["R"][i].reshape(3, 3), parts[i]["R"]) for i in (0, 1, 3) if e0["status"][i] == 1]
+        assert max(bad) > 5.0
+    finally:
+        eng.set_params(guess_mode=0)
