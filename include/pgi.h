@@ -63,6 +63,13 @@ typedef struct {
                                part of a chained pose), re-estimate the translation direction from 32 two-point
                                hypotheses (t . (p2 x R p1) = 0), local optimisation, accept at min_inliers,
                                otherwise the full robust fit */
+    uint32_t lo_linear_pct; /* local optimisation refits an inlier set of at least this many percent of the rows
+                               LINEARLY (smallest eigenvector of the 9x9 normal matrix = least-squares epipolar
+                               matrix): as accurate as the n-point Nister refit there and several times cheaper;
+                               smaller sets keep the Nister refit.  Default 35; 0 = always Nister.  A final model
+                               that comes from a linear refit is not exactly rank 2; R and t come from its SVD
+                               (pose_utils.h:144-169) like for any other E */
+    uint32_t reserved;
 } pgi_params;
 
 /* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.

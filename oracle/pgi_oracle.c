@@ -123,6 +123,8 @@ void pgo_default_params(pgo_params* p) {
     p->guess_quirk = 1;
     p->vote_all_rows = 0;
     p->guess_mode = 0;
+    p->lo_linear_pct = 35;
+    p->reserved = 0;
 }
 
 uint64_t pgo_mix64(uint64_t z) {
@@ -645,6 +647,28 @@ uint32_t pgo_npoint(const float* x1, const float* y1, const float* x2, const flo
     return pgo_backend(basis, NULL, 0, models, NULL);
 }
 
+/* Linear refit of an inlier set: the eigenvector of the smallest eigenvalue of the 9x9 normal matrix (first minimum
+ * wins ties) = the least-squares solution of the epipolar equations, scaled to unit Frobenius norm and rounded to
+ * f32.  No projection onto the essential manifold here: the model is only scored (the Sampson distance is defined for
+ * any 3x3 matrix) and, if it ends up as the final model, decomposed by the SVD of pose_utils.h:144-169, which takes
+ * U and V of whatever matrix it is given.  Returns the number of models (0 or 1). */
+uint32_t pgo_linear_refit(const float* x1, const float* y1, const float* x2, const float* y2, const uint8_t* mask,
+                          uint32_t n, float model[9]) {
+    double A[81], V[81];
+    pgo_normal_matrix(x1, y1, x2, y2, mask, n, A);
+    pgo_jacobi9(A, V);
+    int bi = 0;
+    for (int i = 1; i < 9; ++i)
+        if (A[10 * i] < A[10 * bi]) bi = i;
+    double e[9], n2 = 0.0;
+    for (int l = 0; l < 9; ++l) e[l] = V[9 * l + bi];
+    for (int m = 0; m < 9; ++m) n2 = fma(e[m], e[m], n2);
+    if (!(n2 > 0.0)) return 0;
+    const double inv = 1.0 / sqrt(n2);
+    for (int m = 0; m < 9; ++m) model[m] = (float)(e[m] * inv);
+    return 1;
+}
+
 /* ---- decomposition ------------------------------------------------------ */
 /* one-sided Jacobi on the columns of G = E*V; sigma sorted descending;
  * U2 = U0 x U1 (det U = +1); det V fixed by flipping V2 (pose_utils.h:157-163) */
@@ -1031,7 +1055,14 @@ static void local_optimise(const float* x1, const float* y1, const float* x2, co
         const uint32_t ni = pgo_mask_model(best->E, x1, y1, x2, y2, n, thr2, mask);
         if (ni < 5) break;
         float models[PGO_MAX_MODELS][9];
-        const uint32_t nm = pgo_npoint(x1, y1, x2, y2, mask, n, models);
+        uint32_t nm;
+        /* large inlier sets: the linear refit (smallest eigenvector of the normal matrix) is as accurate as the n-point
+         * Nister refit and far cheaper; small ones keep the Nister refit, which tolerates the outliers inside a poor
+         * model's inlier band better */
+        if (prm->lo_linear_pct && (uint64_t)ni * 100u >= (uint64_t)n * prm->lo_linear_pct)
+            nm = pgo_linear_refit(x1, y1, x2, y2, mask, n, models[0]);
+        else
+            nm = pgo_npoint(x1, y1, x2, y2, mask, n, models);
         ++*lo_runs;
         int improved = 0;
         uint32_t bs = best->score, bi = 0, bn = 0;

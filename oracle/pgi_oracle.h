@@ -63,6 +63,9 @@ typedef struct {
     uint32_t vote_all_rows;  /* 1 = cheirality vote over all rows (pose_utils.h:203)    */
     uint32_t guess_mode;     /* 0 = the reference's guess path (score -> all-inlier refit, :974-1029);
                                 1 = rotation-guided: keep R of the guess, re-estimate t (BASELINE config 5) */
+    uint32_t lo_linear_pct;  /* LO refits an inlier set of at least this many percent of the rows linearly
+                                (pgo_linear_refit); smaller sets with the n-point Nister refit.  0 = always Nister */
+    uint32_t reserved;
 } pgo_params;
 
 typedef struct {
@@ -143,6 +146,8 @@ void pgo_basis_from_eigen(const double A[81], const double V[81], double basis[3
 uint32_t pgo_npoint(const float* x1, const float* y1, const float* x2, const float* y2,
                     const uint8_t* mask, uint32_t n, float models[PGO_MAX_MODELS][9]);
 
+uint32_t pgo_linear_refit(const float* x1, const float* y1, const float* x2, const float* y2, const uint8_t* mask,
+                          uint32_t n, float model[9]);
 void pgo_svd3(const double E[9], double U[9], double S[3], double V[9]);
 /* pose_utils.h:144-252 structure, correct cheirality */
 void pgo_decompose(const double E[9], const float* x1, const float* y1, const float* x2,

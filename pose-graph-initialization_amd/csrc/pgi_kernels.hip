@@ -385,7 +385,8 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
 template <bool LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
                              float thr2, double* wscr0, WgShared* sh, int lane, int floor_score, uint32_t n_bar,
-                             int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, int ni_pre = -1) {
+                             int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, int ni_pre = -1,
+                             uint32_t lin_pct = 0u) {
     double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
     double* loV = loA + 81;                    // 81 (ends at W_REGA + 228 <= W_DOUBLES)
     double* tri = wscr0 + G_BASIS_SZ;          // 45 doubles over basis of groups 1..2
@@ -400,11 +401,29 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     jacobi9_wave(loA, loV, wscr0 + W_BASIS, lane);
     prof.mark<13>();
     float E32[9];
-    const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
-    const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
-                                                        [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
-    wave_sync();
-    const int cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
+    int cnt;
+    if (lin_pct && (uint64_t)ni * 100u >= (uint64_t)n * lin_pct) {  // wave-uniform
+        // Linear refit: the eigenvector of the smallest eigenvalue (jacobi9_wave left it as basis vector W) is the
+        // least-squares solution of the epipolar equations; unit Frobenius norm, f32.  Lanes 0..8 hold one entry each.
+        const double ev = wscr0[W_BASIS + 27 + (lane < 9 ? lane : 0)];
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double ec = __shfl(ev, c);
+            n2 = fma(ec, ec, n2);
+        }
+        const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) E32[c] = (float)(__shfl(ev, c) * inv);
+        wave_sync();
+        cnt = enqueue_models(lane == 0 && (n2 > 0.0), E32, 0u, queue0, sh->q_hyp[0], lane);
+    } else {
+        const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
+        const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
+                                                            [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
+        wave_sync();
+        cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
+    }
     wave_sync();
     prof.mark<20>();
     int b_idx = -1;
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                 int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                 asm volatile("" : "+v"(ln));
                 const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best, cur_ninl, r_score,
-                                                         r_ninl, rE, prof, it == 0 ? ni_first : -1);
+                                                         r_ninl, rE, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct);
                 if (ni < 5) break;
                 if (lane == 0) sh->lo_runs += 1;
                 if (!(r_score > cur_best)) break;
@@ -847,7 +866,8 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
                         int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                         asm volatile("" : "+v"(ln));
                         const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best,
-                                                                 cur_ninl, r_score, r_ninl, rE, prof, it == 0 ? ni_first : -1);
+                                                                 cur_ninl, r_score, r_ninl, rE, prof, it == 0 ? ni_first : -1,
+                                                                 prm.lo_linear_pct);
                         if (ni < 5) break;
                         if (lane == 0) sh->lo_runs += 1;
                         if (!(r_score > cur_best)) break;
@@ -1258,6 +1278,8 @@ void pgi_default_params(pgi_params* p) {
     p->guess_quirk = 1;
     p->vote_all_rows = 0;
     p->guess_mode = 0;
+    p->lo_linear_pct = 35;
+    p->reserved = 0;
 }
 
 pgi_ctx* pgi_create(int device, const pgi_params* params) {
