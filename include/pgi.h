@@ -268,9 +268,11 @@ typedef struct {
      * f16 matrix-core products (16x the f32 rate) and re-evaluates only the few candidates that can matter
      * with the exact f32 chain -- same output, bit for bit; NULL selects the all-f32 kernel */
     const float* d_desc_rm;       /* n_pad x 128 row-major f32, zero padded */
-    const uint16_t* d_desc_f16;   /* n_pad x 128 row-major IEEE half (round to nearest even) */
+    const uint16_t* d_desc_f16;   /* n_pad x 128 IEEE halves (round to nearest even) in the matcher's own tile order:
+                                     opaque, written by pgi_desc_prepare_screen */
 } pgi_desc_view;
-/* d_desc: n x 128 row-major floats -> the padded row-major copy and its half-precision rounding (both n_pad x 128). */
+/* d_desc: n x 128 row-major floats -> the padded row-major copy (n_pad x 128 floats) and its half-precision rounding
+ * (n_pad x 128 halves, tile-ordered for the matrix cores). */
 int pgi_desc_prepare_screen(pgi_ctx* ctx, const float* d_desc, uint32_t n, float* d_desc_rm, uint16_t* d_desc_f16);
 /* Pair p matches image h_src[p] (queries) against h_dst[p].  Outputs, per pair p at
  * stride max_matches: d_match_src / d_match_dst (keypoint indices, :183-197) and d_ratio,

@@ -11,9 +11,14 @@
 //   match_select_kernel   per pair: merge the splits, ratio + mutual test, bitonic sort by (ratio, row)
 #include <algorithm>
 #include <cfloat>
+#include <type_traits>
+#include <utility>
 #include <vector>
 #include "pgi_internal.hpp"
 
+#ifndef PGI_SCREEN_WAVES
+#define PGI_SCREEN_WAVES 8
+#endif
 namespace {
 constexpr int kD = PGI_DESC_DIM;   // 128
 constexpr int kPadRows = 256;      // keypoint padding: the largest workgroup covers 8 wavefronts x one 32-row MFMA tile
@@ -263,7 +268,8 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
 //                        row's two nearest are those with d~2 <= T + 2 eps_i, T = the second smallest d~2 of the row.
 //                        Every lane keeps its two best columns and the VALUE of its third best: if no lane's third
 //                        best is inside the window, the stored columns provably contain the exact top-2 (certificate);
-//                        otherwise the row is flagged.
+//                        otherwise the row is flagged.  The bookkeeping is three VALU operations per distance: the
+//                        column's position rides in the low mantissa bits of the key, so min / med3 carry it along.
 //   desc_verify_kernel   exact f32 chain (the specification) for the stored candidates only -> RowBest; flagged rows
 //                        go to a list.
 //   desc_exact_rows_kernel  flagged rows: full exact scan, one wavefront per row.
@@ -276,11 +282,22 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
 // covers the relative part with margin; d2 = na + nb - 2s doubles everything and adds a few ulps of na + nb.  f16
 // overflows above 65504: |x_k| <= sqrt(norm), so rows or images with a squared norm above 3e9 are simply flagged.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// calls f(integral_constant<int, U>) for U = 0 .. N-1 (a compile-time loop: the slot index stays a constant)
+template <class F, int... U>
+__device__ __forceinline__ void for_each_slot(F&& f, std::integer_sequence<int, U...>) {
+    (f(std::integral_constant<int, U>{}), ...);
+}
+// Layout of the f16 copy of an image: tiles of 64 keypoints; inside a tile, chunk cg = k / 8 of keypoint jj sits at element
+// (cg * 64 + jj) * 8 -- exactly the order the screen kernel's LDS buffer (and the MFMA B operand fetch) wants, so a tile
+// is one contiguous 16 KB block.
+__host__ __device__ __forceinline__ size_t f16_offset(uint32_t keypoint, uint32_t k) {
+    return (size_t)(keypoint >> 6) * (64u * 128u) + ((size_t)(k >> 3) * 64u + (keypoint & 63u)) * 8u + (k & 7u);
+}
 constexpr float kEpsS = 0.0009765625f + 0.000030517578125f;  // 2^-10 + 2^-15
 constexpr int kCand = 8;  // stored candidates per row and column split
 
 struct ScreenPair {
-    const unsigned short *abf, *bbf;  // row-major f16, n_pad x 128
+    const unsigned short *abf, *bbf;  // f16 copies in MFMA operand order per 64-keypoint tile (desc_round_f16_kernel)
     const float *arm, *brm;           // row-major f32,  n_pad x 128
     const float *at, *bt;             // transposed f32, 128 x n_pad (exact fallback)
     const float *na, *nb;
@@ -292,10 +309,11 @@ struct ScreenRow {
     uint32_t j[kCand];
 };
 
-// TOPK = 2: a row's two nearest columns are wanted (each lane keeps two columns + the value of its third);
-// TOPK = 1: only the nearest (the column-wise pass of the swapped problem): one column + the value of the second.
+// TOPK = 2: a row's two nearest columns are wanted; TOPK = 1: only the nearest (the column-wise pass of the swapped
+// problem).  Either way each lane keeps its two best columns and the value of its third (packed keys, see below): the
+// window is T + 2 eps around the row's TOPK-th smallest approximate distance T.
 template <int NW, int TOPK>
-__global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPair* __restrict__ pairs, ScreenRow* __restrict__ out,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(const ScreenPair* __restrict__ pairs, ScreenRow* __restrict__ out,
                                                                 uint32_t splits, uint32_t wgs_per_pair, uint64_t split_stride) {
     __shared__ __attribute__((aligned(16))) unsigned short bt[2][kTileJ * kD];  // 2 x 16 KB, MFMA operand order
     __shared__ float s_nbmax[NW];
@@ -320,35 +338,72 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
     f16x8 a[kD / 16];
 #pragma unroll
     for (int ks = 0; ks < kD / 16; ++ks)
-        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + (size_t)(row_base + c) * kD + 16 * ks + 8 * (int)h);
-    float nar[16], b1[16], b2[16], b3[16];
-    uint32_t j1[16], j2[16];
+        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + f16_offset(row_base + c, 16u * (uint32_t)ks + 8u * h));
+    // Per lane and row: the three smallest KEYS seen so far, b1 <= b2 <= b3, as unsigned integers.  A key is the bit
+    // pattern of the approximate squared distance d~ = max(0, na + nb - 2 s~) -- non-negative floats order like their bit
+    // patterns -- with the column's position inside this lane's stream (code = 2 * (tile - t0) + sub, 9 bits: at most
+    // 256 tiles) in the low mantissa bits.  The column therefore travels with the value through plain integer min / median
+    // instructions: v_med3_u32, v_med3_u32, v_min_u32 keep a top-3 where separate value and index registers needed eleven
+    // compares and selects (and float min / med3 would pay a canonicalising v_max each).  The row norm enters through
+    // the accumulator, which starts at -na/2 instead of 0.  The 2^-14 relative perturbation of the key is part of eps
+    // below; padded columns carry a huge finite norm (an infinity with mantissa bits set would be a NaN).
+    constexpr float kFar = 3.0e38f;
+    constexpr uint32_t kKeyInf = 0x7F800000u;  // above every finite key
+    float nar[16];
+    uint32_t b1[16], b2[16], b3[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         nar[r] = P.na[row_base + mfma_row(r, h)];
-        b1[r] = INFINITY; b2[r] = INFINITY; b3[r] = INFINITY; j1[r] = 0u; j2[r] = 0u;
+        b1[r] = kKeyInf; b2[r] = kKeyInf; b3[r] = kKeyInf;
     }
-    // chunk cg = (ks, h') of 64 columns x 16 bytes: LDS element ((cg * 64 + jj) * 8), global B[j0 + jj][16 ks + 8 h' ..]
-    auto stage = [&](uint32_t tile, uint32_t buf) {
+    auto med3u = [](uint32_t x, uint32_t y, uint32_t z) {
+        uint32_t o;
+        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z));
+        return o;
+    };
+    // B tiles (64 columns x 128 k, 16 KB of f16) travel global -> registers -> LDS.  A tile's MFMA work is only ~500 cycles
+    // per wavefront, far less than a global load takes to come back, so a one-tile-ahead LDS-DMA double buffer left the
+    // kernel waiting on memory every tile; here three tiles are in flight in registers (their loads were issued two
+    // iterations before they are written to LDS), and the LDS double buffer only decouples the writer from the readers.
+    // Chunk cg = (ks, h') of 64 columns x 16 bytes: LDS element ((cg * 64 + jj) * 8), global B[j0 + jj][16 ks + 8 h' ..].
+    constexpr int kChunks = 16 / NW, kPre = 48 / (4 * kChunks);  // 48 VGPRs of tiles in flight: 3 tiles at NW = 4, 6 at NW = 8
+    f16x8 pre[kPre][kChunks];
+    auto gload = [&](uint32_t tile, f16x8 (&dst)[kChunks]) {
 #pragma unroll
-        for (int q = 0; q < 16 / NW; ++q) {
+        for (int q = 0; q < kChunks; ++q) {
             const uint32_t cg = (uint32_t)q * NW + w;
-            const unsigned short* src = P.bbf + (size_t)(tile * kTileJ + lane) * kD + 8u * cg;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(&bt[buf][cg * 512u]), 16, 0, 0);
+            // operand order in HBM: a wavefront reads 1 KB contiguous (the row-major layout made every lane touch its own
+            // 256-byte row, and the vector L1 then spent 64 tag cycles per load instruction)
+            dst[q] = *reinterpret_cast<const f16x8*>(P.bbf + (size_t)tile * (kTileJ * kD) + (cg * 64u + lane) * 8u);
         }
     };
-    if (t0 < t1) stage(t0, 0u);
-    for (uint32_t tile = t0; tile < t1; ++tile) {
+    auto lwrite = [&](const f16x8 (&src)[kChunks], uint32_t buf) {
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const uint32_t cg = (uint32_t)q * NW + w;
+            *reinterpret_cast<f16x8*>(&bt[buf][cg * 512u + lane * 8u]) = src[q];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)
+        if (t0 + (uint32_t)u < t1) gload(t0 + (uint32_t)u, pre[u]);
+    if (t0 < t1) lwrite(pre[0], 0u);
+    // one tile of work; U = the tile's register slot (compile-time, so the ring never turns into selects)
+    auto step = [&](uint32_t tile, auto slot) {
+        constexpr int u = decltype(slot)::value;
         const uint32_t cur = (tile - t0) & 1u;
-        __syncthreads();
-        if (tile + 1 < t1) stage(tile + 1, cur ^ 1u);
+        __syncthreads();  // tile is in bt[cur] (written last iteration); everyone is done reading bt[cur ^ 1]
+        if (tile + 1 < t1) lwrite(pre[(u + 1) % kPre], cur ^ 1u);      // loaded two iterations ago
+        if (tile + (uint32_t)kPre < t1) gload(tile + (uint32_t)kPre, pre[u]);  // this tile's registers are free again
         float nbj[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) nbj[sub] = P.nb[tile * kTileJ + 32u * sub + c];
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t j = tile * kTileJ + 32u * sub + c;
+            nbj[sub] = j < P.n_b ? P.nb[j] : kFar;  // padded columns: never near any window
+        }
         f32x16 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) { acc[0][r] = -0.5f * nar[r]; acc[1][r] = acc[0][r]; }  // so that nb - 2 acc = na + nb - 2 s
 #pragma unroll
         for (int ks = 0; ks < kD / 16; ++ks) {
             const f16x8 x0 = *reinterpret_cast<const f16x8*>(&bt[cur][((2 * ks + (int)h) * 64 + (int)c) * 8]);
@@ -358,51 +413,54 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            const uint32_t j = tile * kTileJ + 32u * sub + c;
-            const bool jvalid = j < P.n_b;
+            const uint32_t code = ((tile - t0) << 1) | (uint32_t)sub;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float d = fmaf(-2.0f, acc[sub][r], nar[r] + nbj[sub]);
-                d = jvalid ? d : INFINITY;  // (no clamp at 0: the window only needs |d~ - d| <= eps, and max(0, .) is 1-Lipschitz)
-                if constexpr (TOPK == 2) {  // the lane's best two columns and the value of its third: medians and selects
-                    const bool lt1 = d < b1[r], lt2 = d < b2[r];
-                    b3[r] = fminf(b3[r], fmaxf(b2[r], d));
-                    const float nb2 = lt1 ? b1[r] : (lt2 ? d : b2[r]);
-                    const uint32_t nj2 = lt1 ? j1[r] : (lt2 ? j : j2[r]);
-                    b2[r] = nb2; j2[r] = nj2;
-                    b1[r] = lt1 ? d : b1[r];
-                    j1[r] = lt1 ? j : j1[r];
-                } else {  // the lane's best column and the value of its second
-                    const bool lt1 = d < b1[r];
-                    b2[r] = fminf(b2[r], fmaxf(b1[r], d));
-                    b1[r] = fminf(b1[r], d);
-                    j1[r] = lt1 ? j : j1[r];
-                }
+                const float d = fmaxf(fmaf(-2.0f, acc[sub][r], nbj[sub]), 0.0f);
+                const uint32_t k = (__float_as_uint(d) & ~0x1FFu) | (code & 0x1FFu);  // v_bfi_b32
+                b3[r] = med3u(b2[r], b3[r], k);  // (old b2): third smallest of {b1, b2, b3, k}
+                b2[r] = med3u(b1[r], b2[r], k);
+                b1[r] = min(b1[r], k);
             }
         }
-    }
+    };
+    for (uint32_t base = t0; base < t1; base += (uint32_t)kPre)  // workgroup-uniform trip counts and guards
+        for_each_slot([&](auto slot) {
+            constexpr uint32_t u = (uint32_t)decltype(slot)::value;
+            if (base + u < t1) step(base + u, slot);
+        }, std::make_integer_sequence<int, kPre>{});
     __syncthreads();
     float nbm = 0.0f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) nbm = fmaxf(nbm, s_nbmax[ww]);
     // per row: T = the TOPK-th smallest approximate distance over the 32 lanes of the row, window T + 2 eps
+    auto column_of = [&](uint32_t key) {  // undo the code: the lane's own column stream is (tile, sub) -> tile*64 + 32*sub + c
+        const uint32_t code = key & 0x1FFu;
+        return (t0 + (code >> 1)) * (uint32_t)kTileJ + 32u * (code & 1u) + c;
+    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float x1 = b1[r], x2 = b2[r];
+        uint32_t x1 = b1[r], x2 = b2[r];
 #pragma unroll
         for (int m = 1; m < 32; m <<= 1) {
-            const float o1 = __shfl_xor(x1, m), o2 = __shfl_xor(x2, m);
-            const float n2 = fminf(fmaxf(x1, o1), fminf(x2, o2));
-            x1 = fminf(x1, o1);
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)x1, m), o2 = (uint32_t)__shfl_xor((int)x2, m);
+            const uint32_t n2 = min(max(x1, o1), min(x2, o2));
+            x1 = min(x1, o1);
             x2 = n2;
         }
-        const float eps = 2.0f * (kEpsS * sqrtf(nar[r] * nbm) + 3.4e-7f * (sqrtf(nar[r]) + sqrtf(nbm))) + 2.4e-7f * (nar[r] + nbm);
-        const float win = (TOPK == 2 ? x2 : x1) + 2.0f * eps;  // +inf when the split has too few valid columns: everything is kept
+        // |d~2 - d2| of the f16 products and f32 accumulations (analysis above; the accumulator starts at -na/2) + the
+        // 2^-14 relative perturbation of a key by its code bits, d~ <= na + nb + 2 sqrt(na nb) <= 2 (na + nb)
+        const float eps = 2.0f * (kEpsS * sqrtf(nar[r] * nbm) + 3.4e-7f * (sqrtf(nar[r]) + sqrtf(nbm))) + 1.0e-6f * (nar[r] + nbm) +
+                          1.25e-4f * (nar[r] + nbm);
+        const uint32_t tk = TOPK == 2 ? x2 : x1;
+        // window bound as a key: every stored key <= it is a candidate (keys of valid columns are finite floats >= 0)
+        const float winf = __uint_as_float(tk & 0xFFFFFE00u) + 2.0f * eps;
+        const uint32_t win = tk >= kKeyInf ? 0x7F7FFFFFu : __float_as_uint(fminf(winf, 3.0e38f)) | 0x1FFu;
         const bool safe = nar[r] <= 3.0e9f && nbm <= 3.0e9f;  // f16 range; also false for NaN norms
-        const bool k1 = b1[r] <= win && b1[r] < INFINITY;
-        const bool k2 = TOPK == 2 && b2[r] <= win && b2[r] < INFINITY;
-        const float unstored = TOPK == 2 ? b3[r] : b2[r];  // best column of this lane that is NOT stored
-        const bool miss = (unstored <= win && unstored < INFINITY) || !safe;
+        const uint32_t kValid = 0x7E967699u;  // bits of 1.0e38f: padded columns (norm 3e38) lie above
+        const bool k1 = b1[r] <= win && b1[r] < kValid;
+        const bool k2 = b2[r] <= win && b2[r] < kValid;
+        const bool miss = (b3[r] <= win && b3[r] < kValid) || !safe;  // b3 = best column of this lane that is NOT stored
         const unsigned long long m1 = __ballot(k1), m2 = __ballot(k2), mm = __ballot(miss);
         const uint32_t h1 = (uint32_t)(m1 >> (32u * h)), h2 = (uint32_t)(m2 >> (32u * h)), hm = (uint32_t)(mm >> (32u * h));
         const uint32_t n1 = __popc(h1), total = n1 + __popc(h2);
@@ -410,8 +468,8 @@ __global__ __launch_bounds__(NW * 64, 2) void desc_screen_kernel(const ScreenPai
         ScreenRow* o = out + (size_t)split * split_stride + P.row_off + row;
         const uint32_t below = (1u << c) - 1u;
         if (total <= (uint32_t)kCand) {
-            if (k1) o->j[__popc(h1 & below)] = j1[r];
-            if (k2) o->j[n1 + __popc(h2 & below)] = j2[r];
+            if (k1) o->j[__popc(h1 & below)] = column_of(b1[r]);
+            if (k2) o->j[n1 + __popc(h2 & below)] = column_of(b2[r]);
         }
         if (c == 0u) {
             o->count = total <= (uint32_t)kCand ? total : 0u;
@@ -556,7 +614,7 @@ __global__ __launch_bounds__(256) void desc_round_f16_kernel(const float* __rest
     const float v = idx < (size_t)n * kD ? desc[idx] : 0.0f;
     rm[idx] = v;
     const _Float16 hv = (_Float16)v;  // v_cvt_f16_f32: round to nearest even, gradual underflow
-    bf[idx] = __builtin_bit_cast(unsigned short, hv);
+    bf[f16_offset((uint32_t)(idx / kD), (uint32_t)(idx % kD))] = __builtin_bit_cast(unsigned short, hv);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -819,7 +877,7 @@ int pgi_desc_prepare_screen(pgi_ctx* ctx, const float* d_desc, uint32_t n, float
 // screened path of pgi_match_descriptors_batch (views validated by the caller, ctx locked)
 static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst, uint32_t n_pairs, uint32_t max_matches,
                           uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
-    constexpr uint32_t NWS = 4, kRowsWg = NWS * 32u;
+    constexpr uint32_t NWS = PGI_SCREEN_WAVES, kRowsWg = NWS * 32u;
     std::vector<MatchPair> hp(n_pairs);
     std::vector<ScreenPair> fwd(n_pairs), bwd(n_pairs);
     uint64_t rows_total = 0, cols_total = 0, rb_f = 0, rb_b = 0;
