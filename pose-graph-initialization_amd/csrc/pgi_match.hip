@@ -1019,6 +1019,8 @@ int pgi_match_descriptors_batch(pgi_ctx* ctx, const pgi_desc_view* h_src, const 
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
+    ctx->d_match_cnt = nullptr;  // the workspace is repurposed: the last screened match's counters are gone
+    ctx->match_cnt_pairs = 0;
     char* ws = (char*)ctx->d_match_ws;
     MatchPair* d_pairs = (MatchPair*)ws;
     RowBest* d_rows = (RowBest*)(ws + pair_bytes);
@@ -1077,6 +1079,8 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
         HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
         ctx->match_ws_bytes = bytes;
     }
+    ctx->d_match_cnt = nullptr;  // the workspace is repurposed: the last screened match's counters are gone
+    ctx->match_cnt_pairs = 0;
     KpPair* d_pairs = (KpPair*)ctx->d_match_ws;
     HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer

@@ -11,7 +11,8 @@ from pyposegraphbuilder import Engine, synthetic as S
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 cases = [dict(), dict(round_size=8), dict(lo_iters=0), dict(fixed_budget=96), dict(confidence=0.999, max_iters=300),
-         dict(min_inliers=5, vote_all_rows=1)]
+         dict(min_inliers=5, vote_all_rows=1), dict(lo_linear_pct=0), dict(guess_mode=1), dict(lo_linear_pct=10, lo_iters=3),
+         dict(guess_mode=1, round_size=16, lo_linear_pct=60)]
 total = 0
 t00 = time.time()
 for ci, kw in enumerate(cases):
@@ -27,6 +28,8 @@ for ci, kw in enumerate(cases):
             R, t = b["R"][i], b["t"][i]
             if rng.random() < 0.3:
                 R = S.rodrigues(np.array([0.0, 0, 1]), rng.uniform(0, 0.3)) @ R
+            if kw.get("guess_mode") == 1 and rng.random() < 0.7:
+                t = rng.standard_normal(3)          # a chained translation is meaningless
             guesses[i, :9], guesses[i, 9:] = R.ravel(), t
     eng = Engine(**kw)
     db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, guesses=guesses, has_guess=has, seed=ci + 7)
@@ -90,6 +93,7 @@ for (s_, d_), (gi, gj, gr) in zip(pairs, got):
         sys.exit(1)
 print("descriptor matcher: %d pairs identical (%.0f s)" % (len(pairs), time.time() - t0))
 n_scene = max(4, P // 2000)
+n_frag = 0
 t0 = time.time()
 for q in range(n_scene):
     views, poses, cam = S.make_feature_views(np.random.default_rng(9000 + q), n_views=2, n_points=int(rng.integers(200, 1500)),
@@ -109,5 +113,14 @@ for q in range(n_scene):
         if not (np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gr, orr)):
             print("GUIDED MISMATCH at scene", q)
             sys.exit(1)
-print("guided matcher: %d scenes identical (%.0f s)" % (n_scene, time.time() - t0))
+        # the reference's 45 epipolar bins: device == literal restatement outside the don't-care band at bin edges
+        gi, gj, gr = eng.guided_match_batch(feats, [(a_, b_)], Rt[None], max_n=0, n_bins=45)[0]
+        size = (int(cam[1]), int(cam[2]))
+        oi, oj, orr, frag = O.ref_guided_match_binned(F, views[a_]["xy"], views[b_]["xy"], views[a_]["desc"], views[b_]["desc"], size, size)
+        keep_o, keep_g = ~frag[oi].astype(bool), ~frag[gi].astype(bool)
+        if not (np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o])):
+            print("BINNED GUIDED MISMATCH at scene", q)
+            sys.exit(1)
+        n_frag += int(frag.sum())
+print("guided matcher (exhaustive and 45 bins): %d scenes identical, %d source points in the bin-edge band (%.0f s)" % (n_scene, n_frag, time.time() - t0))
 print("soak ok")
