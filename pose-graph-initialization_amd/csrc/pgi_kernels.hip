@@ -1488,7 +1488,9 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         return at.type == hipMemoryTypeHost;
     };
     const bool pin_in = page_locked(h_x1) && page_locked(h_y1) && page_locked(h_x2) && page_locked(h_y2);
-    const bool pin_out = page_locked(h_edges) && page_locked(h_masks);
+    // Results always return on the chunk's own stream, two launches behind the front: measured faster than an immediate
+    // copy on a dedicated stream even for page-locked result buffers (8.6 ms vs 9.0-13 ms, scripts/host_path_probe.py)
+    const bool pin_out = false;
     const bool pinned = pin_in;
     // Chunks are multiples of the number of resident workgroups (no chunk ends in a mostly empty last wave of
     // workgroups).  Page-locked: PCIe (~57 GB/s) is only ~1.3x faster than K1 consumes rows, so equal, small chunks keep
