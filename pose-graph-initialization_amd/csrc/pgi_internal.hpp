@@ -65,4 +65,5 @@ struct pgi_ctx {
     int match_screen = 1;  // bf16 screening + exact f32 verification when the views carry the data (env PGI_MATCH_SCREEN)
     int match_waves = 4;  // wavefronts per matching workgroup (4 or 8; env PGI_MATCH_WAVES)
     int lds_min_wgs = 2;  // stage rows in LDS only if this many workgroups still fit per CU
+    int hybrid_rows = 1;  // pairs just above the 4-workgroup LDS capacity keep their tail rows in HBM/L2 (env PGI_HYBRID_ROWS)
 };

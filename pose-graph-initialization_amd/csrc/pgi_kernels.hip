@@ -76,7 +76,8 @@ struct K1Args {
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
-template <bool LDS_PTS>
+// LDS_PTS: 0 = every row from HBM/L2, 1 = every row staged in LDS, 2 = hybrid (the first lds_n rows in LDS, the tail from HBM/L2)
+template <int LDS_PTS>
 struct Rows {
     const float4* lds;
     const float* x1;
@@ -84,9 +85,15 @@ struct Rows {
     const float* x2;
     const float* y2;
     uint32_t n;
+    uint32_t lds_n;  // rows resident in LDS (multiple of 64); hybrid launches keep the rest in HBM/L2
     PGI_DEV float4 get(uint32_t i) const {
-        if constexpr (LDS_PTS) {
+        if constexpr (LDS_PTS == 1) {
             return lds[i];
+        } else if constexpr (LDS_PTS == 2) {
+            if (i < lds_n) return lds[i];  // wave-uniform in the scoring loops (64-row steps)
+            const float nanv = __builtin_nanf("");
+            if (i < n) return make_float4(x1[i], y1[i], x2[i], y2[i]);
+            return make_float4(nanv, nanv, nanv, nanv);
         } else {
             const float nanv = __builtin_nanf("");
             if (i < n) return make_float4(x1[i], y1[i], x2[i], y2[i]);
@@ -108,7 +115,7 @@ PGI_DEV float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlan
 // The counters are wave-uniform popcounts of ballots (SGPR arithmetic).  A block is
 // abandoned as soon as none of its models can still exceed the bar -- exact, because the
 // levels only add: final score <= partial + 4 * rows left.
-template <bool LDS_PTS>
+template <int LDS_PTS>
 PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float* queue,
                          const uint32_t* qhyp, int m_begin, int m_end, float thr2, int lane,
                          int floor_score, uint32_t n_bar, int& b_score, uint32_t& b_ninl, uint32_t& b_hyp,
@@ -186,7 +193,7 @@ PGI_DEV int enqueue_models(bool valid, const float E32[9], uint32_t hyp, float* 
 // count, by ONE wavefront (local optimisation runs on wave 0 while the others solve hypotheses).
 // Summands are pre-rounded to 2^-34 so every summation order agrees.  Three sweeps of <= 18
 // accumulators keep the register footprint small; tri (45 doubles) is scratch for the triangle.
-template <bool LDS_PTS>
+template <int LDS_PTS>
 PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                     double* loA, double* tri, int lane) {
     uint32_t cnt = 0;
@@ -244,7 +251,7 @@ PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, co
 
 // Workgroup-cooperative variant (all NW wavefronts; two barriers): used for the FIRST refit after a
 // merge, where every wavefront is synchronised anyway.  partial: NW*45 doubles of dead scratch.
-template <bool LDS_PTS>
+template <int LDS_PTS>
 PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
                                   double* loA, double* partial, WgShared* sh, int tid) {
     const int lane = tid & 63, w = tid >> 6;
@@ -382,7 +389,7 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
 // workgroup barrier: normal matrix -> 9x9 Jacobi -> Nister back-end -> score the <= 10 roots.
 // Outputs the inlier count and the best refit model that beats `floor_score` (r_score = -1: none).
 // LDS: A, V and the triangle scratch alias wave 0's unused solver groups; the queue is wave 0's.
-template <bool LDS_PTS>
+template <int LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
                              float thr2, double* wscr0, WgShared* sh, int lane, int floor_score, uint32_t n_bar,
                              int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, int ni_pre = -1,
@@ -439,8 +446,8 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     return ni;
 }
 
-template <bool LDS_PTS, bool GUESS>
-__global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
+template <int LDS_PTS, bool GUESS>
+__global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t pair = blockIdx.x;
@@ -462,13 +469,14 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
     rows.lds = pts;
     rows.x1 = a.x1 + o; rows.y1 = a.y1 + o; rows.x2 = a.x2 + o; rows.y2 = a.y2 + o;
     rows.n = n;
+    rows.lds_n = LDS_PTS != 0 ? min(npad, a.pts_cap) : 0u;
 
     pgi_edge* edge = a.edges + pair;
     uint8_t* mask = a.masks + o;
     Prof prof;
     prof.start();
 
-    if (LDS_PTS && npad > a.pts_cap) {  // the caller's max_corr was too small: never overrun the LDS staging area
+    if (LDS_PTS == 1 && npad > a.pts_cap) {  // the caller's max_corr was too small: never overrun the LDS staging area
         for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
         if (tid == 0) {
             edge_clear(edge);
@@ -477,9 +485,9 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
         return;
     }
     // ---- stage the pair: coalesced SoA reads from HBM -> float4 rows in LDS ----
-    if constexpr (LDS_PTS) {
+    if constexpr (LDS_PTS != 0) {
         const float nanv = __builtin_nanf("");
-        for (uint32_t i = tid; i < npad; i += NT)
+        for (uint32_t i = tid; i < rows.lds_n; i += NT)
             pts[i] = (i < n) ? make_float4(rows.x1[i], rows.y1[i], rows.x2[i], rows.y2[i])
                              : make_float4(nanv, nanv, nanv, nanv);
     }
@@ -1006,14 +1014,14 @@ __global__ __launch_bounds__(NT, 3) void estimate_pose_kernel(const K1Args a) {
 
 // Size buckets: dynamic LDS is per launch, so ragged batches are split by row count and every bucket
 // is launched with the LDS (hence the occupancy) its pairs need.  caps[b] = largest row count of
-// bucket b (ascending); pairs above caps[2] go to bucket 3 (rows stay in HBM/L2).
+// bucket b (ascending: 4, 3, 2, 1 workgroups per CU); pairs above caps[3] go to bucket 4 (rows stay in HBM/L2).
 __global__ __launch_bounds__(256) void bucket_pairs_kernel(const uint64_t* __restrict__ off, uint32_t n_pairs, uint32_t cap0,
-                                                           uint32_t cap1, uint32_t cap2, uint32_t* __restrict__ lists,
+                                                           uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t* __restrict__ lists,
                                                            uint32_t* __restrict__ counts) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t n = (uint32_t)(off[p + 1] - off[p]);
-    const int b = n <= cap0 ? 0 : n <= cap1 ? 1 : n <= cap2 ? 2 : 3;
+    const int b = n <= cap0 ? 0 : n <= cap1 ? 1 : n <= cap2 ? 2 : n <= cap3 ? 3 : 4;
     const uint32_t i = atomicAdd(&counts[b], 1u);  // order inside a bucket is irrelevant: results are per pair
     lists[(size_t)b * n_pairs + i] = p;
 }
@@ -1311,9 +1319,12 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (cus > 0) c->resident_wgs = 3 * cus;
     // K1 may use the whole LDS of a CU for staged rows
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
+    if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
     return c;
@@ -1410,28 +1421,36 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
         const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
         return budget > fixed ? (uint32_t)(((budget - fixed) / 16) & ~(size_t)63) : 0u;
     };
-    const uint32_t cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
+    const uint32_t cap4 = rows_cap(4), cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
+    bool hybrid = false;
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + fixed;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<true, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<true, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+        if (hybrid) {  // first cap_rows rows in LDS, the tail from HBM/L2
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+        } else {
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+        }
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<false, true>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<false, false>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
-    // Rows are staged in LDS only while at least `lds_min_wgs` workgroups still fit per CU; bigger pairs read
-    // their rows from HBM/L2 at full occupancy instead (measured: faster than LDS at one workgroup per CU,
-    // scripts/lds_capacity_probe.py).  PGI_LDS_MIN_WGS overrides the default for experiments.
-    const uint32_t lds_cap = ctx->lds_min_wgs >= 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
-    if (cap <= cap3 || b->n_pairs < 64) {  // uniform enough (or tiny): one launch sized for the largest pair
+    // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
+    // cap4 rows run four workgroups per CU (+10-13 % over three), cap3 three, cap2 two.  Rows are staged in LDS only
+    // while at least `lds_min_wgs` workgroups still fit per CU; bigger pairs read their rows from HBM/L2 at full
+    // occupancy instead (measured: faster than LDS at one workgroup per CU, scripts/lds_capacity_probe.py).
+    // PGI_LDS_MIN_WGS overrides the default for experiments.
+    const uint32_t lds_cap = ctx->lds_min_wgs >= 4 ? cap4 : ctx->lds_min_wgs == 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
+    if (cap <= cap4 || b->n_pairs < 64) {  // every pair already gets the top occupancy (or the batch is tiny): one launch
         if (cap <= lds_cap) launch_lds(cap); else launch_global();
-    } else {  // ragged: bucket by row count on the device, one launch per occupancy class
+    } else {  // bucket by row count on the device, one launch per occupancy class
         if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
-        const size_t need = ((size_t)4 * b->n_pairs + 8) * sizeof(uint32_t);
+        const size_t need = ((size_t)5 * b->n_pairs + 8) * sizeof(uint32_t);
         if (need > *bucket_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (*bucket) (void)hipFree(*bucket);
@@ -1444,13 +1463,18 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
         uint32_t* lists = *bucket + 8;
         HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, stream, b->d_offsets,
-                           b->n_pairs, cap3, cap2, cap1, lists, counts);
-        const uint32_t caps[3] = {cap3, cap2, cap1};
-        for (int k = 0; k < 4; ++k) {
+                           b->n_pairs, cap4, cap3, cap2, cap1, lists, counts);
+        const uint32_t caps[4] = {cap4, cap3, cap2, cap1};
+        for (int k = 0; k < 5; ++k) {
             if (k > 0 && cap <= caps[k - 1]) break;  // no pair can be this large
             a.pair_list = lists + (size_t)k * b->n_pairs;
             a.pair_count = counts + k;
-            if (k < 3 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
+            // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
+            // from HBM/L2, which keeps four workgroups per CU instead of three
+            hybrid = k == 1 && ctx->hybrid_rows;
+            if (hybrid) launch_lds(cap4);
+            else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
+            hybrid = false;
         }
     }
     HIP_TRY(hipGetLastError());
