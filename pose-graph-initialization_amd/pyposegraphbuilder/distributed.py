@@ -56,14 +56,27 @@ class Communicator:
             transport = "rccl" if len(set(seen)) == self.world else "host"
         lib = L.load()
         if transport == "rccl":
-            ident = [None]
+            # Every step that can fail on one rank only is followed by an agreement round, so that the ranks either all
+            # hold a communicator or all raise (a rank that raises alone would leave the others blocked in a collective).
+            ident, err = [None], None
             if self.rank == 0:
                 buf = (C.c_uint8 * L.COMM_ID_BYTES)()
-                L.check(lib.pgi_comm_unique_id(buf))
-                ident = [bytes(buf)]
+                rc = lib.pgi_comm_unique_id(buf)
+                ident = [bytes(buf) if rc == 0 else None]
             dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if ident[0] is None:
+                raise L.PgiError("rank 0 could not create the RCCL unique id: " + (L.last_error() if self.rank == 0 else "see rank 0"))
             buf = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(ident[0])
-            L.check(lib.pgi_comm_init_rccl(engine._ctx, self.world, self.rank, buf))
+            rc = lib.pgi_comm_init_rccl(engine._ctx, self.world, self.rank, buf)
+            if rc != 0:
+                err = L.last_error()
+            oks = [None] * self.world
+            dist.all_gather_object(oks, rc == 0, group=group)
+            if not all(oks):
+                if rc == 0:
+                    lib.pgi_comm_destroy(engine._ctx)
+                raise L.PgiError("pgi_comm_init_rccl failed on rank(s) %s%s" % ([r for r, o in enumerate(oks) if not o],
+                                                                              ": " + err if err else ""))
         elif transport == "host":
             if dist.get_backend(group) != "gloo":
                 raise L.PgiError("host transport needs a gloo process group (ranks sharing a device cannot use RCCL)")
