@@ -221,18 +221,24 @@ def main():
         torch.cuda.synchronize()
         t_inc = time.perf_counter() - t0
         del db2
-        eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
-        t0 = time.perf_counter()
-        he, hm = eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
-        t_pipe = time.perf_counter() - t0
+        # (host-pointer runs need a few calls before slots, staging and page mappings are warm: 3 untimed, median of 5)
+        for _ in range(3):
+            eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
+        t_pipe = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            he, hm = eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
+            t_pipe.append(time.perf_counter() - t0)
+        t_pipe = float(np.median(t_pipe))
         # (iii) the same with page-locked caller buffers (hipHostMalloc, here through torch's pinned allocator): true
         # asynchronous DMA on dedicated high-priority copy streams
         px = [torch.from_numpy(np.ascontiguousarray(b[k], np.float32)).pin_memory().numpy() for k in ("x1", "y1", "x2", "y2")]
         pe = torch.zeros(P * EDGE_RECORD_BYTES, dtype=torch.uint8).pin_memory().numpy().view(L.EDGE_DTYPE)
         pm = torch.zeros(P * N, dtype=torch.uint8).pin_memory().numpy()
-        eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
+        for _ in range(4):
+            eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
         t_pin = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
             t_pin.append(time.perf_counter() - t0)
