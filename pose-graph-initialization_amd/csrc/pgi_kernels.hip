@@ -135,8 +135,14 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
         uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
         uint32_t alive = 0xFu;
         bool dead = false;
+        float4 pnext = rows.get(lane);
         for (uint32_t base = 0; base < npad; base += 64) {
-            const float4 p = rows.get(base + lane);
+            const float4 p = pnext;
+            if constexpr (LDS_PTS != 1) {  // rows that may come from HBM/L2: fetch the next 64 while these are scored
+                if (base + 64 < npad) pnext = rows.get(base + 64 + lane);
+            } else {
+                if (base + 64 < npad) pnext = rows.lds[base + 64 + lane];
+            }
             uint32_t c3v[4];
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
@@ -462,6 +468,9 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
     float4* pts = reinterpret_cast<float4*>(smem);
     double* wscr_all = reinterpret_cast<double*>(smem + (size_t)a.pts_cap * 16);  // NW * W_DOUBLES
     WgShared* sh = reinterpret_cast<WgShared*>(wscr_all + NW * W_DOUBLES);
+    // sample stash of the variants whose rows may live in HBM/L2 (NW * 4 groups * 5 rows), behind the shared state
+    float4* smp_stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(sh) + ((sizeof(WgShared) + 15) & ~(size_t)15));
+    (void)smp_stash;
     double* wscr = wscr_all + w * W_DOUBLES;
     float* queue = reinterpret_cast<float*>(wscr + W_REGA);  // overlays region A after each solve
 
@@ -765,9 +774,21 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
             nullspace5_group(mine, s, g * 16, gs);
             prof.mark<2>();
             float E32[9];
-            // the five sample rows are re-read from LDS for the orientation test (not kept in registers)
+            // The orientation test needs the five sample rows again.  Rows in LDS: re-read them (cheaper than keeping
+            // 20 registers live through the solve).  Rows that may sit in HBM/L2 (hybrid / global variants): the lanes
+            // that gathered them park them in a small LDS stash (sub-lane k of the group holds sample k) -- a second
+            // round trip to memory per root would cost far more.
+            if constexpr (LDS_PTS != 1) {
+                if (s < 5) smp_stash[(w * 4 + g) * 5 + s] = mine;
+                wave_sync();
+            }
             const bool valid = backend_group<false, 3, true>(
-                gs, s, g * 16, [&](int i) { return rows.get(idx[i]); }, E32, nullptr, prof);
+                gs, s, g * 16,
+                [&](int i) {
+                    if constexpr (LDS_PTS == 1) return rows.get(idx[i]);
+                    else return smp_stash[(w * 4 + g) * 5 + i];
+                },
+                E32, nullptr, prof);
             wave_sync();  // every group is done with region A: the queue may overlay it
             const int cnt = enqueue_models(valid && active, E32, hyp, queue, sh->q_hyp[w], ln);
             wave_sync();
@@ -1264,7 +1285,8 @@ std::string& last_error_ref() {
 }
 }  // namespace pgi
 
-static size_t k1_fixed_lds() { return (size_t)NW * W_DOUBLES * 8 + sizeof(WgShared) + 64; }
+constexpr size_t kStashBytes = (size_t)NW * 4 * 5 * sizeof(float4);  // 1280 B, variants 0 and 2 only
+static size_t k1_fixed_lds(bool stash) { return (size_t)NW * W_DOUBLES * 8 + sizeof(WgShared) + 64 + (stash ? kStashBytes : 0); }
 
 extern "C" {
 
@@ -1415,17 +1437,18 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.pair_list = nullptr;
     a.pair_count = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t fixed = k1_fixed_lds();
+    const size_t fixed = k1_fixed_lds(false), fixed_stash = k1_fixed_lds(true);
     const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
-    auto rows_cap = [&](int wgs_per_cu) {  // largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
+    auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) {  // largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
         const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
-        return budget > fixed ? (uint32_t)(((budget - fixed) / 16) & ~(size_t)63) : 0u;
+        return budget > fixed_bytes ? (uint32_t)(((budget - fixed_bytes) / 16) & ~(size_t)63) : 0u;
     };
+    auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
     const uint32_t cap4 = rows_cap(4), cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
     bool hybrid = false;
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
-        const size_t lds = (size_t)cap_rows * 16 + fixed;
+        const size_t lds = (size_t)cap_rows * 16 + (hybrid ? fixed_stash : fixed);
         if (hybrid) {  // first cap_rows rows in LDS, the tail from HBM/L2
             if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
             else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
@@ -1436,8 +1459,8 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed, stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed_stash, stream, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed_stash, stream, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
@@ -1472,7 +1495,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
             hybrid = k == 1 && ctx->hybrid_rows;
-            if (hybrid) launch_lds(cap4);
+            if (hybrid) launch_lds(rows_cap_of(4, fixed_stash));  // 1280 rows in LDS next to the sample stash
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;
         }

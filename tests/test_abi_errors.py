@@ -76,6 +76,15 @@ def test_bad_arguments_on_a_live_context(eng):
     assert lib.pgi_comm_init_host(ctx, 2, 2, L.ALLGATHERV_FN(lambda *a: 0), None) == PGI_ERR_INVALID
     w, r, k = C.c_uint32(9), C.c_uint32(9), C.c_uint32(9)
     assert lib.pgi_comm_info(ctx, C.byref(w), C.byref(r), C.byref(k)) == 0 and (w.value, r.value, k.value) == (1, 0, 0)
+    # guided matching: an output stride that cannot hold what a pair may return is refused, not silently clamped
+    fv = (L.FeatureView * 1)()
+    fv[0].d_xy, fv[0].d_desc, fv[0].n = buf.data_ptr(), buf.data_ptr(), 100
+    fv[0].fx = fv[0].fy = 1000.0
+    fv[0].cx, fv[0].cy, fv[0].width, fv[0].height = 800.0, 600.0, 1600.0, 1200.0
+    pose = np.r_[np.eye(3).ravel(), [1.0, 0.0, 0.0]]
+    assert lib.pgi_guided_match_batch(ctx, fv, fv, 1, pose.ctypes.data_as(C.c_void_p), 45, 0, 50, out, out, out, out) == PGI_ERR_INVALID
+    assert lib.pgi_guided_match_batch(ctx, fv, fv, 1, pose.ctypes.data_as(C.c_void_p), 45, 100, 50, out, out, out, out) == PGI_ERR_INVALID
+    assert b"out_stride" in lib.pgi_last_error()
     # the context still works afterwards
     from pyposegraphbuilder import synthetic as S
     p = S.make_pair(1, 300)
