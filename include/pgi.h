@@ -332,6 +332,45 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
                            uint32_t out_stride, uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio,
                            uint32_t* d_counts);
 
+/* ---- tracklets resident in HBM (reconstruction::Tracklets, point_track.h:541-711) ----
+ * The store behind "quick matching": add() grows multi-view tracks from the inlier matches of an
+ * estimated edge (:633-711); getCorrespondences() returns, for a later pair, the keypoints both views
+ * share a track with (:568-631).  Results are those of the reference applied one match at a time, in
+ * array order -- track indices, member order, the order of every view's track list and the reference's
+ * quirks included (oracle/tracklets_oracle.py) -- but the matches of a batch run concurrently wherever
+ * they do not share a keypoint.  View indices are < n_views; keypoint indices are any
+ * 32-bit value. */
+typedef struct pgi_tracklets pgi_tracklets;
+pgi_tracklets* pgi_tracklets_create(pgi_ctx* ctx, uint32_t n_views); /* NULL on failure (pgi_last_error) */
+void pgi_tracklets_destroy(pgi_tracklets* trk);                       /* before pgi_destroy of its context */
+/* One add() call of the reference (point_track.h:633-636): matches (d_src[i], d_dst[i]), i < *d_count
+ * (n_max when d_count is NULL), kept where d_mask[i] != 0 (all when d_mask is NULL).  Device pointers;
+ * the arrays are read while the call runs. */
+typedef struct {
+    uint32_t view_src, view_dst; /* imageIdxSource_, imageIdxDestination_ (must differ) */
+    uint32_t n_max;              /* capacity of the arrays                               */
+    uint32_t reserved;
+    const uint32_t* d_src;       /* keypoint index in the source view      */
+    const uint32_t* d_dst;       /* keypoint index in the destination view */
+    const uint8_t* d_mask;       /* inlierMask_, or NULL                   */
+    const uint32_t* d_count;     /* number of matches on the device, or NULL */
+} pgi_tracklet_pair;
+/* Applies h_pairs[0..n_pairs) in order.  Synchronous: the store is consistent on return. */
+int pgi_tracklets_add_batch(pgi_tracklets* trk, const pgi_tracklet_pair* h_pairs, uint32_t n_pairs);
+/* getCorrespondences for n_queries (source, destination) pairs: query q writes d_count[q] <= max_n + 1
+ * entries (the reference stops only after exceeding the maximum, :626-627) to d_src_idx / d_dst_idx
+ * at q * out_stride, in the order of the destination view's track list.  out_stride >= max_n + 1.
+ * Asynchronous on the stream. */
+int pgi_tracklets_get_batch(pgi_tracklets* trk, const uint32_t* h_view_src, const uint32_t* h_view_dst,
+                            uint32_t n_queries, uint32_t max_n, uint32_t out_stride, uint32_t* d_src_idx,
+                            uint32_t* d_dst_idx, uint32_t* d_count);
+/* Tracks, events (members over all tracks) and the number of launches the last add_batch needed. */
+int pgi_tracklets_info(const pgi_tracklets* trk, uint64_t* n_tracks, uint64_t* n_events, uint32_t* last_rounds);
+/* Members of one track in insertion order as (view << 32 | keypoint); *n_members is the full count,
+ * at most `capacity` are written to the HOST array h_members. */
+int pgi_tracklets_track(pgi_tracklets* trk, uint64_t index, uint64_t* h_members, uint32_t capacity,
+                        uint32_t* n_members);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,7 +371,16 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     });
     VisibilityTable visibilityTable(V);  // :366-367
     for (const EdgeId& id : poseGraph_.getEdgeIds()) visibilityTable.addLink(id.first, id.second);
-    Tracklets tracks(V);                 // :388
+    Tracklets tracks(V);                 // :388; host store, used only when the device store is switched off
+    struct DeviceStore {                 // pgi_tracklets_* (csrc/pgi_tracklets.hip): the same bookkeeping in HBM
+        pgi_tracklets* t = nullptr;
+        ~DeviceStore() { pgi_tracklets_destroy(t); }
+    } store;
+    const bool deviceTracks = deviceTracklets && kUseEpipolarHashing;
+    if (deviceTracks) {
+        store.t = pgi_tracklets_create(ctx, (uint32_t)std::max<size_t>(V, 1));
+        if (!store.t) throw PgiError(pgi_last_error());
+    }
     const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
     uint64_t seed = 0;
     typedef std::vector<Tracklets::Match> Matches;
@@ -384,16 +393,44 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         Clock::time_point tick = Clock::now();
         // (1) quick matching from tracklets for pairs the graph already connects (:493-518)
         std::vector<Matches> matches(P);
+        std::vector<size_t> matchCount(P, 0);  // matches[i].size() where the list itself never reaches the host
         std::vector<char> quick(P, 0), visible(P, 0), fromHost(P, 0);
+        for (size_t i = 0; i < P; ++i) visible[i] = visibilityTable.hasLink(wave[i].src, wave[i].dst);
+        // device store: one batched query for every visible pair; the rows stay in HBM
+        const uint32_t qstride = (uint32_t)kMaximumTrackletNumber + 1;
+        std::vector<size_t> queryOf(P, (size_t)-1);
+        std::vector<uint32_t> qcnt;
+        std::unique_ptr<DevBuf> qsrc, qdst, qcntDev;
+        if (deviceTracks) {
+            std::vector<uint32_t> qs, qd;
+            for (size_t i = 0; i < P; ++i)
+                if (visible[i]) { queryOf[i] = qs.size(); qs.push_back((uint32_t)wave[i].src); qd.push_back((uint32_t)wave[i].dst); }
+            if (!qs.empty()) {
+                const size_t Q = qs.size();
+                qsrc.reset(new DevBuf(Q * (size_t)qstride * 4));
+                qdst.reset(new DevBuf(Q * (size_t)qstride * 4));
+                qcntDev.reset(new DevBuf(Q * 4));
+                Engine::check(pgi_tracklets_get_batch(store.t, qs.data(), qd.data(), (uint32_t)Q, (uint32_t)kMaximumTrackletNumber, qstride,
+                                                      qsrc->as<uint32_t>(), qdst->as<uint32_t>(), qcntDev->as<uint32_t>()));
+                Engine::check(pgi_synchronize(ctx));
+                qcnt.resize(Q);
+                d2h(qcnt.data(), qcntDev->p, Q * 4);
+            }
+        }
         for (size_t i = 0; i < P; ++i) {
-            visible[i] = visibilityTable.hasLink(wave[i].src, wave[i].dst);
             if (kUseEpipolarHashing && visible[i]) {
-                tracks.getCorrespondences(matches[i], wave[i].src, wave[i].dst, kMaximumTrackletNumber);
-                if (matches[i].size() < kMinimumInlierNumber) matches[i].clear();
+                if (deviceTracks) {
+                    matchCount[i] = qcnt[queryOf[i]];
+                } else {
+                    tracks.getCorrespondences(matches[i], wave[i].src, wave[i].dst, kMaximumTrackletNumber);
+                    matchCount[i] = matches[i].size();
+                }
+                if (matchCount[i] < kMinimumInlierNumber) { matches[i].clear(); matchCount[i] = 0; }
                 else { quick[i] = fromHost[i] = 1; ++st.quickMatchingRuns; }
             }
             if (!quick[i] && cachedMatches && (*cachedMatches)(wave[i].src, wave[i].dst, matches[i])) {  // feature_utils.h:115-133
                 fromHost[i] = 1;
+                matchCount[i] = matches[i].size();
                 ++st.cachedMatchLoads;
             }
         }
@@ -414,7 +451,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         uint32_t mm = 1;
         for (size_t k = 0; k < P; ++k) {
             const size_t i = order[k];
-            mm = std::max(mm, fromHost[i] ? (uint32_t)matches[i].size() : (uint32_t)views[wave[i].src].size());
+            mm = std::max(mm, fromHost[i] ? (uint32_t)matchCount[i] : (uint32_t)views[wave[i].src].size());
         }
         DevBuf dsrc(P * (size_t)mm * 4), ddst(P * (size_t)mm * 4), dratio(P * (size_t)mm * 8), dcnt(P * 4);
         std::vector<uint32_t> hsrc(P * (size_t)mm), hdst(P * (size_t)mm), hcnt(P, 0);
@@ -426,13 +463,16 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                                                       dratio.as<double>(), dcnt.as<uint32_t>()));
             Engine::check(pgi_synchronize(ctx));
             d2h(hcnt.data(), dcnt.p, Pn * 4);
-            d2h(hsrc.data(), dsrc.p, Pn * (size_t)mm * 4);
-            d2h(hdst.data(), ddst.p, Pn * (size_t)mm * 4);
             st.matchingRuns += Pn;
-            for (size_t k = 0; k < Pn; ++k) {
-                Matches& m = matches[order[k]];
-                m.resize(hcnt[k]);
-                for (uint32_t q = 0; q < hcnt[k]; ++q) m[q] = Tracklets::Match(hsrc[k * (size_t)mm + q], hdst[k * (size_t)mm + q], 0.0);
+            for (size_t k = 0; k < Pn; ++k) matchCount[order[k]] = hcnt[k];
+            if (kUseEpipolarHashing && !deviceTracks) {  // the host store consumes the match lists themselves
+                d2h(hsrc.data(), dsrc.p, Pn * (size_t)mm * 4);
+                d2h(hdst.data(), ddst.p, Pn * (size_t)mm * 4);
+                for (size_t k = 0; k < Pn; ++k) {
+                    Matches& m = matches[order[k]];
+                    m.resize(hcnt[k]);
+                    for (uint32_t q = 0; q < hcnt[k]; ++q) m[q] = Tracklets::Match(hsrc[k * (size_t)mm + q], hdst[k * (size_t)mm + q], 0.0);
+                }
             }
         }
         {   // :545-546
@@ -441,9 +481,21 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             if (Pn) { statistics.addTime("[Matching]", dt, Pn); statistics.addCount("[Matching] Runs", Pn, Pn); }
         }
         tick = Clock::now();
-        for (size_t k = Pn; k < P; ++k) {  // tracklet matches join the same device layout
-            const Matches& m = matches[order[k]];
-            hcnt[k] = (uint32_t)m.size();
+        bool hostRows = false;
+        for (size_t k = Pn; k < P; ++k) {  // tracklet / cached matches join the same device layout
+            const size_t i = order[k];
+            hcnt[k] = (uint32_t)matchCount[i];
+            if (deviceTracks && quick[i]) {  // rows of the batched query: device to device
+                const size_t q = queryOf[i];
+                if (hipMemcpyAsync((uint32_t*)dsrc.p + k * (size_t)mm, qsrc->as<uint32_t>() + q * (size_t)qstride, (size_t)hcnt[k] * 4,
+                                   hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+                    hipMemcpyAsync((uint32_t*)ddst.p + k * (size_t)mm, qdst->as<uint32_t>() + q * (size_t)qstride, (size_t)hcnt[k] * 4,
+                                   hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
+                    throw PgiError("hipMemcpy D2D failed");
+                continue;
+            }
+            const Matches& m = matches[i];
+            hostRows = true;
             for (size_t q = 0; q < m.size(); ++q) {
                 hsrc[k * (size_t)mm + q] = (uint32_t)std::get<0>(m[q]);
                 hdst[k * (size_t)mm + q] = (uint32_t)std::get<1>(m[q]);
@@ -452,9 +504,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         std::vector<char> skipped(P, 0);
         for (size_t k = 0; k < P; ++k)
             if (hcnt[k] < kMinimumPointNumber) { skipped[k] = 1; hcnt[k] = 0; ++st.tooFewMatches; }  // :550-551 `continue`
-        if (P > Pn) {
-            h2d((char*)dsrc.p + Pn * (size_t)mm * 4, hsrc.data() + Pn * (size_t)mm, (P - Pn) * (size_t)mm * 4);
-            h2d((char*)ddst.p + Pn * (size_t)mm * 4, hdst.data() + Pn * (size_t)mm, (P - Pn) * (size_t)mm * 4);
+        if (hostRows) {
+            for (size_t k = Pn; k < P; ++k) {
+                if (deviceTracks && quick[order[k]]) continue;
+                h2d((uint32_t*)dsrc.p + k * (size_t)mm, hsrc.data() + k * (size_t)mm, (size_t)matchCount[order[k]] * 4);
+                h2d((uint32_t*)ddst.p + k * (size_t)mm, hdst.data() + k * (size_t)mm, (size_t)matchCount[order[k]] * 4);
+            }
         }
         h2d(dcnt.p, hcnt.data(), P * 4);
         // (3) createCorrespondenceMatrix on the device (:553-565)
@@ -577,16 +632,21 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         const uint32_t gstride = (uint32_t)std::max<size_t>(1, kMaximumPointNumberForEpipolarHashing);
         constexpr uint32_t kEpipolarBins = 45;  // HashingBasedMatcherWithPose<false, 45> (pose_graph_builder.h:738)
         std::vector<uint32_t> gsrc, gdst, gcnt;
+        std::unique_ptr<DevBuf> ds, dd, dr, dc;
         if (!guidedOf.empty()) {
             const size_t G = guidedOf.size();
-            DevBuf ds(G * (size_t)gstride * 4), dd(G * (size_t)gstride * 4), dr(G * (size_t)gstride * 8), dc(G * 4);
-            Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds.as<uint32_t>(),
-                                                 dd.as<uint32_t>(), dr.as<double>(), dc.as<uint32_t>()));
+            ds.reset(new DevBuf(G * (size_t)gstride * 4)); dd.reset(new DevBuf(G * (size_t)gstride * 4));
+            dr.reset(new DevBuf(G * (size_t)gstride * 8)); dc.reset(new DevBuf(G * 4));
+            Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds->as<uint32_t>(),
+                                                 dd->as<uint32_t>(), dr->as<double>(), dc->as<uint32_t>()));
             Engine::check(pgi_synchronize(ctx));
-            gsrc.resize(G * (size_t)gstride); gdst.resize(G * (size_t)gstride); gcnt.resize(G);
-            d2h(gsrc.data(), ds.p, gsrc.size() * 4);
-            d2h(gdst.data(), dd.p, gdst.size() * 4);
-            d2h(gcnt.data(), dc.p, G * 4);
+            gcnt.resize(G);
+            d2h(gcnt.data(), dc->p, G * 4);
+            if (!deviceTracks) {
+                gsrc.resize(G * (size_t)gstride); gdst.resize(G * (size_t)gstride);
+                d2h(gsrc.data(), ds->p, gsrc.size() * 4);
+                d2h(gdst.data(), dd->p, gdst.size() * 4);
+            }
             st.guidedMatchingRuns += G;
         }
         {   // :684-686
@@ -606,6 +666,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
         std::vector<size_t> guidedSlot(P, (size_t)-1);
         for (size_t q = 0; q < guidedOf.size(); ++q) guidedSlot[guidedOf[q]] = q;
+        std::vector<pgi_tracklet_pair> adds;
         for (size_t i = 0; i < P; ++i) {
             const size_t k = slotOf[i];
             ++st.pairsProcessed;
@@ -618,11 +679,28 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
             poseGraph_.addVertex(wave[i].src);
             poseGraph_.addVertex(wave[i].dst);
-            poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matches[i].size());
+            poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matchCount[i]);
             ++st.edgesAdded;
             visibilityTable.addLink(wave[i].src, wave[i].dst);
             if (!kUseEpipolarHashing) continue;
-            if (quick[i]) {
+            if (deviceTracks) {  // the add() calls of the wave, in commit order, straight from the device rows
+                pgi_tracklet_pair a{};
+                a.view_src = (uint32_t)wave[i].src;
+                a.view_dst = (uint32_t)wave[i].dst;
+                if (quick[i]) {
+                    const size_t q = guidedSlot[k];
+                    a.n_max = gcnt[q];
+                    a.d_src = ds->as<uint32_t>() + q * (size_t)gstride;
+                    a.d_dst = dd->as<uint32_t>() + q * (size_t)gstride;
+                    st.guidedMatchesAdded += gcnt[q];
+                } else {
+                    a.n_max = hcnt[k];
+                    a.d_src = dsrc.as<uint32_t>() + k * (size_t)mm;
+                    a.d_dst = ddst.as<uint32_t>() + k * (size_t)mm;
+                    a.d_mask = dmasks.as<uint8_t>() + off[k];
+                }
+                adds.push_back(a);
+            } else if (quick[i]) {
                 const size_t q = guidedSlot[k];
                 Matches extra(gcnt[q]);
                 for (uint32_t r = 0; r < gcnt[q]; ++r) extra[r] = Tracklets::Match(gsrc[q * (size_t)gstride + r], gdst[q * (size_t)gstride + r], 0.0);
@@ -633,6 +711,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 tracks.add(wave[i].src, wave[i].dst, matches[i], mask);
             }
         }
+        if (!adds.empty()) Engine::check(pgi_tracklets_add_batch(store.t, adds.data(), (uint32_t)adds.size()));
         {   // :698-699 (the commit loop holds the visibility update)
             const double dt = since(tick);
             st.secTrackUpdate += dt;
@@ -652,6 +731,11 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     }
     processWave(wave);
     st.trackNumber = tracks.trackNumber();
+    if (deviceTracks) {
+        uint64_t n = 0;
+        Engine::check(pgi_tracklets_info(store.t, &n, nullptr, nullptr));
+        st.trackNumber = (size_t)n;
+    }
     return st;
 }
 

@@ -452,7 +452,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // connects (:493-518), descriptor matching for the rest (:521-546), createCorrespondenceMatrix (:553-565), A*
     // pose guesses (:568-599), estimatePose (:616-627), edge + visibility update (:645-654, :692), guided matching
     // and tracklet update (:657-709).  Matching, correspondence building, guess screening, pose estimation and guided
-    // matching are one device launch sequence per wave; tracklets, A* and the graph stay on the host.
+    // matching and the tracklet store are device launch sequences per wave; A* and the graph stay on the host.
     // cachedMatches (optional): the correspondences.h5 lookup of matchFeatures (feature_utils.h:113-133) -- returns
     // true and fills the (src index, dst index, ratio) list when the pair's matches are already known.
     typedef std::function<bool(ViewId, ViewId, std::vector<std::tuple<size_t, size_t, double>>&)> MatchLookup;
@@ -476,6 +476,8 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
         Engine::check(pgi_set_params(engine->get(), &p));
         rotationGuidedGuesses = on;
     }
+    // tracklets in HBM (pgi_tracklets_*, the default) or in the host store (host/tracklets.hpp); same results
+    void setDeviceTracklets(bool on) { deviceTracklets = on; }
     // one process per GPU: the host-side channel of this rank (also install the engine's transport: dist::attach)
     void setHostComm(dist::HostComm* comm) { hostComm = comm; }
     uint32_t worldSize() const;
@@ -485,6 +487,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     RunningStatistics statistics;
     dist::HostComm* hostComm = nullptr;
     bool rotationGuidedGuesses = false;
+    bool deviceTracklets = true;
     const size_t kCoreNumber, kMinimumInlierNumber, kMinimumPointNumber, kMaximumPointNumberForEpipolarHashing,
         kMaximumSearchDepth, kMaximumPathNumber, kMaximumTrackletNumber;
     const std::string kImagePath, kWorkspacePath, kSimilarityGraphPath, kFocalLengthPath;

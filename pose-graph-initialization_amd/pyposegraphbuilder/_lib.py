@@ -54,7 +54,9 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
            "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch",
            "pgi_get_params", "pgi_rotation_average_edges", "pgi_comm_unique_id", "pgi_comm_init_rccl", "pgi_comm_init_host",
-           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv", "pgi_host_register", "pgi_host_unregister"]
+           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv", "pgi_host_register", "pgi_host_unregister",
+           "pgi_tracklets_create", "pgi_tracklets_destroy", "pgi_tracklets_add_batch", "pgi_tracklets_get_batch",
+           "pgi_tracklets_info", "pgi_tracklets_track"]
 COMM_ID_BYTES = 128
 # pgi_allgatherv_fn: int (*)(void* user, const void* send, uint64 send_bytes, void* recv, const uint64* recv_bytes, uint32 world)
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
@@ -72,6 +74,12 @@ class KeypointView(C.Structure):
     """pgi_keypoint_view (include/pgi.h)."""
     _fields_ = [("d_xy", C.c_void_p), ("n", C.c_uint32), ("reserved", C.c_uint32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+class TrackletPair(C.Structure):
+    """pgi_tracklet_pair (include/pgi.h)."""
+    _fields_ = [("view_src", C.c_uint32), ("view_dst", C.c_uint32), ("n_max", C.c_uint32), ("reserved", C.c_uint32),
+                ("d_src", C.c_void_p), ("d_dst", C.c_void_p), ("d_mask", C.c_void_p), ("d_count", C.c_void_p)]
 
 
 class FeatureView(C.Structure):
@@ -117,6 +125,15 @@ def load():
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]
     lib.pgi_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    lib.pgi_tracklets_create.restype = C.c_void_p
+    lib.pgi_tracklets_create.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pgi_tracklets_destroy.restype = None
+    lib.pgi_tracklets_destroy.argtypes = [C.c_void_p]
+    lib.pgi_tracklets_add_batch.argtypes = [C.c_void_p, C.POINTER(TrackletPair), C.c_uint32]
+    lib.pgi_tracklets_get_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+    lib.pgi_tracklets_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.pgi_tracklets_track.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pgi_host_register.argtypes = [C.c_void_p, C.c_uint64]
     lib.pgi_host_unregister.argtypes = [C.c_void_p]
     lib.pgi_rotation_average_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

@@ -365,3 +365,81 @@ class Engine:
             None if g is None else g.ctypes.data_as(C.c_void_p), 0 if g is None else len(g), int(min_inliers),
             int(seed), int(pair_id), C.byref(e), mask.ctypes.data_as(C.c_void_p)))
         return bool(rc), e, mask[:len(c)]
+
+
+class DeviceTracklets:
+    """reconstruction::Tracklets (point_track.h:541-711) resident in HBM: pgi_tracklets_* of include/pgi.h.
+    add() takes one or many (src view, dst view, matches, mask) calls and applies them in order."""
+
+    def __init__(self, engine, n_views):
+        self.eng, self._lib = engine, engine._lib
+        self._t = self._lib.pgi_tracklets_create(engine._ctx, int(n_views))
+        if not self._t:
+            raise L.PgiError("pgi_tracklets_create failed: " + L.last_error())
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._lib.pgi_tracklets_destroy(self._t)
+            self._t = None
+
+    __del__ = close
+
+    def add_batch(self, calls):
+        """calls: [(src, dst, matches (m x 2 integer array-like or a pair of device int32 tensors), mask or None)]."""
+        dev = self.eng.device
+        n = len(calls)
+        arr = (L.TrackletPair * max(n, 1))()
+        keep = []
+        for i, (s, d, m, mask) in enumerate(calls):
+            if isinstance(m, tuple) and torch.is_tensor(m[0]):
+                ts, td = m
+            else:
+                mm = np.asarray(m, np.int64).reshape(-1, 2)
+                ts = torch.as_tensor(mm[:, 0].astype(np.int32)).to(dev)
+                td = torch.as_tensor(mm[:, 1].astype(np.int32)).to(dev)
+            tm = None
+            if mask is not None:
+                tm = mask if torch.is_tensor(mask) else torch.as_tensor(np.asarray(mask, np.uint8)).to(dev)
+            keep += [ts, td, tm]
+            arr[i].view_src, arr[i].view_dst, arr[i].n_max = int(s), int(d), int(ts.numel())
+            arr[i].d_src = ts.data_ptr() if ts.numel() else None
+            arr[i].d_dst = td.data_ptr() if td.numel() else None
+            arr[i].d_mask = tm.data_ptr() if tm is not None and tm.numel() else None
+            arr[i].d_count = None
+        self.eng._bind_stream()
+        L.check(self._lib.pgi_tracklets_add_batch(self._t, arr, n))
+
+    def add(self, src, dst, matches, mask=None):
+        self.add_batch([(src, dst, matches, mask)])
+
+    def get_correspondences_batch(self, queries, max_n, raw=False):
+        """[(src view, dst view)] -> per query an (m x 2) array of (source keypoint, destination keypoint)."""
+        q = np.asarray(queries, np.uint32).reshape(-1, 2)
+        n, stride = len(q), int(max_n) + 1
+        vs, vd = np.ascontiguousarray(q[:, 0]), np.ascontiguousarray(q[:, 1])
+        dev = self.eng.device
+        src = torch.empty((max(n, 1), stride), dtype=torch.int32, device=dev)
+        dst = torch.empty_like(src)
+        cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.eng._bind_stream()
+        L.check(self._lib.pgi_tracklets_get_batch(self._t, vs.ctypes.data_as(C.c_void_p), vd.ctypes.data_as(C.c_void_p), n, int(max_n), stride,
+                                                  _ptr(src), _ptr(dst), _ptr(cnt)))
+        if raw:
+            return src, dst, cnt
+        c, s_h, d_h = cnt.cpu().numpy(), src.cpu().numpy(), dst.cpu().numpy()
+        return [np.stack([s_h[i, :c[i]], d_h[i, :c[i]]], 1).astype(np.int64) for i in range(n)]
+
+    def get_correspondences(self, src, dst, max_n):
+        return self.get_correspondences_batch([(src, dst)], max_n)[0]
+
+    def info(self):
+        a, b, r = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        L.check(self._lib.pgi_tracklets_info(self._t, C.byref(a), C.byref(b), C.byref(r)))
+        return {"tracks": a.value, "events": b.value, "rounds": r.value}
+
+    def track(self, index):
+        n = C.c_uint32()
+        L.check(self._lib.pgi_tracklets_track(self._t, int(index), None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), np.uint64)
+        L.check(self._lib.pgi_tracklets_track(self._t, int(index), buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return [(int(k >> np.uint64(32)), int(k & np.uint64(0xFFFFFFFF))) for k in buf[:n.value]]

@@ -1,6 +1,7 @@
 // Feature-level pipeline on the GPU: reads views (keypoints, descriptors, camera), candidate pairs and a similarity
-// matrix written by tests/test_feature_pipeline.py, runs PoseGraphBuilder::processFeatures in three configurations
-// (plain; + path finding; + path finding + epipolar hashing/tracklets) and writes statistics + edges.
+// matrix written by tests/test_feature_pipeline.py, runs PoseGraphBuilder::processFeatures in four configurations
+// (plain; + path finding; + path finding + epipolar hashing/tracklets in HBM; the same with the host tracklet store) and
+// writes statistics + edges.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -40,10 +41,11 @@ int main(int argc, char** argv) {
     }
     if (!in) return 3;
     std::ofstream out(argv[2], std::ios::binary);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {  // mode 3 = mode 2 with the tracklets in the host store instead of HBM
         const bool usePath = mode >= 1, useHashing = mode >= 2;
         // thresholds as in examples/cpp_example.cpp: 20 inliers, 50 points, 100 guided matches, 0.75 px
         PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.75, "", "", "", "", usePath, true, useHashing);
+        builder.setDeviceTracklets(mode != 3);
         PoseGraph graph;
         auto cand = pairs;
         const auto t0 = std::chrono::steady_clock::now();

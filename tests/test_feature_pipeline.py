@@ -31,7 +31,7 @@ def make_scene():
 
 def parse(buf):
     pos, res = 0, []
-    for _ in range(3):
+    for _ in range(4):
         st = struct.unpack_from("<16Q", buf, pos)
         pos += 128
         edges = {}
@@ -62,7 +62,11 @@ def test_feature_pipeline_three_configurations(tmp_path):
             f.write(struct.pack("<IId", i, j, s))
     r = subprocess.run([EXE, fin, fout], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr
-    (st0, e0), (st1, e1), (st2, e2) = parse(open(fout, "rb").read())
+    (st0, e0), (st1, e1), (st2, e2), (st3, e3) = parse(open(fout, "rb").read())
+    # tracklets in HBM (mode 2) and in the host store (mode 3) are the same bookkeeping: every counter and edge agrees
+    assert st2 == st3 and e2.keys() == e3.keys()
+    for key in e2:
+        assert e2[key][0] == e3[key][0] and np.array_equal(e2[key][1], e3[key][1]) and np.array_equal(e2[key][2], e3[key][2])
     for mode, (st, edges) in enumerate(((st0, e0), (st1, e1), (st2, e2))):
         assert st[0] == len(pairs) and st[1] == st[8] == len(edges) and st[1] >= 0.95 * len(pairs)
         err, tcos = [], []
