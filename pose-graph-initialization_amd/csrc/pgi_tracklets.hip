@@ -25,6 +25,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,8 +40,7 @@
 
 namespace {
 
-constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr int kSubBits = 12;  // events per match < 4096
+constexpr int kSubBits = 16;  // events per match < 65535
 constexpr int NT = 256;
 
 struct DevBuf {
@@ -76,7 +78,7 @@ struct DeviceState {       // lives in device memory, mirrored to the host betwe
     uint32_t n_new;        // events written by the running batch
     uint32_t n_done;       // matches finished
     uint32_t overflow;     // bit 0: event buffer full, bit 1: more than 4095 events in one match
-    uint32_t n_new_tracks;
+    uint32_t n_valid;      // valid events among the reserved slots (set after the rounds)
 };
 
 }  // namespace
@@ -97,9 +99,10 @@ struct pgi_tracklets {
     DevBuf sort_tmp, a64, b64, a32, b32, c32, d32;
     DevBuf pairs, pair_off;
     DevBuf keyS, keyD, segS, segD, rankS, rankD, done, newflag, newrank;
-    DevBuf seg_lo, seg_hi, seg_head, seg_last, seg_cnt, cursor;
-    DevBuf nev_track, nev_key, nev_seq, nev_next;
+    DevBuf seg_lo, seg_hi, seg_cnt, cursor, run_start, run_len;
+    DevBuf nev_track, nev_key, nev_seq;
     size_t nev_cap = 0;
+    double slots_per_match = 0;  // of the last batch: sizes the next batch's event buffer
     uint32_t last_rounds = 0;
 };
 
@@ -113,11 +116,10 @@ struct PairDesc {
     const uint32_t* d_count;
 };
 
-__device__ inline uint32_t load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // block-wide exclusive prefix of a flag, in thread order; returns the block total through `total`
-__device__ inline uint32_t block_rank(bool flag, uint32_t* wave_tot /* NT/64 + 1 words of LDS */, uint32_t& total) {
+template <int WAVES = NT / 64>
+__device__ inline uint32_t block_rank(bool flag, uint32_t* wave_tot /* WAVES + 1 words of LDS */, uint32_t& total) {
     const uint64_t m = __ballot(flag);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -125,7 +127,7 @@ __device__ inline uint32_t block_rank(bool flag, uint32_t* wave_tot /* NT/64 + 1
     if (lane == 0) wave_tot[w] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t before = 0, all = 0;
-    for (int i = 0; i < NT / 64; ++i) {
+    for (int i = 0; i < WAVES; ++i) {
         const uint32_t t = wave_tot[i];
         if (i < w) before += t;
         all += t;
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(NT) trk_pair_scan_kernel(const uint32_t* valid
         st->n_new = 0;
         st->n_done = 0;
         st->overflow = 0;
-        st->n_new_tracks = 0;
+        st->n_valid = 0;
     }
 }
 
@@ -264,99 +266,235 @@ struct RoundArgs {
     const uint32_t *segS, *segD, *rankS, *rankD;
     uint8_t* done;
     uint32_t* newflag;
-    const uint32_t *seg_lo, *seg_hi;
-    uint32_t *seg_head, *seg_last, *seg_cnt, *cursor;
-    const uint32_t* pt_track;  // committed lists
-    uint32_t *nev_track, *nev_next;
+    const uint32_t *seg_start, *seg_lo, *seg_hi;
+    uint32_t* seg_cnt;
+    uint64_t* cursor;               // per point: (launch that wrote it) << 32 | matches of the batch it has seen
+    uint32_t *run_start, *run_len;  // per (point, match) incidence of the batch, in the sorted entry order
+    const uint32_t* pt_track;       // committed lists
+    uint32_t* nev_track;
     uint64_t *nev_key, *nev_seq;
     uint32_t nev_cap, n_matches, track_base;
-    int first_ever;  // the store was empty when the batch started
+    uint32_t list_cap;  // entries per staged list (kListCap or kListCapHuge)
+    uint32_t launch;    // 1, 2, ... within the batch
+    int first_ever;   // the store was empty when the batch started
 };
 
-// a point's track list: committed part [lo, hi) of pt_track, then `cnt` cells of this batch chained from `head`;
-// `skip` drops the very first entry (the forgotten first track of the first point ever registered)
-struct PointList {
-    uint32_t lo, hi, head, cnt;
-    bool skip;
-};
+// tracks per point a wavefront stages in LDS: the usual configuration (four wavefronts per workgroup), and the one the
+// host falls back to for the rest of a batch once a longer list shows up (one wavefront per workgroup, 128 KB of LDS)
+constexpr uint32_t kListCap = 1024, kListCapHuge = 16384;
 
-template <class F>
-__device__ inline void for_each_track(const RoundArgs& a, const PointList& l, F f) {
-    bool skip = l.skip;
-    for (uint32_t i = l.lo; i < l.hi; ++i) {
-        if (skip) { skip = false; continue; }
-        f(a.pt_track[i]);
-    }
-    uint32_t c = l.head;
-    for (uint32_t i = 0; i < l.cnt; ++i, c = a.nev_next[c]) {
-        if (skip) { skip = false; continue; }
-        f(a.nev_track[c]);
-    }
-}
-__device__ inline bool list_holds(const RoundArgs& a, const PointList& l, uint32_t track) {
-    bool found = false;
-    for_each_track(a, l, [&](uint32_t t) { found |= (t == track); });
-    return found;
+__device__ inline void wave_sync() {  // DS operations of one wavefront execute in order: only the compiler needs a fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (5) one lane per match; runs it if both its points are ready for it
-__global__ void __launch_bounds__(NT) trk_round_kernel(RoundArgs a) {
-    const uint32_t k = blockIdx.x * NT + threadIdx.x;
-    if (k >= a.n_matches || a.done[k]) return;
-    const uint32_t sS = a.segS[k], sD = a.segD[k], rS = a.rankS[k], rD = a.rankD[k];
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        if (load_acquire(&a.cursor[sS]) != rS || load_acquire(&a.cursor[sD]) != rD) continue;
-        const uint64_t kS = a.keyS[k], kD = a.keyD[k];
-        // the id-0 quirk (point_track.h:651-657)
-        uint32_t phase = a.st->qphase;
-        uint64_t qkey = a.st->qkey;
-        if (a.first_ever && k == 0) {
-            a.st->qkey = qkey = kS;
-            a.st->qphase = phase = 1;
-        } else if (phase == 1 && (kS == qkey || kD == qkey)) {
-            a.st->qphase = phase = 2;
+// Stages a point's track list in LDS: the committed part [lo, hi) of pt_track, then the runs appended by the `rank`
+// lower-ranked matches of the batch (their descriptors sit side by side in the run directory, so neither the directory
+// nor the runs are chased: every lane takes one run).  Returns the length, or cap + 1 if it does not fit.
+__device__ inline uint32_t stage_list(const RoundArgs& a, uint32_t seg, uint32_t rank, uint32_t* lds, int lane, uint32_t cap) {
+    const uint32_t lo = a.seg_lo[seg], n_old = a.seg_hi[seg] - lo, d0 = a.seg_start[seg];
+    if (n_old > cap) return cap + 1;
+    for (uint32_t i = lane; i < n_old; i += 64) lds[i] = a.pt_track[lo + i];
+    uint32_t pos = n_old;
+    for (uint32_t r0 = 0; r0 < rank; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        uint32_t start = 0, len = 0;
+        if (r < rank) { start = a.run_start[d0 + r]; len = a.run_len[d0 + r]; }
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
         }
-        const bool qS = phase == 2 && kS == qkey, qD = phase == 2 && kD == qkey;
-        const PointList LS{a.seg_lo[sS], a.seg_hi[sS], a.seg_head[sS], a.seg_cnt[sS], qS};
-        const PointList LD{a.seg_lo[sD], a.seg_hi[sD], a.seg_head[sD], a.seg_cnt[sD], qD};
-        uint32_t sub = 0;
-        auto emit = [&](uint32_t track, uint64_t key, uint32_t seg) {
-            const uint32_t e = atomicAdd(&a.st->n_new, 1u);
-            if (e >= a.nev_cap) { atomicOr(&a.st->overflow, 1u); return; }
-            if (sub >= (1u << kSubBits)) { atomicOr(&a.st->overflow, 2u); return; }
-            a.nev_track[e] = track;
-            a.nev_key[e] = key;
-            a.nev_seq[e] = ((uint64_t)k << kSubBits) | sub++;
-            a.nev_next[e] = kNone;
-            const uint32_t c = a.seg_cnt[seg];
-            if (c == 0) a.seg_head[seg] = e; else a.nev_next[a.seg_last[seg]] = e;
-            a.seg_last[seg] = e;
-            a.seg_cnt[seg] = c + 1;
-        };
-        // every track of the source point learns the destination point (point_track.h:664-681) ...
-        for_each_track(a, LS, [&](uint32_t t) {
-            if (list_holds(a, LD, t) || (qD && t == 0)) return;
-            emit(t, kD, sD);
-        });
-        // ... and every earlier track of the destination point learns the source point (:683-699)
-        for_each_track(a, LD, [&](uint32_t t) {
-            if (list_holds(a, LS, t) || (qS && t == 0)) return;
-            emit(t, kS, sS);
-        });
-        if (sub == 0) {  // nothing extended: the match starts a track (:701-709)
-            const uint32_t t = a.track_base + k;
-            emit(t, kS, sS);
-            emit(t, kD, sD);
-            a.newflag[k] = 1;
-        }
-        __threadfence();
-        store_release(&a.cursor[sS], rS + 1);
-        store_release(&a.cursor[sD], rD + 1);
-        a.done[k] = 1;
-        const uint64_t act = __ballot(1);
-        if ((threadIdx.x & 63) == (uint32_t)__ffsll((long long)act) - 1u) atomicAdd(&a.st->n_done, (uint32_t)__popcll(act));
-        return;
+        const uint32_t total = __shfl(incl, 63);
+        if (pos + total > cap) return cap + 1;
+        const uint32_t at = pos + incl - len;
+        for (uint32_t c = 0; c < len; ++c) lds[at + c] = a.nev_track[start + c];
+        pos += total;
     }
+    return pos;
+}
+
+// (5) One launch = one level of the dependency order.  A workgroup looks at 256 matches, one lane each; those whose two
+// points have seen all lower-ranked matches BEFORE THIS LAUNCH are run by the workgroup's wavefronts, one match per
+// wavefront at a time: both track lists are staged in LDS, the lanes test membership and append in list order.
+// Cursors carry the launch that wrote them, so a match never builds on something written by the running launch:
+// the kernel boundary is the only synchronisation between workgroups (the XCDs' L2s are not coherent with one another
+// inside a launch, and agent-scope release/acquire per match -- an L2 write-back and invalidate each -- cost 20x more).
+// Event slots are reserved per workgroup from an upper bound (the two list lengths); unused slots are tagged invalid
+// and sorted away afterwards.
+__device__ inline bool cursor_ready(uint64_t c, uint32_t rank, uint32_t launch) { return (uint32_t)c == rank && (uint32_t)(c >> 32) < launch; }
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) trk_round_kernel(RoundArgs a) {
+    constexpr int BT = WAVES * 64;
+    __shared__ uint32_t wt[WAVES + 1];
+    __shared__ uint32_t ready_k[BT], ready_first[BT];
+    __shared__ uint32_t slot_base;
+    extern __shared__ uint32_t lists[];  // WAVES x 2 x list_cap
+    const uint32_t cap = a.list_cap;
+    const uint32_t k = blockIdx.x * BT + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool live = k < a.n_matches && !a.done[k];
+    uint32_t sS = 0, sD = 0, rS = 0, rD = 0;
+    if (live) { sS = a.segS[k]; sD = a.segD[k]; rS = a.rankS[k]; rD = a.rankD[k]; }
+    uint32_t finished = 0;
+    if (a.st->overflow & 1u) return;  // (set by an earlier launch of the burst) nothing more fits until the host has grown the buffer
+    {
+        const bool ready = live && cursor_ready(a.cursor[sS], rS, a.launch) && cursor_ready(a.cursor[sD], rD, a.launch);
+        uint32_t need = 0;
+        if (ready) need = max(2u, (a.seg_hi[sS] - a.seg_lo[sS]) + a.seg_cnt[sS] + (a.seg_hi[sD] - a.seg_lo[sD]) + a.seg_cnt[sD]);
+        // ready matches in lane order, and their slots
+        uint32_t n_ready;
+        const uint32_t r = block_rank<WAVES>(ready, wt, n_ready);
+        uint32_t incl = need;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        __syncthreads();
+        if (lane == 63) wt[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int i = 0; i < WAVES; ++i) {
+            if (i < w) before += wt[i];
+            total += wt[i];
+        }
+        if (threadIdx.x == 0 && total) slot_base = atomicAdd(&a.st->n_new, total);
+        __syncthreads();
+        if (!n_ready) return;
+        if ((uint64_t)slot_base + total > a.nev_cap) {
+            // event buffer full: these matches stay pending, the slots stay reserved (and unused: the buffer is pre-filled
+            // with the invalid tag); the host grows the buffer past n_new and goes on
+            if (threadIdx.x == 0) atomicOr(&a.st->overflow, 1u);
+            return;
+        }
+        if (ready) {
+            ready_k[r] = k;
+            ready_first[r] = slot_base + before + incl - need;
+            live = false;
+        }
+        __syncthreads();
+        uint32_t* LS = lists + (size_t)w * 2 * cap;
+        uint32_t* LD = LS + cap;
+        for (uint32_t j = w; j < n_ready; j += WAVES) {
+            const uint32_t m = ready_k[j], first = ready_first[j];
+            const uint32_t mS = a.segS[m], mD = a.segD[m], mrS = a.rankS[m], mrD = a.rankD[m];
+            const uint64_t kS = a.keyS[m], kD = a.keyD[m];
+            // the id-0 quirk (point_track.h:651-657): the same decision in every lane, written by one
+            uint32_t phase = a.st->qphase;
+            uint64_t qkey = a.st->qkey;
+            if (a.first_ever && m == 0) {
+                qkey = kS;
+                phase = 1;
+                if (lane == 0) { a.st->qkey = qkey; a.st->qphase = 1; }
+            } else if (phase == 1 && (kS == qkey || kD == qkey)) {
+                phase = 2;
+                if (lane == 0) a.st->qphase = 2;
+            }
+            const bool qS = phase == 2 && kS == qkey, qD = phase == 2 && kD == qkey;
+            wave_sync();  // the previous match of this wavefront is done with the lists
+            uint32_t nS = stage_list(a, mS, mrS, LS, lane, cap), nD = stage_list(a, mD, mrD, LD, lane, cap);
+            wave_sync();
+            uint32_t nA = 0, nB = 0;
+            if (nS > cap || nD > cap) {
+                // a list too long for this configuration: the match stays pending (its slots are given up as invalid)
+                // and the host switches to the large-list configuration for the rest of the batch
+                if (lane == 0) atomicOr(&a.st->overflow, 4u);
+                continue;
+            } else {
+                // the forgotten first track of the first point ever registered: its list starts one entry later
+                const uint32_t* S = LS + (qS && nS ? 1 : 0);
+                const uint32_t* D = LD + (qD && nD ? 1 : 0);
+                nS -= (qS && nS ? 1 : 0);
+                nD -= (qD && nD ? 1 : 0);
+                // every track of the source point learns the destination point (point_track.h:664-681) ...
+                for (uint32_t i0 = 0; i0 < nS; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    bool add = false;
+                    uint32_t t = 0;
+                    if (i < nS) {
+                        t = S[i];
+                        add = !(qD && t == 0);
+                        for (uint32_t q = 0; q < nD && add; ++q) add = D[q] != t;
+                    }
+                    const uint64_t mask = __ballot(add);
+                    if (add) {
+                        const uint32_t sub = nA + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        if (sub < (1u << kSubBits) - 1u) {
+                            const uint32_t e = first + sub;
+                            a.nev_track[e] = t;
+                            a.nev_key[e] = kD;
+                            a.nev_seq[e] = ((uint64_t)m << kSubBits) | sub;
+                        }
+                    }
+                    nA += (uint32_t)__popcll(mask);
+                }
+                // ... and every earlier track of the destination point learns the source point (:683-699)
+                for (uint32_t i0 = 0; i0 < nD; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    bool add = false;
+                    uint32_t t = 0;
+                    if (i < nD) {
+                        t = D[i];
+                        add = !(qS && t == 0);
+                        for (uint32_t q = 0; q < nS && add; ++q) add = S[q] != t;
+                    }
+                    const uint64_t mask = __ballot(add);
+                    if (add) {
+                        const uint32_t sub = nA + nB + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        if (sub < (1u << kSubBits) - 1u) {
+                            const uint32_t e = first + sub;
+                            a.nev_track[e] = t;
+                            a.nev_key[e] = kS;
+                            a.nev_seq[e] = ((uint64_t)m << kSubBits) | sub;
+                        }
+                    }
+                    nB += (uint32_t)__popcll(mask);
+                }
+                if (nA + nB >= (1u << kSubBits) - 1u) {
+                    if (lane == 0) atomicOr(&a.st->overflow, 2u);
+                    nA = nB = 0;
+                }
+            }
+            const uint32_t used = nA + nB;
+            if (lane == 0) {
+                if (used == 0) {
+                    // nothing extended: the match starts a track (:701-709); source member first
+                    const uint32_t t = a.track_base + m;
+                    a.nev_track[first] = t;     a.nev_key[first] = kS;     a.nev_seq[first] = ((uint64_t)m << kSubBits) | 0u;
+                    a.nev_track[first + 1] = t; a.nev_key[first + 1] = kD; a.nev_seq[first + 1] = ((uint64_t)m << kSubBits) | 1u;
+                    a.newflag[m] = 1;
+                    a.run_start[a.seg_start[mS] + mrS] = first;     a.run_len[a.seg_start[mS] + mrS] = 1;
+                    a.run_start[a.seg_start[mD] + mrD] = first + 1; a.run_len[a.seg_start[mD] + mrD] = 1;
+                    a.seg_cnt[mS] += 1;
+                    a.seg_cnt[mD] += 1;
+                } else {
+                    a.run_start[a.seg_start[mD] + mrD] = first;      a.run_len[a.seg_start[mD] + mrD] = nA;
+                    a.run_start[a.seg_start[mS] + mrS] = first + nA; a.run_len[a.seg_start[mS] + mrS] = nB;
+                    a.seg_cnt[mD] += nA;
+                    a.seg_cnt[mS] += nB;
+                }
+            }
+            if (lane == 0) {
+                a.cursor[mS] = ((uint64_t)a.launch << 32) | (mrS + 1);
+                a.cursor[mD] = ((uint64_t)a.launch << 32) | (mrD + 1);
+                a.done[m] = 1;
+                ++finished;
+            }
+        }
+    }
+    if (finished) atomicAdd(&a.st->n_done, finished);
+}
+
+__global__ void trk_fill64_kernel(uint64_t* p, size_t n, uint64_t value) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+
+// number of valid tags in the sorted tag array = position of the first invalid one
+__global__ void trk_count_valid_kernel(const uint64_t* sorted_seq, uint32_t n, uint64_t invalid_seq, uint32_t* out) {
+    if (threadIdx.x == 0) *out = lower_bound64(sorted_seq, n, invalid_seq);
 }
 
 // (6) after the rounds: events in tag order, provisional track numbers replaced, appended to the log
@@ -472,6 +610,21 @@ int scan_u32(pgi_tracklets* t, const uint32_t* in, uint32_t* out, size_t n, bool
     return PGI_SUCCESS;
 }
 
+// PGI_TRACKLETS_TIMING=1: wall-clock per phase of add_batch on stderr (each mark synchronises the stream)
+struct PhaseTimer {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(hipStream_t stream) : on(std::getenv("PGI_TRACKLETS_TIMING") != nullptr), s(stream), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[tracklets] %-28s %9.3f ms\n", what, 1e3 * std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int read_state(pgi_tracklets* t, DeviceState& h, hipStream_t s) {
     TRK_TRY(hipMemcpyAsync(&h, t->state.p, sizeof h, hipMemcpyDeviceToHost, s));
     TRK_TRY(hipStreamSynchronize(s));
@@ -569,6 +722,7 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     }
     if (m_cap >= (1ull << 31)) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: more than 2^31 matches in one batch");
     if (!m_cap) return PGI_SUCCESS;
+    PhaseTimer timer(s);
     TRK_TRY(t->pairs.reserve(desc.size() * sizeof(PairDesc), s));
     TRK_TRY(t->pair_off.reserve(((size_t)n_pairs * 2 + 2) * 4, s));
     TRK_TRY(hipMemcpyAsync(t->pairs.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, s));
@@ -578,6 +732,7 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     TRK_TRY(t->a64.reserve(m_cap * 16, s));
     TRK_TRY(t->b64.reserve(m_cap * 16, s));
     DeviceState* st = t->state.as<DeviceState>();
+    timer.mark("(entry, buffers)");
     hipLaunchKernelGGL(trk_count_kernel, dim3(n_pairs), dim3(NT), 0, s, t->pairs.as<PairDesc>(), valid);
     hipLaunchKernelGGL(trk_pair_scan_kernel, dim3(1), dim3(NT), 0, s, valid, t->pair_off.as<uint32_t>(), n_pairs, st);
     hipLaunchKernelGGL(trk_flatten_kernel, dim3(n_pairs), dim3(NT), 0, s, t->pairs.as<PairDesc>(), t->pair_off.as<uint32_t>(),
@@ -589,12 +744,16 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     const uint32_t M = h.n_matches;
     if (!M) return PGI_SUCCESS;
     const size_t E = (size_t)M * 2;
+    timer.mark("flatten");
     // per-point segments and ranks
     for (DevBuf* b : {&t->segS, &t->segD, &t->rankS, &t->rankD, &t->newflag, &t->newrank}) TRK_TRY(b->reserve(((size_t)M + 1) * 4, s));
     TRK_TRY(t->done.reserve(M, s));
-    for (DevBuf* b : {&t->a32, &t->b32, &t->c32, &t->d32, &t->seg_lo, &t->seg_hi, &t->seg_head, &t->seg_last, &t->seg_cnt, &t->cursor})
+    for (DevBuf* b : {&t->a32, &t->b32, &t->c32, &t->d32, &t->seg_lo, &t->seg_hi, &t->seg_cnt, &t->run_start, &t->run_len})
         TRK_TRY(b->reserve(E * 4, s));
+    TRK_TRY(t->cursor.reserve(E * 8, s));
+    timer.mark("(buffers)");
     if ((rc = sort_pairs_iota<uint64_t>(t, t->a64.as<uint64_t>(), t->b64.as<uint64_t>(), t->a32.as<uint32_t>(), E, 32 + bits_for(t->n_views), s))) return rc;
+    timer.mark("sort incidences");
     hipLaunchKernelGGL(trk_heads_kernel, grid_for(E), dim3(NT), 0, s, t->b64.as<uint64_t>(), (uint32_t)E, t->b32.as<uint32_t>());
     if ((rc = scan_u32(t, t->b32.as<uint32_t>(), t->c32.as<uint32_t>(), E, true, s))) return rc;
     hipLaunchKernelGGL(trk_segment_kernel, grid_for(E), dim3(NT), 0, s, t->b64.as<uint64_t>(), t->c32.as<uint32_t>(), (uint32_t)E,
@@ -603,65 +762,108 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
                        t->segS.as<uint32_t>(), t->segD.as<uint32_t>(), t->rankS.as<uint32_t>(), t->rankD.as<uint32_t>());
     TRK_TRY(hipGetLastError());
 
-    // rounds; the event buffer starts at 3 events per match and the batch is simply replayed with a larger one if it
-    // overflows (everything a round writes is per-batch scratch; the committed log is read-only until the append)
-    size_t cap = std::max<size_t>(t->nev_cap, (size_t)M * 3 + 1024);
-    const DeviceState committed = h;
+    timer.mark("point segments and ranks");
+    // rounds: one launch per level until every match is done.  The event buffer grows in place when a launch runs out
+    // of slots (the workgroups that found it full did nothing and try again).
+    size_t cap = std::max<size_t>(t->nev_cap, (size_t)((double)M * std::max(8.0, 1.5 * t->slots_per_match)) + 1024);
+    if (const char* e = std::getenv("PGI_TRACKLETS_EVENT_CAP")) cap = std::max(64, std::atoi(e));  // tests: force the growth path
+    TRK_TRY(t->nev_track.reserve(cap * 4, s));
+    TRK_TRY(t->nev_key.reserve(cap * 8, s));
+    TRK_TRY(t->nev_seq.reserve(cap * 8, s));
+    t->nev_cap = cap;
+    const uint64_t invalid_seq = (uint64_t)M << kSubBits;  // tag of a slot that holds no event: sorts behind every real one
+    hipLaunchKernelGGL(trk_fill64_kernel, grid_for(cap), dim3(NT), 0, s, t->nev_seq.as<uint64_t>(), cap, invalid_seq);
+    TRK_TRY(hipMemsetAsync(t->done.p, 0, M, s));
+    TRK_TRY(hipMemsetAsync(t->newflag.p, 0, ((size_t)M + 1) * 4, s));
+    TRK_TRY(hipMemsetAsync(t->seg_cnt.p, 0, E * 4, s));
+    TRK_TRY(hipMemsetAsync(t->cursor.p, 0, E * 8, s));
+    timer.mark("(buffers)");
+    RoundArgs a{};
+    a.st = st;
+    a.keyS = t->keyS.as<uint64_t>(); a.keyD = t->keyD.as<uint64_t>();
+    a.segS = t->segS.as<uint32_t>(); a.segD = t->segD.as<uint32_t>(); a.rankS = t->rankS.as<uint32_t>(); a.rankD = t->rankD.as<uint32_t>();
+    a.done = t->done.as<uint8_t>(); a.newflag = t->newflag.as<uint32_t>();
+    a.seg_start = t->d32.as<uint32_t>(); a.seg_lo = t->seg_lo.as<uint32_t>(); a.seg_hi = t->seg_hi.as<uint32_t>();
+    a.seg_cnt = t->seg_cnt.as<uint32_t>(); a.cursor = t->cursor.as<uint64_t>();
+    a.run_start = t->run_start.as<uint32_t>(); a.run_len = t->run_len.as<uint32_t>();
+    a.pt_track = t->pt_track.as<uint32_t>();
+    a.n_matches = M;
+    a.track_base = t->n_tracks;
+    a.first_ever = t->n_events == 0 ? 1 : 0;
+    uint32_t rounds = 0, last_done = 0;
+    int burst = 8;
+    // PGI_TRACKLETS_LIST_CAP (tests): a smaller usual configuration, so that the large-list path is exercised
+    uint32_t list_cap = kListCap;
+    if (const char* e = std::getenv("PGI_TRACKLETS_LIST_CAP")) list_cap = std::min<uint32_t>(kListCap, std::max(8, std::atoi(e)));
+    bool huge = false;
+    a.list_cap = list_cap;
+    const DeviceState committed = h;  // a batch that fails leaves the store as it was (the rounds may have advanced the quirk state)
+    auto give_up = [&](int code, const char* msg) {
+        (void)hipMemcpyAsync(st, &committed, sizeof committed, hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);
+        return pgi::fail(code, msg);
+    };
     for (;;) {
-        TRK_TRY(t->nev_track.reserve(cap * 4, s));
-        TRK_TRY(t->nev_next.reserve(cap * 4, s));
-        TRK_TRY(t->nev_key.reserve(cap * 8, s));
-        TRK_TRY(t->nev_seq.reserve(cap * 8, s));
-        t->nev_cap = cap;
-        TRK_TRY(hipMemsetAsync(t->done.p, 0, M, s));
-        TRK_TRY(hipMemsetAsync(t->newflag.p, 0, ((size_t)M + 1) * 4, s));
-        TRK_TRY(hipMemsetAsync(t->seg_cnt.p, 0, E * 4, s));
-        TRK_TRY(hipMemsetAsync(t->cursor.p, 0, E * 4, s));
-        DeviceState reset = committed;
-        reset.n_new = reset.n_done = reset.overflow = reset.n_new_tracks = 0;
-        TRK_TRY(hipMemcpyAsync(st, &reset, sizeof reset, hipMemcpyHostToDevice, s));
-        RoundArgs a{};
-        a.st = st;
-        a.keyS = t->keyS.as<uint64_t>(); a.keyD = t->keyD.as<uint64_t>();
-        a.segS = t->segS.as<uint32_t>(); a.segD = t->segD.as<uint32_t>(); a.rankS = t->rankS.as<uint32_t>(); a.rankD = t->rankD.as<uint32_t>();
-        a.done = t->done.as<uint8_t>(); a.newflag = t->newflag.as<uint32_t>();
-        a.seg_lo = t->seg_lo.as<uint32_t>(); a.seg_hi = t->seg_hi.as<uint32_t>();
-        a.seg_head = t->seg_head.as<uint32_t>(); a.seg_last = t->seg_last.as<uint32_t>(); a.seg_cnt = t->seg_cnt.as<uint32_t>();
-        a.cursor = t->cursor.as<uint32_t>();
-        a.pt_track = t->pt_track.as<uint32_t>();
-        a.nev_track = t->nev_track.as<uint32_t>(); a.nev_next = t->nev_next.as<uint32_t>();
+        a.nev_track = t->nev_track.as<uint32_t>();
         a.nev_key = t->nev_key.as<uint64_t>(); a.nev_seq = t->nev_seq.as<uint64_t>();
         a.nev_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u);
-        a.n_matches = M;
-        a.track_base = t->n_tracks;
-        a.first_ever = t->n_events == 0 ? 1 : 0;
-        uint32_t rounds = 0, last_done = 0;
-        int burst = 4;
-        for (;;) {
-            for (int r = 0; r < burst; ++r) hipLaunchKernelGGL(trk_round_kernel, grid_for(M), dim3(NT), 0, s, a);
-            rounds += burst;
-            TRK_TRY(hipGetLastError());
-            if ((rc = read_state(t, h, s))) return rc;
-            if (h.n_done >= M || h.overflow) break;
-            if (h.n_done == last_done) return pgi::fail(PGI_ERR_DEVICE, "pgi_tracklets_add_batch: no match became ready (internal error)");
-            last_done = h.n_done;
-            burst = std::min(burst * 2, 32);
+        for (int r = 0; r < burst; ++r) {
+            a.launch = ++rounds;
+            if (!huge) hipLaunchKernelGGL((trk_round_kernel<4>), grid_for(M, 256), dim3(256), (size_t)4 * 2 * list_cap * 4, s, a);
+            else hipLaunchKernelGGL((trk_round_kernel<1>), grid_for(M, 64), dim3(64), (size_t)2 * kListCapHuge * 4, s, a);
         }
-        t->last_rounds = rounds;
-        if (h.overflow & 2u) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: a match extended more than 4095 tracks");
-        if (!(h.overflow & 1u)) break;
-        cap = std::max<size_t>(cap * 2, (size_t)h.n_new + 1024);
-        if (cap > 0xFFFFFFF0u) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: event buffer beyond 2^32 entries");
+        TRK_TRY(hipGetLastError());
+        if ((rc = read_state(t, h, s))) return rc;
+        if (timer.on) {
+            char what[96];
+            std::snprintf(what, sizeof what, "  %d launches: %u of %u done%s", burst, h.n_done, M, (h.overflow & 1u) ? " (buffer full)" : "");
+            timer.mark(what);
+        }
+        if ((h.overflow & 2u) || ((h.overflow & 4u) && huge))
+            return give_up(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: a keypoint sits in more than 16384 tracks");
+        if (h.n_done >= M) break;
+        if (h.overflow & 4u) {  // lists beyond the usual configuration: large-list launches from here on
+            huge = true;
+            a.list_cap = kListCapHuge;
+            TRK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_round_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * kListCapHuge * 4)));
+        }
+        if (h.overflow & 1u) {
+            if (cap >= 0xFFFFFFF0u) return give_up(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: event buffer beyond 2^32 entries");
+            const size_t old = cap;
+            cap = std::min<size_t>(std::max<size_t>(cap * 2, (size_t)h.n_new + (size_t)h.n_new / 4), 0xFFFFFFF0u);
+            if (h.n_new >= cap) return give_up(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: event buffer beyond 2^32 entries");
+            TRK_TRY(t->nev_track.reserve(cap * 4, s, old * 4));
+            TRK_TRY(t->nev_key.reserve(cap * 8, s, old * 8));
+            TRK_TRY(t->nev_seq.reserve(cap * 8, s, old * 8));
+            hipLaunchKernelGGL(trk_fill64_kernel, grid_for(cap - old), dim3(NT), 0, s, t->nev_seq.as<uint64_t>() + old, cap - old, invalid_seq);
+            t->nev_cap = cap;
+        }
+        if (h.overflow) {
+            TRK_TRY(hipMemsetAsync(&st->overflow, 0, 4, s));
+        } else if (h.n_done == last_done) {
+            return give_up(PGI_ERR_DEVICE, "pgi_tracklets_add_batch: no match became ready (internal error)");
+        }
+        last_done = h.n_done;
+        burst = std::min(burst * 2, 32);
     }
-    const uint32_t n_new = h.n_new;
+    t->last_rounds = rounds;
+    timer.mark("rounds");
+    const uint32_t n_slots = h.n_new;  // reserved slots; the unused ones carry the invalid tag and sort to the end
+    t->slots_per_match = (double)n_slots / (double)M;
     // new tracks are numbered in match order, the order the reference creates them in
     if ((rc = scan_u32(t, t->newflag.as<uint32_t>(), t->newrank.as<uint32_t>(), (size_t)M + 1, false, s))) return rc;
     uint32_t created = 0;
     TRK_TRY(hipMemcpyAsync(&created, t->newrank.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost, s));
     // events back in sequential order
-    TRK_TRY(t->a64.reserve((size_t)n_new * 8, s));
-    TRK_TRY(t->a32.reserve((size_t)n_new * 4, s));
-    if ((rc = sort_pairs_iota<uint64_t>(t, t->nev_seq.as<uint64_t>(), t->a64.as<uint64_t>(), t->a32.as<uint32_t>(), n_new, kSubBits + bits_for(M), s))) return rc;
+    TRK_TRY(t->a64.reserve((size_t)n_slots * 8, s));
+    TRK_TRY(t->a32.reserve((size_t)n_slots * 4, s));
+    if ((rc = sort_pairs_iota<uint64_t>(t, t->nev_seq.as<uint64_t>(), t->a64.as<uint64_t>(), t->a32.as<uint32_t>(), n_slots,
+                                        kSubBits + bits_for((uint64_t)M + 1), s))) return rc;
+    hipLaunchKernelGGL(trk_count_valid_kernel, dim3(1), dim3(64), 0, s, t->a64.as<uint64_t>(), n_slots, invalid_seq, &st->n_valid);
+    uint32_t n_new = 0;
+    TRK_TRY(hipMemcpyAsync(&n_new, &st->n_valid, 4, hipMemcpyDeviceToHost, s));
+    TRK_TRY(hipStreamSynchronize(s));
     const size_t N0 = t->n_events, N1 = N0 + n_new;
     if (N1 >= 0xFFFFFFF0u) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: more than 2^32 events");
     TRK_TRY(t->ev_track.reserve(N1 * 4, s, N0 * 4));
@@ -672,7 +874,10 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     TRK_TRY(hipStreamSynchronize(s));
     t->n_tracks += created;
     t->n_events = N1;
-    return rebuild_views(t, s);
+    timer.mark("order and append events");
+    rc = rebuild_views(t, s);
+    timer.mark("rebuild the three orderings");
+    return rc;
 }
 
 int pgi_tracklets_get_batch(pgi_tracklets* t, const uint32_t* h_view_src, const uint32_t* h_view_dst, uint32_t n_queries, uint32_t max_n,

@@ -27,4 +27,4 @@ with tempfile.TemporaryDirectory() as d:
             f.write(struct.pack("<IId", i, j, s))
     print("views %d, keypoints/view ~%d, pairs %d, wave %d" % (V, np.mean([len(v["xy"]) for v in views]), len(pairs), wave))
     r = subprocess.run([os.path.join(ROOT, "pose-graph-initialization_amd", "test_pipeline"), fin, fout], capture_output=True, text=True)
-    print(r.stdout, r.stderr[-500:])
+    print(r.stdout, r.stderr[-6000:])

@@ -122,20 +122,20 @@ def test_dense_repeats_and_first_point_returning(eng):
         dev.close()
 
 
-def test_scheduler_sized_batch(eng):
-    """A wave the size the pipeline commits: 24 views of 2000 physical points, 60 pairs x ~1200 inlier matches in one
-    batch on top of a committed store; compared with the oracle on every view pair."""
-    from pyposegraphbuilder.engine import DeviceTracklets
+@pytest.fixture(scope="module")
+def scheduler_scene():
+    """24 views of 1500 physical points; three waves of 40 pairs x ~800 inlier matches, and the oracle's state after each."""
+    import copy
     rng = np.random.default_rng(99)
-    views, pts = 24, 2000
+    views, pts = 24, 1500
     perm = [rng.permutation(pts) for _ in range(views)]       # keypoint index of physical point j in view v
-    inv = [np.argsort(p) for p in perm]
-    dev, ref = DeviceTracklets(eng, views), TO.Tracklets()
+    ref = TO.Tracklets()
     pairs = [(a, b) for a in range(views) for b in range(a + 1, views)]
     order = rng.permutation(len(pairs))
+    waves = []
     for w in range(3):
         calls = []
-        for pi in order[w * 60:(w + 1) * 60]:
+        for pi in order[w * 40:(w + 1) * 40]:
             a, b = pairs[pi]
             vis = np.nonzero(rng.random(pts) < 0.6)[0]
             src = perm[a][vis]
@@ -146,11 +146,56 @@ def test_scheduler_sized_batch(eng):
             mask = (rng.random(len(vis)) < 0.9).astype(np.uint8)
             calls.append((a, b, m, mask))
             ref.add(a, b, [tuple(r) for r in m.tolist()], mask.tolist())
+        waves.append((calls, copy.deepcopy(ref) if w == 1 else None))
+    return views, waves, ref
+
+
+@pytest.mark.parametrize("event_cap", [None, 3000])
+def test_scheduler_sized_batch(eng, scheduler_scene, event_cap, monkeypatch):
+    """Waves the size the pipeline commits, each one batch on top of the committed store; compared with the oracle on
+    every view pair.  With PGI_TRACKLETS_EVENT_CAP=3000 the event buffer starts far too small and grows several times in
+    the middle of every batch."""
+    from pyposegraphbuilder.engine import DeviceTracklets
+    if event_cap:
+        monkeypatch.setenv("PGI_TRACKLETS_EVENT_CAP", str(event_cap))
+    views, waves, ref = scheduler_scene
+    dev = DeviceTracklets(eng, views)
+    for calls, snapshot in waves:
         dev.add_batch(calls)
-        assert dev.info()["rounds"] < 400
-    _check_state(dev, ref, views, max_ns=(100, 100000))
+        assert dev.info()["rounds"] < 1000
+        if snapshot is not None:
+            _check_state(dev, snapshot, views, max_ns=(30000,))
+    _check_state(dev, ref, views, max_ns=(100, 30000))
     _check_tracks(dev, ref, range(0, len(ref.tracks), 997))
-    assert inv is not None
+    dev.close()
+
+
+@pytest.mark.parametrize("list_cap", [None, 48])
+def test_long_track_lists(eng, list_cap, monkeypatch):
+    """Few keypoints, many views, 30 % wrong matches: every keypoint ends up in more than a hundred tracks, so lists span
+    several 64-entry chunks and more than 64 runs per batch.  With PGI_TRACKLETS_LIST_CAP=48 the usual configuration
+    cannot stage them and the batch finishes in the large-list configuration."""
+    from pyposegraphbuilder.engine import DeviceTracklets
+    if list_cap:
+        monkeypatch.setenv("PGI_TRACKLETS_LIST_CAP", str(list_cap))
+    rng = np.random.default_rng(1)
+    V, K = 30, 12
+    dev, ref = DeviceTracklets(eng, V), TO.Tracklets()
+    pairs = [(a, b) for a in range(V) for b in range(a + 1, V)]
+    order = rng.permutation(len(pairs))
+    calls = []
+    for n, pi in enumerate(order):
+        a, b = pairs[pi]
+        m = [(p, p if rng.random() > 0.3 else int(rng.integers(0, K))) for p in range(K) if rng.random() < 0.7]
+        ref.add(a, b, m, [1] * len(m))
+        calls.append((a, b, m, None))
+        if len(calls) == 145:
+            dev.add_batch(calls)
+            calls = []
+            _check_state(dev, ref, V, max_ns=(1000000,))
+    assert not calls
+    assert max(len(v) for v in ref.id_tracks.values()) > 100
+    _check_tracks(dev, ref, range(len(ref.tracks)))
     dev.close()
 
 
