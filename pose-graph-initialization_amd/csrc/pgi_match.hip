@@ -108,6 +108,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(con
                                              (__attribute__((address_space(3))) void*)(&bt[buf][ch * 256u]), 16, 0, 0);
         }
     };
+    // Rows past the image and columns past the image carry an infinite norm: their distances come out as +inf by the
+    // same two operations as everyone else's and drop out of every minimum without a per-element select.
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (row_base + mfma_row(r, h) >= P.n_a) nar[r] = INFINITY;
     if (t0 < t1) stage(t0, 0u);
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint32_t cur = (tile - t0) & 1u;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(con
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t j = tile * kTileJ + 32u * sub + c;
-            nbj[sub] = P.nb[j];
+            nbj[sub] = j < P.n_b ? P.nb[j] : INFINITY;
             seen[sub] = __builtin_nontemporal_load(&colbest[P.col_off + j]);
         }
         const float* bcur = &bt[cur][lane];
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(con
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             if (s + kAhead < kD / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        // branch-free epilogue: every update is a compare + selects
+        // branch-free epilogue, 10 VALU operations per distance.  On this chip they are NOT hidden behind the other
+        // wavefront's MFMAs (f32 MFMA and f32 VALU peak at the same 256 flop/cycle/CU and, measured, add up: DESIGN.md §7),
+        // so every operation removed here is kernel time
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t j = tile * kTileJ + 32u * sub + c;
@@ -156,17 +163,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_top2_kernel(con
                 const float t = nar[r] + nbj[sub];
                 float d2 = fmaf(-2.0f, acc[sub][r], t);  // == t - 2*acc: the product is exact
                 d2 = d2 > 0.0f ? d2 : 0.0f;
-                const float dr = jvalid ? d2 : INFINITY;  // padded columns never enter a row's top-2
-                const bool lt1 = dr < b1[r], lt2 = dr < b2[r];
-                const float keep2 = lt2 ? dr : b2[r];
-                b2[r] = lt1 ? b1[r] : keep2;
-                b1[r] = lt1 ? dr : b1[r];
+                // columns arrive in ascending order: strict < keeps the lowest column on ties
+                const bool lt1 = d2 < b1[r];
+                b2[r] = __builtin_amdgcn_fmed3f(b1[r], b2[r], d2);  // second smallest of {b1 <= b2, d2}
+                b1[r] = fminf(b1[r], d2);
                 j1[r] = lt1 ? j : j1[r];
-                const uint32_t i = row_base + mfma_row(r, h);  // ascending in r: strict < keeps the lowest row on ties
-                const float dc = i < P.n_a ? d2 : INFINITY;
-                const bool ltc = dc < cbest;
-                cbest = ltc ? dc : cbest;
-                ci = ltc ? i : ci;
+                const bool ltc = d2 < cbest;  // rows ascend in r: strict < keeps the lowest row on ties
+                cbest = ltc ? d2 : cbest;
+                ci = ltc ? row_base + mfma_row(r, h) : ci;
             }
             unsigned long long ckey = ((unsigned long long)__float_as_uint(cbest) << 32) | ci;
             const unsigned long long other = __shfl_xor(ckey, 32);
