@@ -52,6 +52,8 @@ struct pgi_ctx {
         size_t bytes = 0;
         uint32_t* d_bucket = nullptr;
         size_t bucket_bytes = 0;
+        void* h_small = nullptr;  // page-locked staging of the chunk's per-pair arrays
+        size_t h_small_bytes = 0;
         hipStream_t stream = nullptr;
         hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
         bool used = false;

@@ -1365,6 +1365,7 @@ void pgi_destroy(pgi_ctx* ctx) {
     for (int k = 0; k < 4; ++k) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
+        if (ctx->hslot[k].h_small) (void)hipHostFree(ctx->hslot[k].h_small);
         if (ctx->hslot[k].stream) (void)hipStreamDestroy(ctx->hslot[k].stream);
         if (ctx->hslot[k].in_done) (void)hipEventDestroy(ctx->hslot[k].in_done);
         if (ctx->hslot[k].k_done) (void)hipEventDestroy(ctx->hslot[k].k_done);
@@ -1559,6 +1560,11 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         cuts.push_back(q);
         p = q;
     }
+    // the kernel of the last chunk is pure tail (nothing left to overlap it with): keep that chunk to one quantum
+    if (pinned && cuts.size() >= 3) {
+        const uint32_t a0 = cuts[cuts.size() - 2], b0 = cuts.back();
+        if (b0 - a0 >= quantum + quantum / 2) cuts.insert(cuts.end() - 1, b0 - quantum);
+    }
     const size_t n_chunks = cuts.size() - 1;
     struct Lay { size_t x1, y1, x2, y2, off, thr, guess, has, edges, masks, total; };
     auto layout = [&](uint64_t rows, uint32_t pairs) {
@@ -1592,7 +1598,6 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         }
         S.used = false;
     }
-    std::vector<uint64_t> off_local[kSlots];
     Lay lay[kSlots];
     auto fetch = [&](size_t c) -> int {  // edge records and masks of chunk c back to the caller's buffers
         pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
@@ -1607,7 +1612,10 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         HIP_TRY(hipEventRecord(S.out_done, out));
         return PGI_SUCCESS;
     };
-    for (size_t c = 0; c < n_chunks; ++c) {
+    uint32_t max_corr_of[kSlots] = {};
+    // host side of a chunk in two halves, so that the copies of chunk c + 1 are queued BEFORE the launches of chunk c
+    // (the half-dozen launches per chunk otherwise left the copy stream idle for ~60 us per chunk)
+    auto stage_in = [&](size_t c) -> int {
         pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t rbase = h_offsets[p0], rows = h_offsets[p0 + np] - rbase, r0 = rbase - h_offsets[0];
@@ -1620,11 +1628,26 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             S.bytes = L.total + L.total / 4;
         }
         char* d = (char*)S.d;
-        std::vector<uint64_t>& ol = off_local[c % kSlots];
-        ol.resize((size_t)np + 1);
+        // The per-pair arrays (rebased offsets, thresholds, guesses) travel as ONE copy from a page-locked staging block
+        // of the slot that mirrors the device layout [L.off, L.has + np): four small copies from pageable memory cost
+        // ~0.14 ms of the copy stream per chunk (13 % of its time on BASELINE config 2; profiles/r02_host_timeline.txt)
+        const size_t small_bytes = (L.has + np) - L.off;
+        if (small_bytes > S.h_small_bytes) {
+            if (S.h_small) (void)hipHostFree(S.h_small);
+            S.h_small = nullptr; S.h_small_bytes = 0;
+            HIP_TRY(hipHostMalloc(&S.h_small, small_bytes + small_bytes / 4, hipHostMallocDefault));
+            S.h_small_bytes = small_bytes + small_bytes / 4;
+        }
+        char* hs = (char*)S.h_small;
+        uint64_t* ol = reinterpret_cast<uint64_t*>(hs);
         uint32_t max_corr = 0;
         for (uint32_t k = 0; k <= np; ++k) ol[k] = h_offsets[p0 + k] - rbase;
         for (uint32_t k = 0; k < np; ++k) max_corr = std::max(max_corr, (uint32_t)(ol[k + 1] - ol[k]));
+        memcpy(hs + (L.thr - L.off), h_thr + p0, (size_t)np * 8);
+        if (guesses) {
+            memcpy(hs + (L.guess - L.off), h_guess_Rt + 12 * (size_t)p0, (size_t)np * 96);
+            memcpy(hs + (L.has - L.off), h_has_guess + p0, np);
+        }
         // pageable buffers: every copy is staged by the runtime on this thread; keep them on the slot's own stream so
         // that the copies of neighbouring chunks still overlap (one shared copy stream would serialise them)
         hipStream_t in = pinned ? ctx->copy_in : S.stream;
@@ -1634,13 +1657,17 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             HIP_TRY(hipMemcpyAsync(d + L.x2, h_x2 + r0, rows * 4, hipMemcpyHostToDevice, in));
             HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, in));
         }
-        HIP_TRY(hipMemcpyAsync(d + L.off, ol.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, in));
-        HIP_TRY(hipMemcpyAsync(d + L.thr, h_thr + p0, (size_t)np * 8, hipMemcpyHostToDevice, in));
-        if (guesses) {
-            HIP_TRY(hipMemcpyAsync(d + L.guess, h_guess_Rt + 12 * (size_t)p0, (size_t)np * 96, hipMemcpyHostToDevice, in));
-            HIP_TRY(hipMemcpyAsync(d + L.has, h_has_guess + p0, np, hipMemcpyHostToDevice, in));
-        }
+        HIP_TRY(hipMemcpyAsync(d + L.off, hs, guesses ? small_bytes : (L.thr + (size_t)np * 8) - L.off, hipMemcpyHostToDevice, in));
         HIP_TRY(hipEventRecord(S.in_done, in));
+        lay[c % kSlots] = L;
+        max_corr_of[c % kSlots] = max_corr;
+        return PGI_SUCCESS;
+    };
+    auto launch = [&](size_t c) -> int {
+        pgi_ctx::HostSlot& S = ctx->hslot[c % kSlots];
+        const Lay& L = lay[c % kSlots];
+        const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0, max_corr = max_corr_of[c % kSlots];
+        char* d = (char*)S.d;
         HIP_TRY(hipStreamWaitEvent(S.stream, S.in_done, 0));
         pgi_batch b{};
         b.d_x1 = (const float*)(d + L.x1); b.d_y1 = (const float*)(d + L.y1); b.d_x2 = (const float*)(d + L.x2); b.d_y2 = (const float*)(d + L.y2);
@@ -1651,8 +1678,20 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
         if (rc < 0) return rc;
         HIP_TRY(hipEventRecord(S.k_done, S.stream));
-        lay[c % kSlots] = L;
         S.used = true;
+        return PGI_SUCCESS;
+    };
+    {
+        const int rc0 = stage_in(0);
+        if (rc0 < 0) return rc0;
+    }
+    for (size_t c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) {
+            const int rc1 = stage_in(c + 1);
+            if (rc1 < 0) return rc1;
+        }
+        const int rcl = launch(c);
+        if (rcl < 0) return rcl;
         // Results: page-locked -> enqueue the device-to-host copies right away (asynchronous).  Pageable -> a copy to
         // pageable memory blocks this thread until the kernel is done, so fetch a chunk only two launches later.
         if (pin_out) {
