@@ -192,6 +192,29 @@ void pgo_score_model(const float E[9], const float* x1, const float* y1, const f
     *n_inl = c;
 }
 
+/* pgo_score_model with an exact early exit: the levels only add, so a model whose partial score plus 4 per remaining
+ * row cannot exceed `bar` (the best score that still matters) can be dropped without changing any result.  Checked
+ * every 64 rows, like the kernels do (score_queue, csrc/pgi_kernels.hip).  Returns 0 if the model was dropped. */
+static int score_model_bounded(const float E[9], const float* x1, const float* y1, const float* x2, const float* y2,
+                               uint32_t n, double thr, long bar, uint32_t* score, uint32_t* n_inl) {
+    const float thr2 = (float)(thr * thr);
+    uint32_t s = 0, c = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t end = base + 64 < n ? base + 64 : n;
+        for (uint32_t i = base; i < end; ++i) {
+            float r2, den;
+            sampson_terms(E, x1[i], y1[i], x2[i], y2[i], &r2, &den);
+            const float t = thr2 * den;
+            s += (r2 < 0.25f * t) + (r2 < 0.5625f * t) + (r2 < t) + (r2 < 2.25f * t);
+            c += (r2 < t);
+        }
+        if ((long)s + 4l * (long)(n - end) <= bar) return 0;
+    }
+    *score = s;
+    *n_inl = c;
+    return 1;
+}
+
 uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, const float* x2,
                         const float* y2, uint32_t n, float tau2, uint8_t* mask) {
     uint32_t c = 0;
@@ -1109,7 +1132,10 @@ void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, con
             for (uint32_t m = 0; m < nm; ++m) {
                 uint32_t s, c;
                 if (!pgo_preverify(models[m], x1, y1, x2, y2, n, thr, n_bar)) continue;
-                pgo_score_model(models[m], x1, y1, x2, y2, n, thr, &s, &c);
+                /* only a model that beats the round's best so far AND the best of earlier rounds can change anything */
+                long bar = rb.valid ? (long)rb.score : -1;
+                if (best.valid && (long)best.score > bar) bar = (long)best.score;
+                if (!score_model_bounded(models[m], x1, y1, x2, y2, n, thr, bar, &s, &c)) continue;
                 if (!rb.valid || s > rb.score) {
                     memcpy(rb.E, models[m], sizeof rb.E);
                     rb.score = s; rb.n_inl = c; rb.valid = 1;
