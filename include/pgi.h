@@ -69,7 +69,13 @@ typedef struct {
                                smaller sets keep the Nister refit.  Default 35; 0 = always Nister.  A final model
                                that comes from a linear refit is not exactly rank 2; R and t come from its SVD
                                (pose_utils.h:144-169) like for any other E */
-    uint32_t reserved;
+    uint32_t sampler;       /* 0 = uniform 5-row samples (default).  1 = progressive ("optionally PROSAC --
+                               matches are already sorted by SNN ratio", feature_utils.h:184-186): hypothesis h draws its
+                               five rows from the FIRST n(h) rows only, n(h) = max(5, floor(N * (s / 64)^(1/5))),
+                               s = ceil(64 (h + 1) / max_iters) -- PROSAC's growth (n / N)^5 ~ t / T_N with T_N = max_iters
+                               in 64 steps, without its forced newest point; scoring, local optimisation and the
+                               stopping rule use all rows, so the gain is an earlier good model (it shows where the
+                               iteration cap binds), not a lower adaptive count */
 } pgi_params;
 
 /* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.

@@ -124,7 +124,7 @@ void pgo_default_params(pgo_params* p) {
     p->vote_all_rows = 0;
     p->guess_mode = 0;
     p->lo_linear_pct = 35;
-    p->reserved = 0;
+    p->sampler = 0;
 }
 
 uint64_t pgo_mix64(uint64_t z) {
@@ -160,6 +160,25 @@ void pgo_sample5(uint64_t seed, uint64_t pair_id, uint32_t hyp, uint32_t n, uint
         for (uint32_t q = 0; q < got; ++q) dup |= (idx[q] == j);
         if (!dup || k >= 64) idx[got++] = j; /* k>=64: give up on distinctness */
     }
+}
+
+/* Progressive sampling (pgi_params.sampler = 1): hypothesis `hyp` samples the first n(hyp) rows,
+ * n(hyp) = max(5, floor(n * (s / 64)^(1/5))) with s = ceil(64 * (hyp + 1) / T) (T = max_iters): PROSAC's growth
+ * (n / N)^5 ~ t / T_N in 64 steps.  Integer arithmetic on a table of floor(2^32 * (i / 64)^(1/5)) (exact values), the
+ * same table as the kernels' (progressive_rows, csrc/pgi_device.hpp). */
+static const uint32_t kFifthRoot64[65] = {
+    0x00000000u, 0x6F6E336Bu, 0x80000000u, 0x8ACFF893u, 0x93088C35u, 0x99BE7209u, 0x9F741C86u, 0xA472339Du, 0xA8E5A29Du, 0xACEC422Fu, 0xB09AFB46u,
+    0xB4010FB1u, 0xB729FEAEu, 0xBA1EAD01u, 0xBCE6228Cu, 0xBF860882u, 0xC203001Du, 0xC460DFEFu, 0xC6A2E032u, 0xC8CBBB8Du, 0xCADDC7B6u, 0xCCDB0842u,
+    0xCEC53D43u, 0xD09DEEBCu, 0xD26675BFu, 0xD42003BEu, 0xD5CBA87Au, 0xD76A56DCu, 0xD8FCE8FAu, 0xDA842364u, 0xDC00B7F1u, 0xDD734813u, 0xDEDC66D6u,
+    0xE03C9A92u, 0xE1945E57u, 0xE2E42331u, 0xE42C513Du, 0xE56D4891u, 0xE6A76213u, 0xE7DAF02Eu, 0xE9083F70u, 0xEA2F9717u, 0xEB513993u, 0xEC6D64ECu,
+    0xED84532Eu, 0xEE963AB8u, 0xEFA34E8Fu, 0xF0ABBEA6u, 0xF1AFB819u, 0xF2AF6567u, 0xF3AAEEA8u, 0xF4A279B9u, 0xF5962A67u, 0xF6862294u, 0xF772825Eu,
+    0xF85B6838u, 0xF940F10Eu, 0xFA23385Bu, 0xFB025844u, 0xFBDE69ABu, 0xFCB78447u, 0xFD8DBEB6u, 0xFE612E8Du, 0xFF31E869u, 0xFFFFFFFFu};
+uint32_t pgo_progressive_rows(uint32_t hyp, uint32_t n, uint32_t T) {
+    if (n <= 5 || T == 0) return n;
+    const uint64_t step = ((uint64_t)(hyp + 1) * 64u + (T - 1)) / T;
+    if (step >= 64) return n;
+    const uint32_t m = (uint32_t)(((uint64_t)kFifthRoot64[step] * (uint64_t)n) >> 32);
+    return m < 5 ? 5 : m;
 }
 
 /* ---- scoring (f32) ---------------------------------------------------- */
@@ -1123,7 +1142,7 @@ void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, con
         for (uint32_t h = hyps; h < hyps + rs; ++h) {
             uint32_t idx[5];
             float pts[5][4], models[PGO_MAX_MODELS][9];
-            pgo_sample5(seed, pair_id, h, n, idx);
+            pgo_sample5(seed, pair_id, h, prm->sampler ? pgo_progressive_rows(h, n, prm->max_iters) : n, idx);
             for (int k = 0; k < 5; ++k) {
                 pts[k][0] = x1[idx[k]]; pts[k][1] = y1[idx[k]];
                 pts[k][2] = x2[idx[k]]; pts[k][3] = y2[idx[k]];

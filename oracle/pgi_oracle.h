@@ -65,7 +65,7 @@ typedef struct {
                                 1 = rotation-guided: keep R of the guess, re-estimate t (BASELINE config 5) */
     uint32_t lo_linear_pct;  /* LO refits an inlier set of at least this many percent of the rows linearly
                                 (pgo_linear_refit); smaller sets with the n-point Nister refit.  0 = always Nister */
-    uint32_t reserved;
+    uint32_t sampler;        /* 0 uniform, 1 progressive prefix sampling (see include/pgi.h) */
 } pgo_params;
 
 typedef struct {

@@ -128,6 +128,24 @@ PGI_DEV uint32_t draw_index(uint64_t base, uint32_t hyp, uint32_t k, uint32_t n)
     const uint32_t h = fmix32((lo ^ (hyp * 0x9E3779B1u)) + (hi ^ (k * 0x85EBCA77u)));
     return __umulhi(h, n);
 }
+// Progressive sampling (pgi_params.sampler = 1): the first n(hyp) rows, n(hyp) = max(5, floor(n * (s / 64)^(1/5))) with
+// s = ceil(64 * (hyp + 1) / T).  Integer arithmetic on floor(2^32 * (i / 64)^(1/5)) -- the oracle's table
+// (pgo_progressive_rows); no floating point, so nothing to keep bit-compatible and no f64 registers in the round loop.
+__constant__ uint32_t kFifthRoot64[65] = {
+    0x00000000u, 0x6F6E336Bu, 0x80000000u, 0x8ACFF893u, 0x93088C35u, 0x99BE7209u, 0x9F741C86u, 0xA472339Du, 0xA8E5A29Du, 0xACEC422Fu, 0xB09AFB46u,
+    0xB4010FB1u, 0xB729FEAEu, 0xBA1EAD01u, 0xBCE6228Cu, 0xBF860882u, 0xC203001Du, 0xC460DFEFu, 0xC6A2E032u, 0xC8CBBB8Du, 0xCADDC7B6u, 0xCCDB0842u,
+    0xCEC53D43u, 0xD09DEEBCu, 0xD26675BFu, 0xD42003BEu, 0xD5CBA87Au, 0xD76A56DCu, 0xD8FCE8FAu, 0xDA842364u, 0xDC00B7F1u, 0xDD734813u, 0xDEDC66D6u,
+    0xE03C9A92u, 0xE1945E57u, 0xE2E42331u, 0xE42C513Du, 0xE56D4891u, 0xE6A76213u, 0xE7DAF02Eu, 0xE9083F70u, 0xEA2F9717u, 0xEB513993u, 0xEC6D64ECu,
+    0xED84532Eu, 0xEE963AB8u, 0xEFA34E8Fu, 0xF0ABBEA6u, 0xF1AFB819u, 0xF2AF6567u, 0xF3AAEEA8u, 0xF4A279B9u, 0xF5962A67u, 0xF6862294u, 0xF772825Eu,
+    0xF85B6838u, 0xF940F10Eu, 0xFA23385Bu, 0xFB025844u, 0xFBDE69ABu, 0xFCB78447u, 0xFD8DBEB6u, 0xFE612E8Du, 0xFF31E869u, 0xFFFFFFFFu};
+PGI_DEV uint32_t progressive_rows(uint32_t hyp, uint32_t n, uint32_t T) {
+    if (n <= 5u || T == 0u) return n;
+    const uint32_t step = ((hyp + 1u) * 64u + (T - 1u)) / T;  // hyp < max_iters: no overflow
+    if (step >= 64u) return n;
+    const uint32_t m = __umulhi(kFifthRoot64[step], n);
+    return m < 5u ? 5u : m;
+}
+
 // Five distinct row indices: draws k = 0,1,2,... are accepted in order unless they repeat an
 // earlier accepted index.  The first eight draws are hashed up front (independent chains).
 PGI_DEV void sample5(uint64_t base, uint32_t hyp, uint32_t n, uint32_t idx[5]) {

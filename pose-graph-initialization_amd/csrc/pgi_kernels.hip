@@ -763,7 +763,7 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
             const bool active = local < rs;
             const uint32_t hyp = base_hyp + (active ? local : 0u);
             uint32_t idx[5];
-            sample5(rng_base, hyp, n, idx);
+            sample5(rng_base, hyp, prm.sampler ? progressive_rows(hyp, n, prm.max_iters) : n, idx);
             uint32_t my = idx[0];
 #pragma unroll
             for (int k = 1; k < 5; ++k)
@@ -1309,7 +1309,7 @@ void pgi_default_params(pgi_params* p) {
     p->vote_all_rows = 0;
     p->guess_mode = 0;
     p->lo_linear_pct = 35;
-    p->reserved = 0;
+    p->sampler = 0;
 }
 
 pgi_ctx* pgi_create(int device, const pgi_params* params) {

@@ -319,7 +319,8 @@ def test_python_builder_surface():
 
 @pytest.mark.parametrize("kw", [dict(lo_iters=0), dict(lo_iters=1), dict(lo_iters=3), dict(round_size=16), dict(round_size=64),
                                 dict(round_size=20), dict(confidence=0.999), dict(max_iters=100), dict(min_inliers=200),
-                                dict(vote_all_rows=1), dict(guess_quirk=0), dict(fixed_budget=40, lo_iters=1)])
+                                dict(vote_all_rows=1), dict(guess_quirk=0), dict(fixed_budget=40, lo_iters=1),
+                                dict(sampler=1), dict(sampler=1, max_iters=300, round_size=16)])
 def test_parameter_variants_match_oracle(eng, kw):
     sizes = [300, 1000, 64, 2000, 150, 700, 450, 90]
     b = S.make_batch(range(12000, 12000 + len(sizes)), sizes, inlier_ratio=0.45)
@@ -329,7 +330,7 @@ def test_parameter_variants_match_oracle(eng, kw):
         guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
         has[i] = 1
     base = dict(lo_iters=2, round_size=32, confidence=0.99, max_iters=1000, min_inliers=20, vote_all_rows=0,
-                guess_quirk=1, fixed_budget=0)
+                guess_quirk=1, fixed_budget=0, sampler=0)
     eng.set_params(**{**base, **kw})
     try:
         db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has,
@@ -342,6 +343,42 @@ def test_parameter_variants_match_oracle(eng, kw):
                                         O.default_params(**kw), 23, pair_id_base=12000, guesses=guesses, has_guess=has)
     assert np.array_equal(masks.cpu().numpy(), emasks)
     assert_edges_match(got, exp)
+
+
+def test_progressive_sampling_on_ratio_sorted_rows(eng):
+    """pgi_params.sampler = 1 (optional PROSAC): rows sorted by a quality score that correlates with being an
+    inlier, as the matcher's ratio-sorted output does (feature_utils.h:184-186).  HIP == oracle bit for bit.  The schedule
+    finds the model early; the stopping rule still counts inliers over all rows, so the gain shows where the budget is
+    the limit: 35 % inliers need ~875 uniform hypotheses, the cap here is 160.  On unsorted rows nothing is lost."""
+    rng = np.random.default_rng(77)
+    P, N = 256, 1000
+    b = S.make_batch(range(15000, 15000 + P), N, inlier_ratio=0.35)
+    srt = {k: b[k].copy() for k in ("x1", "y1", "x2", "y2")}
+    for i in range(P):
+        a, z = i * N, (i + 1) * N
+        quality = np.where(b["inlier"][a:z], rng.random(N) * 0.8, 0.2 + rng.random(N) * 0.8)  # lower = better match
+        order = a + np.argsort(quality, kind="stable")
+        for k in srt:
+            srt[k][a:z] = b[k][order]
+    stats = {}
+    try:
+        for tag, rows in (("sorted", srt), ("unsorted", b)):
+            for sampler in (0, 1):
+                eng.set_params(sampler=sampler, max_iters=160)
+                db = eng.upload(rows["x1"], rows["y1"], rows["x2"], rows["y2"], b["offsets"], 7.5e-4, seed=5, pair_id_base=15000)
+                edges, masks = eng.estimate_pose_batch(db)
+                got = eng.edges_to_numpy(edges)
+                exp, emasks = O.estimate_pose_batch(rows["x1"], rows["y1"], rows["x2"], rows["y2"], b["offsets"], 7.5e-4,
+                                                    O.default_params(sampler=sampler, max_iters=160), 5, pair_id_base=15000)
+                assert np.array_equal(masks.cpu().numpy(), emasks)
+                assert_edges_match(got, exp)
+                err = np.array([S.rot_err_deg(got["R"][i].reshape(3, 3), b["R"][i]) if got["status"][i] == 1 else 180.0 for i in range(P)])
+                stats[(tag, sampler)] = (got["iters"].mean(), np.mean(err < 1.0))
+    finally:
+        eng.set_params(sampler=0, max_iters=1000)
+    print("hypotheses / recall@1deg:", {k: (round(float(v[0]), 1), round(float(v[1]), 3)) for k, v in stats.items()})
+    assert stats[("sorted", 1)][1] > stats[("sorted", 0)][1] + 0.1            # the point of the schedule
+    assert abs(stats[("unsorted", 1)][1] - stats[("unsorted", 0)][1]) < 0.12   # without an ordering: neither gain nor harm
 
 
 def test_understated_max_corr_is_reported_not_overrun(eng):
