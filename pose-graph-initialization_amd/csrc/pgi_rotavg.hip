@@ -20,6 +20,8 @@
 #include "pgi_internal.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(1024) void rot_solve_kernel(uint32_t n_views, const
                                                          const int8_t* __restrict__ adj_sign,
                                                          const uint8_t* __restrict__ is_root,
                                                          const double* __restrict__ omega, const double* __restrict__ w,
-                                                         uint32_t cg_iters, double cg_tol, double* __restrict__ diag,
+                                                         uint32_t cg_iters, double cg_tol, uint32_t row_lanes, double* __restrict__ diag,
                                                          double* __restrict__ x, double* __restrict__ r,
                                                          double* __restrict__ p, double* __restrict__ Ap,
                                                          double* __restrict__ stats /* mean|d|, cg iterations */) {
@@ -186,24 +188,32 @@ __global__ __launch_bounds__(1024) void rot_solve_kernel(uint32_t n_views, const
         for (int c = 0; c < 3; ++c) done &= !(rz[c] > cg_tol * cg_tol * rz0[c]);
         if (done) break;  // uniform: rz is identical in every thread
         double pAp[3] = {0, 0, 0};
-        for (uint32_t k = tid; k < n_views; k += 1024) {
+        // `row_lanes` lanes share a view (its incidences strided over them, partial rows combined by a fixed xor tree):
+        // one thread per view walks tens of neighbours as a chain of dependent gathers, the whole cost of the product
+        const uint32_t sub = (uint32_t)tid & (row_lanes - 1u), per_pass = 1024u / row_lanes;
+        for (uint32_t k0 = 0; k0 < n_views; k0 += per_pass) {  // uniform trip count: the shuffles below need every lane
+            const uint32_t k = k0 + (uint32_t)tid / row_lanes;
+            const bool live = k < n_views, free_k = live && !is_root[k];
             double y[3] = {0, 0, 0};
-            if (!is_root[k]) {
-                const double d = diag[k];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) y[c] = d * p[3 * (size_t)k + c];
-                for (uint32_t a = adj_ptr[k]; a < adj_ptr[k + 1]; ++a) {
+            if (free_k)
+                for (uint32_t a = adj_ptr[k] + sub; a < adj_ptr[k + 1]; a += row_lanes) {
                     const uint32_t o = adj_other[a];
                     if (is_root[o]) continue;
                     const double we = w[adj_edge[a]];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) y[c] -= we * p[3 * (size_t)o + c];
                 }
-            }
+            for (uint32_t m = 1; m < row_lanes; m <<= 1)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                Ap[3 * (size_t)k + c] = y[c];
-                pAp[c] += p[3 * (size_t)k + c] * y[c];
+                for (int c = 0; c < 3; ++c) y[c] += __shfl_xor(y[c], (int)m);
+            if (live && sub == 0u) {
+                const double d = diag[k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double pk = p[3 * (size_t)k + c], yc = free_k ? d * pk + y[c] : 0.0;
+                    Ap[3 * (size_t)k + c] = yc;
+                    pAp[c] += pk * yc;
+                }
             }
         }
         block_sum3(pAp, red, tid);
@@ -246,12 +256,13 @@ __global__ __launch_bounds__(1024) void rot_solve_kernel(uint32_t n_views, const
     }
 }
 
-// ---- multi-workgroup PCG (large graphs): the same recurrences as rot_solve_kernel, one phase per launch,
-// scalars (rz, alpha, beta, done) resident on the device; block partials are reduced in a fixed order.
+// ---- multi-workgroup PCG (large graphs): scalars (gamma, alpha, beta, done) resident on the device; block partials
+// are reduced in a fixed order.
 struct CgState {
     double rz[3], rz0[3], alpha[3], beta[3];
     double mean_step, iters;
     int done;
+    unsigned int ticket;  // workgroups that have delivered their partial sums (fused kernels)
 };
 constexpr int kCgBlock = 256;
 
@@ -315,114 +326,123 @@ __global__ __launch_bounds__(kCgBlock) void cg_init_kernel(uint32_t n_views, con
         for (int c = 0; c < 3; ++c) partial[3 * blockIdx.x + c] = rz[c];
 }
 
-// one block: fixed-order sum of the block partials -> mode 0: rz0 = rz; mode 1: alpha = rz / pAp;
-// mode 2: rz_new -> beta, rz, convergence flag, iteration count
-__global__ __launch_bounds__(kCgBlock) void cg_reduce_kernel(const double* __restrict__ partial, uint32_t n_blocks, int mode,
-                                                             double tol, CgState* __restrict__ st) {
-    __shared__ double red[3 * kCgBlock];
-    const int tid = threadIdx.x;
-    if (mode != 0 && st->done) return;
-    double v[3] = {0, 0, 0};
-    for (uint32_t b = tid; b < n_blocks; b += kCgBlock)
-        for (int c = 0; c < 3; ++c) v[c] += partial[3 * (size_t)b + c];
-    block_sum3_256(v, red, tid);
+// ---- ONE launch per PCG iteration.  The solve is bound by the ~13 us between small dependent kernels and by the depth
+// of the gather chains inside them, not by arithmetic, so the iteration is arranged around a single grid-wide
+// synchronisation point (the kernel boundary):
+//   * Chronopoulos-Gear form of preconditioned CG: with s = A z kept next to q = A p, both inner products of an
+//     iteration (gamma = r.z, delta = z.s) belong to the same vectors and are reduced together;
+//       beta = gamma' / gamma,  alpha' = gamma' / (delta' - beta gamma' / alpha),
+//       p = z + beta p,  q = s + beta q,  x += alpha p,  r -= alpha q,  z = r / diag,  s = A z
+//   * a thread rebuilds the z entries it gathers from the PREVIOUS iteration's vectors,
+//       z'[o] = (r[o] - alpha (s[o] + beta q[o])) / diag[o],
+//     so the vector update needs no launch of its own (r, q, s are double-buffered: neighbours read the old ones);
+//   * kRowLanes lanes share a view -- a view of a dense scene graph has tens of neighbours, and one thread walking
+//     them is a chain of dependent gathers (40 us per product at V = 5000); the partial rows are combined by a fixed
+//     xor tree;
+//   * the fixed-order sum of the block partials is done by whichever workgroup delivers last (ticket counter).
+// Everything is a fixed function of the graph: same input, same bits, on any number of ranks.
+constexpr int kRowLanes = 16;
+constexpr int kRowsPerBlock = kCgBlock / kRowLanes;
+
+__device__ bool deliver_partial(const double v[6], double* __restrict__ partial, CgState* __restrict__ st, int tid) {
+    __shared__ bool last;
     if (tid == 0) {
-        if (mode == 0) {
-            bool done = true;
-            for (int c = 0; c < 3; ++c) {
-                st->rz[c] = st->rz0[c] = v[c];
-                done &= !(v[c] > 0.0);
-            }
-            st->done = done;
-            st->iters = 0;
-        } else if (mode == 1) {
-            for (int c = 0; c < 3; ++c) st->alpha[c] = v[c] > 0.0 ? st->rz[c] / v[c] : 0.0;
-        } else {
-            bool done = true;
-            for (int c = 0; c < 3; ++c) {
-                st->beta[c] = st->rz[c] > 0.0 ? v[c] / st->rz[c] : 0.0;
-                st->rz[c] = v[c];
-                done &= !(v[c] > tol * tol * st->rz0[c]);
-            }
-            st->iters += 1;
-            st->done = done;
-        }
+        for (int c = 0; c < 6; ++c) partial[6 * blockIdx.x + c] = v[c];
+        __threadfence();  // the partials leave this XCD's L2 before the ticket is taken
+        last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1u;
     }
+    __syncthreads();
+    if (last) __threadfence();  // and the last workgroup reads the others' from memory
+    return last;
 }
 
-__global__ __launch_bounds__(kCgBlock) void cg_spmv_kernel(uint32_t n_views, const uint32_t* __restrict__ adj_ptr,
-                                                           const uint32_t* __restrict__ adj_edge,
-                                                           const uint32_t* __restrict__ adj_other,
-                                                           const uint8_t* __restrict__ is_root, const double* __restrict__ w,
-                                                           const double* __restrict__ diag, const double* __restrict__ p,
-                                                           double* __restrict__ Ap, double* __restrict__ partial,
-                                                           const CgState* __restrict__ st) {
+// init_pass: alpha = beta = 0 (x and r stay, p becomes z, q becomes 0): produces s0 = A z0, gamma0, delta0, alpha0
+__global__ __launch_bounds__(kCgBlock) void cg_iteration_kernel(uint32_t n_views, const uint32_t* __restrict__ adj_ptr,
+                                                                const uint32_t* __restrict__ adj_edge,
+                                                                const uint32_t* __restrict__ adj_other,
+                                                                const uint8_t* __restrict__ is_root, const double* __restrict__ w,
+                                                                const double* __restrict__ diag, double* __restrict__ x,
+                                                                double* __restrict__ p, const double* r_old, double* r_new,
+                                                                const double* q_old, double* q_new, const double* s_old,
+                                                                double* s_new, int init_pass, double tol,
+                                                                double* __restrict__ partial, CgState* __restrict__ st) {
     __shared__ double red[3 * kCgBlock];
-    if (st->done) return;
-    const int tid = threadIdx.x;
-    const uint32_t k = blockIdx.x * kCgBlock + tid;
-    double pAp[3] = {0, 0, 0};
+    if (!init_pass && st->done) return;
+    const int tid = threadIdx.x, sub = tid & (kRowLanes - 1);
+    const uint32_t k = blockIdx.x * kRowsPerBlock + (uint32_t)(tid / kRowLanes);
+    double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
+    if (!init_pass)
+        for (int c = 0; c < 3; ++c) { alpha[c] = st->alpha[c]; beta[c] = st->beta[c]; }
+    double gd[6] = {0, 0, 0, 0, 0, 0};  // gamma (3), delta (3)
     if (k < n_views) {
+        const bool free_k = !is_root[k];
+        // neighbours: their new z, rebuilt from the old vectors
         double y[3] = {0, 0, 0};
-        if (!is_root[k]) {
-            const double d = diag[k];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) y[c] = d * p[3 * (size_t)k + c];
-            for (uint32_t a = adj_ptr[k]; a < adj_ptr[k + 1]; ++a) {
+        if (free_k)
+            for (uint32_t a = adj_ptr[k] + (uint32_t)sub; a < adj_ptr[k + 1]; a += kRowLanes) {
                 const uint32_t o = adj_other[a];
                 if (is_root[o]) continue;
-                const double we = w[adj_edge[a]];
+                const double we = w[adj_edge[a]], dn = diag[o], inv = dn > 0.0 ? 1.0 / dn : 0.0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) y[c] -= we * p[3 * (size_t)o + c];
+                for (int c = 0; c < 3; ++c) {
+                    const size_t i = 3 * (size_t)o + c;
+                    const double qo = s_old[i] + beta[c] * q_old[i];
+                    y[c] -= we * ((r_old[i] - alpha[c] * qo) * inv);
+                }
+            }
+#pragma unroll
+        for (int m = 1; m < kRowLanes; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y[c] += __shfl_xor(y[c], m);
+        if (sub == 0) {  // the view's own entries of every vector
+            const double d = diag[k], inv = d > 0.0 ? 1.0 / d : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = 3 * (size_t)k + c;
+                const double ro = r_old[i];
+                const double pk = ro * inv + beta[c] * p[i];
+                const double qk = s_old[i] + beta[c] * q_old[i];
+                const double rn = ro - alpha[c] * qk, zn = rn * inv;
+                const double sn = free_k ? d * zn + y[c] : 0.0;
+                p[i] = pk;
+                q_new[i] = qk;
+                x[i] += alpha[c] * pk;
+                r_new[i] = rn;
+                s_new[i] = sn;
+                gd[c] = rn * zn;
+                gd[3 + c] = zn * sn;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Ap[3 * (size_t)k + c] = y[c];
-            pAp[c] = p[3 * (size_t)k + c] * y[c];
-        }
     }
-    block_sum3_256(pAp, red, tid);
-    if (tid == 0)
-        for (int c = 0; c < 3; ++c) partial[3 * blockIdx.x + c] = pAp[c];
-}
-
-__global__ __launch_bounds__(kCgBlock) void cg_update_kernel(uint32_t n_views, const double* __restrict__ diag,
-                                                             const double* __restrict__ p, const double* __restrict__ Ap,
-                                                             double* __restrict__ x, double* __restrict__ r,
-                                                             double* __restrict__ partial, const CgState* __restrict__ st) {
-    __shared__ double red[3 * kCgBlock];
-    if (st->done) return;
-    const int tid = threadIdx.x;
-    const uint32_t k = blockIdx.x * kCgBlock + tid;
-    double rzn[3] = {0, 0, 0};
-    if (k < n_views) {
-        const double d = diag[k], inv = d > 0.0 ? 1.0 / d : 0.0;
-#pragma unroll
+    block_sum3_256(gd, red, tid);
+    block_sum3_256(gd + 3, red, tid);
+    if (!deliver_partial(gd, partial, st, tid)) return;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = tid; b < gridDim.x; b += kCgBlock)
+        for (int c = 0; c < 6; ++c) v[c] += partial[6 * (size_t)b + c];
+    block_sum3_256(v, red, tid);
+    block_sum3_256(v + 3, red, tid);
+    if (tid == 0) {
+        bool done = true;
         for (int c = 0; c < 3; ++c) {
-            const size_t i = 3 * (size_t)k + c;
-            x[i] += st->alpha[c] * p[i];
-            const double rn = r[i] - st->alpha[c] * Ap[i];
-            r[i] = rn;
-            rzn[c] = rn * (rn * inv);
+            const double g = v[c], dl = v[3 + c];
+            if (init_pass) {
+                st->rz0[c] = g;
+                st->beta[c] = 0.0;
+                st->alpha[c] = dl > 0.0 ? g / dl : 0.0;
+                done &= !(g > 0.0);
+            } else {
+                const double bt = st->rz[c] > 0.0 ? g / st->rz[c] : 0.0;
+                const double den = alpha[c] != 0.0 ? dl - bt * g / alpha[c] : dl;
+                st->beta[c] = bt;
+                st->alpha[c] = den > 0.0 ? g / den : 0.0;
+                done &= !(g > tol * tol * st->rz0[c]);
+            }
+            st->rz[c] = g;
         }
-    }
-    block_sum3_256(rzn, red, tid);
-    if (tid == 0)
-        for (int c = 0; c < 3; ++c) partial[3 * blockIdx.x + c] = rzn[c];
-}
-
-__global__ __launch_bounds__(kCgBlock) void cg_direction_kernel(uint32_t n_views, const double* __restrict__ diag,
-                                                                const double* __restrict__ r, double* __restrict__ p,
-                                                                const CgState* __restrict__ st) {
-    if (st->done) return;
-    const uint32_t k = blockIdx.x * kCgBlock + threadIdx.x;
-    if (k >= n_views) return;
-    const double d = diag[k], inv = d > 0.0 ? 1.0 / d : 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const size_t i = 3 * (size_t)k + c;
-        p[i] = r[i] * inv + st->beta[c] * p[i];
+        st->iters = init_pass ? 0.0 : st->iters + 1.0;
+        st->done = done;
+        st->ticket = 0;
     }
 }
 
@@ -579,9 +599,10 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_v
     const size_t o_R = carve(V * 72), o_ptr = carve((V + 1) * 4),
                  o_aedge = carve(2 * E * 4), o_aother = carve(2 * E * 4), o_asign = carve(2 * E),
                  o_root = carve(V), o_omega = carve(E * 24), o_w = carve(E * 8), o_diag = carve(V * 8),
-                 o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24),
+                 o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24), o_r2 = carve(V * 24), o_q2 = carve(V * 24), o_s = carve(V * 24),
+                 o_s2 = carve(V * 24),
                  o_stats = carve(16), o_cg = carve(sizeof(CgState)),
-                 o_part = carve(3 * 8 * ((V + kCgBlock - 1) / kCgBlock + 1));
+                 o_part = carve(6 * 8 * ((V + kRowsPerBlock - 1) / kRowsPerBlock + 1));
     char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, off));
     struct Guard {
@@ -596,15 +617,18 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_v
     HIP_TRY(hipMemcpyAsync(d + o_asign, asign.data(), 2 * E, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_root, is_root.data(), V, hipMemcpyHostToDevice, st));
     const double sigma = prm.sigma_deg * 3.14159265358979323846 / 180.0;
+    const bool trace = std::getenv("PGI_ROTAVG_TRACE") != nullptr;
     uint32_t iters = 0;
     for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
         hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_rot, n_edges,
                            (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0, sigma, (double*)(d + o_omega), (double*)(d + o_w));
         if (n_views <= kSingleWgViews) {
+            uint32_t row_lanes = 16;  // as many lanes per view as keep all views in one pass of the 1024 threads
+            while (row_lanes > 1 && (uint64_t)n_views * row_lanes > 1024u) row_lanes >>= 1;
             hipLaunchKernelGGL(rot_solve_kernel, dim3(1), dim3(1024), 0, st, n_views, (const uint32_t*)(d + o_ptr),
                                (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const int8_t*)(d + o_asign),
                                (const uint8_t*)(d + o_root), (const double*)(d + o_omega), (const double*)(d + o_w),
-                               prm.cg_iters, 1e-10, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
+                               prm.cg_iters, 1e-10, row_lanes, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
                                (double*)(d + o_p), (double*)(d + o_Ap), (double*)(d + o_stats));
         } else {  // multi-workgroup PCG: launches are cheap next to a one-CU solve at this size
             const uint32_t nb = (n_views + kCgBlock - 1) / kCgBlock;
@@ -614,22 +638,26 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_v
                                (const uint32_t*)(d + o_aedge), (const int8_t*)(d + o_asign), (const uint8_t*)(d + o_root),
                                (const double*)(d + o_omega), (const double*)(d + o_w), (double*)(d + o_diag),
                                (double*)(d + o_x), (double*)(d + o_r), (double*)(d + o_p), part);
-            hipLaunchKernelGGL(cg_reduce_kernel, dim3(1), dim3(kCgBlock), 0, st, part, nb, 0, 1e-10, cst);
+            const uint32_t nbp = (n_views + kRowsPerBlock - 1) / kRowsPerBlock;  // kRowLanes lanes per view
+            double* rbuf[2] = {(double*)(d + o_r), (double*)(d + o_r2)};
+            double* qbuf[2] = {(double*)(d + o_Ap), (double*)(d + o_q2)};
+            double* sbuf[2] = {(double*)(d + o_s), (double*)(d + o_s2)};
+            int cur = 0;  // buffers holding the vectors of the last finished iteration
+            HIP_TRY(hipMemsetAsync(d + o_cg + offsetof(CgState, ticket), 0, sizeof(unsigned int), st));
+            HIP_TRY(hipMemsetAsync(qbuf[0], 0, V * 24, st));
+            HIP_TRY(hipMemsetAsync(sbuf[0], 0, V * 24, st));
+            auto iterate = [&](int init_pass) {
+                hipLaunchKernelGGL(cg_iteration_kernel, dim3(nbp), dim3(kCgBlock), 0, st, n_views, (const uint32_t*)(d + o_ptr),
+                                   (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const uint8_t*)(d + o_root),
+                                   (const double*)(d + o_w), (const double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_p),
+                                   (const double*)rbuf[cur], rbuf[cur ^ 1], (const double*)qbuf[cur], qbuf[cur ^ 1],
+                                   (const double*)sbuf[cur], sbuf[cur ^ 1], init_pass, 1e-10, part, cst);
+                cur ^= 1;
+            };
+            iterate(1);
             for (uint32_t ci = 0; ci < prm.cg_iters;) {
                 const uint32_t chunk = std::min<uint32_t>(16, prm.cg_iters - ci);  // kernels no-op once converged
-                for (uint32_t q = 0; q < chunk; ++q) {
-                    hipLaunchKernelGGL(cg_spmv_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const uint32_t*)(d + o_ptr),
-                                       (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother),
-                                       (const uint8_t*)(d + o_root), (const double*)(d + o_w), (const double*)(d + o_diag),
-                                       (const double*)(d + o_p), (double*)(d + o_Ap), part, cst);
-                    hipLaunchKernelGGL(cg_reduce_kernel, dim3(1), dim3(kCgBlock), 0, st, part, nb, 1, 1e-10, cst);
-                    hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_diag),
-                                       (const double*)(d + o_p), (const double*)(d + o_Ap), (double*)(d + o_x),
-                                       (double*)(d + o_r), part, cst);
-                    hipLaunchKernelGGL(cg_reduce_kernel, dim3(1), dim3(kCgBlock), 0, st, part, nb, 2, 1e-10, cst);
-                    hipLaunchKernelGGL(cg_direction_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views,
-                                       (const double*)(d + o_diag), (const double*)(d + o_r), (double*)(d + o_p), cst);
-                }
+                for (uint32_t q = 0; q < chunk; ++q) iterate(0);
                 ci += chunk;
                 int done = 0;
                 HIP_TRY(hipMemcpyAsync(&done, (char*)cst + offsetof(CgState, done), sizeof(int), hipMemcpyDeviceToHost, st));
@@ -655,6 +683,17 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_v
             stats[0] = sum / (double)n_views;
         }
         iters = it + 1;
+        if (trace) {  // PGI_ROTAVG_TRACE=1: one line per outer iteration
+            double cg_it = stats[1];
+            if (n_views > kSingleWgViews) {
+                CgState hs;
+                HIP_TRY(hipMemcpyAsync(&hs, d + o_cg, sizeof hs, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                cg_it = hs.iters;
+            }
+            std::fprintf(stderr, "[rotavg] outer %2u (%s): %3.0f PCG iterations, mean step %.3e rad\n", it, it < prm.l1_iters ? "L1" : "IRLS", cg_it,
+                         stats[0]);
+        }
         if (stats[0] < prm.tol) break;
     }
     HIP_TRY(hipMemcpyAsync(h_R_out, d + o_R, V * 72, hipMemcpyDeviceToHost, st));
