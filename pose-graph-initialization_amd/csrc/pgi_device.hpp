@@ -197,6 +197,24 @@ PGI_DEV void sampson_terms(const float e[9], float x1, float y1, float x2, float
     r2 = r * r;
 }
 
+// Two models at once on the packed-f32 VALU path (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per lane and
+// instruction, which is what the chip's f32 vector peak is quoted on).  Component by component the same operations in
+// the same order as sampson_terms, so the bits are the same.  K1 is bound by vector-ALU issue (>= 68 % busy,
+// profiles/r02_k1_pmc.json), so instructions saved are time saved.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+PGI_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+PGI_DEV void sampson_terms2(const f32x2 e[9], float x1, float y1, float x2, float y2, f32x2& r2, f32x2& den) {
+    const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, X2 = {x2, x2}, Y2 = {y2, y2};
+    const f32x2 rxc = pk_fma(e[0], X2, pk_fma(e[3], Y2, e[6]));
+    const f32x2 ryc = pk_fma(e[1], X2, pk_fma(e[4], Y2, e[7]));
+    const f32x2 rwc = pk_fma(e[2], X2, pk_fma(e[5], Y2, e[8]));
+    const f32x2 r = pk_fma(X1, rxc, pk_fma(Y1, ryc, rwc));
+    const f32x2 rx = pk_fma(e[0], X1, pk_fma(e[1], Y1, e[2]));
+    const f32x2 ry = pk_fma(e[3], X1, pk_fma(e[4], Y1, e[5]));
+    den = pk_fma(rxc, rxc, pk_fma(ryc, ryc, pk_fma(rx, rx, ry * ry)));
+    r2 = r * r;
+}
+
 // ---- small f64 helpers -----------------------------------------------------------
 PGI_DEV int pivot_key(double a, int row) {
     const uint32_t hi = (uint32_t)__double2hiint(a) & 0x7FFFFFFFu;

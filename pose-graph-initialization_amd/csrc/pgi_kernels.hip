@@ -124,12 +124,12 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
     // good as the bar (n_bar inliers) is expected to show
     const uint32_t k_min = n_bar ? (uint32_t)((16ull * n_bar) / n) : 0u;
     for (int m0 = m_begin; m0 < m_end; m0 += 4) {
-        float e[4][9];
+        f32x2 e[2][9];  // models (m0, m0 + 1) and (m0 + 2, m0 + 3), packed
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             const int m = min(m0 + mm, m_end - 1);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) e[mm][c] = queue[9 * m + c];  // VGPRs: no constant-bus moves
+            for (int c = 0; c < 9; ++c) e[mm >> 1][c][mm & 1] = queue[9 * m + c];  // VGPRs: no constant-bus moves
         }
         const int bar = __builtin_amdgcn_readfirstlane(max(floor_score, b_score));  // wave-uniform
         uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
@@ -145,17 +145,21 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
             }
             uint32_t c3v[4];
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                float r2, den;
-                sampson_terms(e[mm], p.x, p.y, p.z, p.w, r2, den);
-                const float t = thr2 * den;
-                const uint32_t c0 = __popcll(__ballot(r2 < 0.25f * t));
-                const uint32_t c1 = __popcll(__ballot(r2 < 0.5625f * t));
-                const uint32_t c2 = __popcll(__ballot(r2 < t));
-                const uint32_t c3 = __popcll(__ballot(r2 < 2.25f * t));
-                sc[mm] += (c0 + c1) + (c2 + c3);
-                ni[mm] += c2;
-                c3v[mm] = c3;
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x2 r2, den;
+                sampson_terms2(e[pr], p.x, p.y, p.z, p.w, r2, den);
+                const f32x2 t = den * thr2, t0 = t * 0.25f, t1 = t * 0.5625f, t3 = t * 2.25f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int mm = 2 * pr + h;
+                    const uint32_t c0 = __popcll(__ballot(r2[h] < t0[h]));
+                    const uint32_t c1 = __popcll(__ballot(r2[h] < t1[h]));
+                    const uint32_t c2 = __popcll(__ballot(r2[h] < t[h]));
+                    const uint32_t c3 = __popcll(__ballot(r2[h] < t3[h]));
+                    sc[mm] += (c0 + c1) + (c2 + c3);
+                    ni[mm] += c2;
+                    c3v[mm] = c3;
+                }
             }
             if (base == 0) {
                 alive = (c3v[0] >= k_min ? 1u : 0u) | (c3v[1] >= k_min ? 2u : 0u) | (c3v[2] >= k_min ? 4u : 0u) |

@@ -71,6 +71,14 @@ def main():
         "grbm_gui_active_per_launch": round(c["GRBM_GUI_ACTIVE"]),
         "shader_clock_ghz_est": round(c["GRBM_GUI_ACTIVE"] / 8 / (c["_avg_us_lds"] * 1e-6) / 1e9, 3),  # summed over the 8 XCDs
     }
+    # SIMD-level view: a wave64 VALU instruction holds its SIMD's vector ALU for 4 cycles (16 lanes per cycle; f64 FMA and
+    # unpacked f32 alike -- the 157.3 TFLOP/s f32 peak assumes v_pk_* instructions); transcendental, f64 division / sqrt
+    # sequences and 32-bit integer multiplies take longer, so this is a LOWER bound on how busy the vector ALUs are.
+    simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * (c["_avg_us_mix"] / c["_avg_us_lds"]) * 1024
+    out["valu_issue_busy_frac"] = round(c["SQ_INSTS_VALU"] * 4 / simd_cycles, 3)
+    out["valu_issue_busy_note"] = ("SQ_INSTS_VALU x 4 cycles / (shader cycles x 1024 SIMDs): the kernel is bound by vector-ALU issue, "
+                                   "not by memory or latency -- the per-wave 'waiting' share is time spent behind the other three "
+                                   "wavefronts of the SIMD")
     dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
     json.dump(out, open(dst, "w"), indent=2)
     print(json.dumps(out, indent=2))
