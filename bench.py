@@ -210,6 +210,19 @@ def main():
         ms = a.elapsed_time(z)
         out["fixed_budget_256"] = {"edges_per_s": round(P / (ms * 1e-3), 1), "kernel_ms": round(ms, 3)}
         eng.set_params(fixed_budget=args.fixed_budget)
+        # PCIe-inclusive rate (never `value`), headline variant first: page-locked caller buffers (hipHostMalloc, here through
+        # torch's pinned allocator), true asynchronous DMA on a dedicated high-priority copy stream
+        px = [torch.from_numpy(np.ascontiguousarray(b[k], np.float32)).pin_memory().numpy() for k in ("x1", "y1", "x2", "y2")]
+        pe = torch.zeros(P * EDGE_RECORD_BYTES, dtype=torch.uint8).pin_memory().numpy().view(L.EDGE_DTYPE)
+        pm = torch.zeros(P * N, dtype=torch.uint8).pin_memory().numpy()
+        for _ in range(4):
+            eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
+        t_pin = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
+            t_pin.append(time.perf_counter() - t0)
+        t_pin = float(np.median(t_pin))
         # PCIe-inclusive rate: host SoA in, edge records + masks back to the host (never `value`).  (i) the naive
         # sequence upload -> kernel -> download; (ii) pgi_estimate_pose_batch_host: chunks on two streams, copies
         # overlapping kernels
@@ -230,19 +243,6 @@ def main():
             he, hm = eng.estimate_pose_batch_host(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
             t_pipe.append(time.perf_counter() - t0)
         t_pipe = float(np.median(t_pipe))
-        # (iii) the same with page-locked caller buffers (hipHostMalloc, here through torch's pinned allocator): true
-        # asynchronous DMA on dedicated high-priority copy streams
-        px = [torch.from_numpy(np.ascontiguousarray(b[k], np.float32)).pin_memory().numpy() for k in ("x1", "y1", "x2", "y2")]
-        pe = torch.zeros(P * EDGE_RECORD_BYTES, dtype=torch.uint8).pin_memory().numpy().view(L.EDGE_DTYPE)
-        pm = torch.zeros(P * N, dtype=torch.uint8).pin_memory().numpy()
-        for _ in range(4):
-            eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
-        t_pin = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            eng.estimate_pose_batch_host(*px, b["offsets"], thr, seed=seed, pair_id_base=pair_base, out=(pe, pm))
-            t_pin.append(time.perf_counter() - t0)
-        t_pin = float(np.median(t_pin))
         pinned_same = bool(np.array_equal(pm, masks_host) and np.array_equal(pe["E"], got["E"]))
         out["h2d_inclusive"] = {"edges_per_s": round(P / t_pin, 1), "ms": round(1e3 * t_pin, 2),
                                 "pageable_edges_per_s": round(P / t_pipe, 1), "pageable_ms": round(1e3 * t_pipe, 2),

@@ -58,7 +58,7 @@ struct pgi_ctx {
         hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
         bool used = false;
     } hslot[4];
-    hipStream_t copy_in = nullptr, copy_out = nullptr;  // high-priority copy streams of the host-pointer path
+    hipStream_t copy_in = nullptr, copy_out = nullptr;  // high-priority input stream of the host-pointer path (copy_out: unused)
     int resident_wgs = 768;  // workgroups of K1 the device keeps resident (CUs x 3): the chunk quantum of the host path
     void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
     size_t match_ws_bytes = 0;

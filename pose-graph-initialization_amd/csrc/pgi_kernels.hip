@@ -1540,9 +1540,8 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         return at.type == hipMemoryTypeHost;
     };
     const bool pin_in = page_locked(h_x1) && page_locked(h_y1) && page_locked(h_x2) && page_locked(h_y2);
-    // Results always return on the chunk's own stream, two launches behind the front: measured faster than an immediate
-    // copy on a dedicated stream even for page-locked result buffers (8.6 ms vs 9.0-13 ms, scripts/host_path_probe.py)
-    const bool pin_out = false;
+    // (results always return on the chunk's kernel stream, two launches behind the front: measured faster than an
+    // immediate copy on a dedicated stream even for page-locked result buffers, 8.6 ms vs 9.0-13 ms)
     const bool pinned = pin_in;
     // Chunks are multiples of the number of resident workgroups (no chunk ends in a mostly empty last wave of
     // workgroups).  Page-locked: PCIe (~57 GB/s) is only ~1.3x faster than K1 consumes rows, so equal, small chunks keep
@@ -1582,19 +1581,22 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         L.total = o;
         return L;
     };
-    // Streams: copies travel on two dedicated HIGH-PRIORITY streams (in / out), kernels on one stream per slot.  A copy
+    // Streams: input copies travel on ONE dedicated HIGH-PRIORITY stream, kernels (and the result copies behind them)
+    // alternate between TWO streams -- consecutive chunks overlap, and that is all the overlap there is to have.  A copy
     // that shares a stream -- or a priority -- with K1 is starved by the ten thousand workgroups K1 keeps queued
-    // (measured: page-locked buffers were SLOWER than pageable ones that way); events carry the dependencies.
+    // (measured: page-locked buffers were SLOWER than pageable ones that way); events carry the dependencies.  Three
+    // streams, not seven: the runtime multiplexes streams onto a handful of hardware queues, and with one kernel stream
+    // per device slot two chunks that should overlap could end up on the same queue (20 % slower in a process that had
+    // already created other streams, e.g. bench.py after its resident runs; GPU_MAX_HW_QUEUES=12 made it go away).
     constexpr size_t kSlots = 4;
     if (!ctx->copy_in) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
         HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_in, hipStreamNonBlocking, hi));
-        HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_out, hipStreamNonBlocking, hi));
     }
     for (size_t k = 0; k < kSlots; ++k) {
         pgi_ctx::HostSlot& S = ctx->hslot[k];
-        if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        if (k < 2 && !S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         if (!S.in_done) {
             HIP_TRY(hipEventCreateWithFlags(&S.in_done, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&S.k_done, hipEventDisableTiming));
@@ -1609,7 +1611,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t r0 = h_offsets[p0] - h_offsets[0], rows = h_offsets[p0 + np] - h_offsets[p0];
         char* d = (char*)S.d;
-        hipStream_t out = pin_out ? ctx->copy_out : S.stream;
+        hipStream_t out = ctx->hslot[c & 1].stream;  // behind the chunk's own kernel
         HIP_TRY(hipStreamWaitEvent(out, S.k_done, 0));
         HIP_TRY(hipMemcpyAsync(h_edges + p0, d + L.edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, out));
         if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + L.masks, rows, hipMemcpyDeviceToHost, out));
@@ -1654,7 +1656,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         }
         // pageable buffers: every copy is staged by the runtime on this thread; keep them on the slot's own stream so
         // that the copies of neighbouring chunks still overlap (one shared copy stream would serialise them)
-        hipStream_t in = pinned ? ctx->copy_in : S.stream;
+        hipStream_t in = ctx->copy_in;
         if (rows) {
             HIP_TRY(hipMemcpyAsync(d + L.x1, h_x1 + r0, rows * 4, hipMemcpyHostToDevice, in));
             HIP_TRY(hipMemcpyAsync(d + L.y1, h_y1 + r0, rows * 4, hipMemcpyHostToDevice, in));
@@ -1672,16 +1674,17 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         const Lay& L = lay[c % kSlots];
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0, max_corr = max_corr_of[c % kSlots];
         char* d = (char*)S.d;
-        HIP_TRY(hipStreamWaitEvent(S.stream, S.in_done, 0));
+        hipStream_t ks = ctx->hslot[c & 1].stream;
+        HIP_TRY(hipStreamWaitEvent(ks, S.in_done, 0));
         pgi_batch b{};
         b.d_x1 = (const float*)(d + L.x1); b.d_y1 = (const float*)(d + L.y1); b.d_x2 = (const float*)(d + L.x2); b.d_y2 = (const float*)(d + L.y2);
         b.d_offsets = (const uint64_t*)(d + L.off); b.d_thr = (const double*)(d + L.thr);
         b.d_guess_Rt = guesses ? (const double*)(d + L.guess) : nullptr;
         b.d_has_guess = guesses ? (const uint8_t*)(d + L.has) : nullptr;
         b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
-        const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), S.stream, &S.d_bucket, &S.bucket_bytes);
+        const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), ks, &S.d_bucket, &S.bucket_bytes);
         if (rc < 0) return rc;
-        HIP_TRY(hipEventRecord(S.k_done, S.stream));
+        HIP_TRY(hipEventRecord(S.k_done, ks));
         S.used = true;
         return PGI_SUCCESS;
     };
@@ -1694,23 +1697,20 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             const int rc1 = stage_in(c + 1);
             if (rc1 < 0) return rc1;
         }
-        const int rcl = launch(c);
-        if (rcl < 0) return rcl;
-        // Results: page-locked -> enqueue the device-to-host copies right away (asynchronous).  Pageable -> a copy to
-        // pageable memory blocks this thread until the kernel is done, so fetch a chunk only two launches later.
-        if (pin_out) {
-            const int rc2 = fetch(c);
-            if (rc2 < 0) return rc2;
-        } else if (c >= 2) {
+        // Results of chunk c - 2 go out on the stream both chunks share, queued BEFORE the kernel of chunk c (the stream is
+        // first in, first out).  Two launches behind the front: a copy into pageable memory blocks this thread until
+        // its kernel is done.
+        if (c >= 2) {
             const int rc2 = fetch(c - 2);
             if (rc2 < 0) return rc2;
         }
+        const int rcl = launch(c);
+        if (rcl < 0) return rcl;
     }
-    if (!pin_out)
-        for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c) {
-            const int rc2 = fetch(c);
-            if (rc2 < 0) return rc2;
-        }
+    for (size_t c = n_chunks >= 2 ? n_chunks - 2 : 0; c < n_chunks; ++c) {
+        const int rc2 = fetch(c);
+        if (rc2 < 0) return rc2;
+    }
     for (size_t k = 0; k < kSlots; ++k)
         if (ctx->hslot[k].used) HIP_TRY(hipEventSynchronize(ctx->hslot[k].out_done));
     return PGI_SUCCESS;
