@@ -307,6 +307,70 @@ def main():
                                                  "speedup": round(ms / ms_s, 2), "identical_output": same,
                                                  "note": "f16 MFMA screen + exact f32 verification (default path)"}}
 
+        # rotation averaging (north_star's second stage; BASELINE config 4's graph size): 5000 views, ~21 edges per view,
+        # 1 deg noise, 15 % outlier edges, L1 + IRLS to convergence
+        from scipy.spatial.transform import Rotation
+        rg = np.random.default_rng(2)
+        V_ra = 5000
+        Rgt = Rotation.random(V_ra, random_state=2).as_matrix()
+        es = set()
+        for i in range(V_ra):
+            es.add((i, i + 1) if i + 1 < V_ra else (0, i))
+            for j in rg.choice(V_ra, 20, replace=False):
+                if j != i:
+                    es.add((min(i, int(j)), max(i, int(j))))
+        es = np.array(sorted(es))
+        s_ra, d_ra = es[:, 0], es[:, 1]
+        Rrel = np.einsum("eij,ekj->eik", Rgt[d_ra], Rgt[s_ra])
+        Rrel = np.einsum("eij,ejk->eik", Rotation.from_rotvec(rg.standard_normal((len(es), 3)) * np.deg2rad(1.0) / np.sqrt(3)).as_matrix(), Rrel)
+        bad = rg.random(len(es)) < 0.15
+        Rrel[bad] = Rotation.random(int(bad.sum()), random_state=3).as_matrix()
+        w_ra = np.where(bad, rg.uniform(0.1, 0.4, len(es)), rg.uniform(0.4, 1.0, len(es)))
+        eng.rotation_average(s_ra, d_ra, Rrel, w_ra, V_ra)
+        t0 = time.perf_counter()
+        R_ra, it_ra = eng.rotation_average(s_ra, d_ra, Rrel, w_ra, V_ra)
+        t_ra = time.perf_counter() - t0
+        Gfix = Rgt[0].T @ R_ra[0]
+        dR = np.einsum("kij,jl,kml->kim", Rgt, Gfix, R_ra)
+        err_ra = np.degrees(np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1)))
+        out["rotation_averaging"] = {"views": V_ra, "edges": int(len(es)), "ms": round(1e3 * t_ra, 2), "outer_iterations": int(it_ra),
+                                     "mean_err_deg": round(float(err_ra.mean()), 4),
+                                     "note": "host edge list in, rotations out (uploads, spanning-forest init and downloads included)"}
+        # multi-view tracklets in HBM: one committed wave of 120 pairs over 16 views x 8000 keypoints
+        from pyposegraphbuilder.engine import DeviceTracklets
+        rt = np.random.default_rng(3)
+        Vt, Kt = 16, 8000
+        perm = [rt.permutation(Kt) for _ in range(Vt)]
+        prs = [(a_, b_) for a_ in range(Vt) for b_ in range(a_ + 1, Vt)]
+        calls, n_match = [], 0
+        for pi in rt.permutation(len(prs))[:120]:
+            a_, b_ = prs[pi]
+            vis = np.nonzero(rt.random(Kt) < 0.6)[0]
+            dd = perm[b_][vis].copy()
+            wrong = rt.random(len(vis)) < 0.05
+            dd[wrong] = rt.integers(0, Kt, int(wrong.sum()))
+            mk = (rt.random(len(vis)) < 0.9).astype(np.uint8)
+            calls.append((a_, b_, (torch.as_tensor(perm[a_][vis].astype(np.int32)).to(eng.device), torch.as_tensor(dd.astype(np.int32)).to(eng.device)),
+                          torch.as_tensor(mk).to(eng.device)))
+            n_match += int(mk.sum())
+        for rep in range(2):  # first pass warms buffers and code objects
+            trk = DeviceTracklets(eng, Vt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trk.add_batch(calls)
+            torch.cuda.synchronize()
+            t_trk = time.perf_counter() - t0
+            info_t = trk.info()
+            t0 = time.perf_counter()
+            qres = trk.get_correspondences_batch([(c_[0], c_[1]) for c_ in calls], 5000, raw=True)
+            torch.cuda.synchronize()
+            t_q = time.perf_counter() - t0
+            trk.close()
+        out["tracklets"] = {"pairs": len(calls), "inlier_matches": n_match, "add_ms": round(1e3 * t_trk, 2),
+                            "ns_per_match": round(1e9 * t_trk / n_match, 1), "tracks": info_t["tracks"], "events": info_t["events"],
+                            "round_launches": info_t["rounds"], "query_ms": round(1e3 * t_q, 2),
+                            "correspondences_returned": int(qres[2].sum().item())}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),
         # same inputs / seeds / mode, all host cores, bounded sample; also re-checks parity on that sample

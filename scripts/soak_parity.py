@@ -12,7 +12,7 @@ from pyposegraphbuilder import Engine, synthetic as S
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 cases = [dict(), dict(round_size=8), dict(lo_iters=0), dict(fixed_budget=96), dict(confidence=0.999, max_iters=300),
          dict(min_inliers=5, vote_all_rows=1), dict(lo_linear_pct=0), dict(guess_mode=1), dict(lo_linear_pct=10, lo_iters=3),
-         dict(guess_mode=1, round_size=16, lo_linear_pct=60)]
+         dict(guess_mode=1, round_size=16, lo_linear_pct=60), dict(sampler=1), dict(sampler=1, max_iters=160, round_size=24)]
 total = 0
 t00 = time.time()
 for ci, kw in enumerate(cases):
