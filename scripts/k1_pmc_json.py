@@ -76,6 +76,10 @@ def main():
     # sequences and 32-bit integer multiplies take longer, so this is a LOWER bound on how busy the vector ALUs are.
     simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * (c["_avg_us_mix"] / c["_avg_us_lds"]) * 1024
     out["valu_issue_busy_frac"] = round(c["SQ_INSTS_VALU"] * 4 / simd_cycles, 3)
+    out["roofline_compute"]["valu_issue_busy_frac"] = out["valu_issue_busy_frac"]  # travels with bench.py's roofline_compute
+    out["roofline_compute"]["note"] += ("; valu_issue_busy_frac = SQ_INSTS_VALU x 4 cycles / SIMD cycles, a lower bound on vector-ALU "
+                                        "occupancy (the kernel is issue-bound); v_pk_* instructions count once, so f32_tflops "
+                                        "understates the packed scoring arithmetic")
     out["valu_issue_busy_note"] = ("SQ_INSTS_VALU x 4 cycles / (shader cycles x 1024 SIMDs): the kernel is bound by vector-ALU issue, "
                                    "not by memory or latency -- the per-wave 'waiting' share is time spent behind the other three "
                                    "wavefronts of the SIMD")
