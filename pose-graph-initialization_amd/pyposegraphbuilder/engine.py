@@ -28,6 +28,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None):
+            for child in list(getattr(self, "_children", ())):  # stores that live on this context go first
+                child.close()
             self._lib.pgi_destroy(self._ctx)
             self._ctx = None
 
@@ -376,10 +378,15 @@ class DeviceTracklets:
         self._t = self._lib.pgi_tracklets_create(engine._ctx, int(n_views))
         if not self._t:
             raise L.PgiError("pgi_tracklets_create failed: " + L.last_error())
+        if not hasattr(engine, "_children"):
+            import weakref
+            engine._children = weakref.WeakSet()
+        engine._children.add(self)  # Engine.close() destroys its stores before its context
 
     def close(self):
         if getattr(self, "_t", None):
-            self._lib.pgi_tracklets_destroy(self._t)
+            if getattr(self.eng, "_ctx", None):  # (a store outliving its context is abandoned, never touched)
+                self._lib.pgi_tracklets_destroy(self._t)
             self._t = None
 
     __del__ = close

@@ -28,11 +28,15 @@ def test_null_context_is_rejected_everywhere():
         lambda: lib.pgi_allgather_edges(z, z, z, z), lambda: lib.pgi_allgatherv(z, z, z, z),
         lambda: lib.pgi_rotation_average_edges(z, z, z, z, z, 0, 1, None, z, z, z),
         lambda: lib.pgi_comm_unique_id(z),
+        lambda: lib.pgi_tracklets_add_batch(z, None, 1), lambda: lib.pgi_tracklets_get_batch(z, z, z, 1, 1, 2, z, z, z),
+        lambda: lib.pgi_tracklets_info(z, None, None, None), lambda: lib.pgi_tracklets_track(z, 0, z, 0, None),
     ]
     for call in calls:
         assert call() < 0
         assert lib.pgi_last_error()
-    lib.pgi_destroy(z)                                     # a no-op, not a crash
+    assert not lib.pgi_tracklets_create(z, 4) and lib.pgi_last_error()
+    lib.pgi_tracklets_destroy(z)                           # no-ops, not crashes
+    lib.pgi_destroy(z)
     assert lib.pgi_desc_padded(0) == 0 and lib.pgi_desc_padded(1) == 256 and lib.pgi_desc_padded(8000) == 8192
     p = L.Params()
     lib.pgi_default_params(C.byref(p))

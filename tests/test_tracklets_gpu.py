@@ -199,6 +199,18 @@ def test_long_track_lists(eng, list_cap, monkeypatch):
     dev.close()
 
 
+def test_store_is_released_with_its_engine():
+    """Closing the engine first must not leave the store pointing at a dead context."""
+    from pyposegraphbuilder.engine import DeviceTracklets, Engine
+    e = Engine()
+    dev = DeviceTracklets(e, 3)
+    dev.add(0, 1, [(1, 2), (3, 4)], None)
+    e.close()          # destroys the store, then the context
+    assert dev._t is None
+    dev.close()        # no-op
+    del dev, e
+
+
 def test_argument_errors(eng):
     from pyposegraphbuilder import _lib as L
     from pyposegraphbuilder.engine import DeviceTracklets
