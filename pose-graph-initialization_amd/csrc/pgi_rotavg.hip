@@ -568,7 +568,7 @@ static void forest_bfs_init(uint32_t V, const std::vector<std::vector<ForestEdge
 
 // The solve proper.  The rotation-graph edges are already in HBM at d_rot (RotEdgeDev[n_edges]); the host holds only
 // their endpoints, the initial rotations and the root flags.
-static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_views, uint32_t n_edges, const uint32_t* h_src,
+static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t n_views, uint32_t n_edges, const uint32_t* h_src,
                         const uint32_t* h_dst, const RotEdgeDev* d_rot, const std::vector<double>& R,
                         const std::vector<uint8_t>& is_root, double* h_R_out, uint32_t* h_iters_out) {
     // CSR adjacency, incidences in edge order
@@ -616,8 +616,10 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm, uint32_t n_v
     HIP_TRY(hipMemcpyAsync(d + o_aother, aother.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_asign, asign.data(), 2 * E, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_root, is_root.data(), V, hipMemcpyHostToDevice, st));
-    const double sigma = prm.sigma_deg * 3.14159265358979323846 / 180.0;
     const bool trace = std::getenv("PGI_ROTAVG_TRACE") != nullptr;
+    pgi_rotavg_params prm = prm_in;
+    if (const char* e = std::getenv("PGI_ROTAVG_CG_ITERS")) prm.cg_iters = (uint32_t)std::max(1, std::atoi(e));  // experiments
+    const double sigma = prm.sigma_deg * 3.14159265358979323846 / 180.0;
     uint32_t iters = 0;
     for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
         hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_rot, n_edges,

@@ -7,6 +7,7 @@
 // RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT come from the environment (torch.distributed.run style).
 // Each rank writes <out prefix>.<rank>; tests/test_distributed_gpu.py demands that every rank's file equals the
 // single-process file byte for byte.  Scene format: tests/test_distributed_gpu.py (write_scene).
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -56,15 +57,23 @@ int main(int argc, char** argv) {
         std::ofstream out(std::string(argv[2]) + "." + std::to_string(env.rank), std::ios::binary);
         PoseGraph graph;
         PoseGraphBuilder::GlobalRotations rot;
+        typedef std::chrono::steady_clock Clock;
+        auto since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
+        const Clock::time_point t_start = Clock::now();
+        double sec_graph = 0, sec_average = 0;
         if (mode == "shard") {
             std::vector<pgi_edge> edges;
             rot = builder.estimateAndAverage(pairs, graph, V, /*seed*/ 7, &edges);
+            sec_graph = since(t_start);  // estimate + gather + average in one call
             const uint64_t hdr[4] = {P, graph.numEdges(), rot.iterations, rot.edgesUsed};
             out.write((const char*)hdr, sizeof hdr);
             out.write((const char*)edges.data(), (std::streamsize)(edges.size() * sizeof(pgi_edge)));
         } else {
             const auto st = builder.run(pairs, graph, wave, &sim);
+            sec_graph = since(t_start);
+            const Clock::time_point t_avg = Clock::now();
             rot = builder.averageRotations(graph, V);
+            sec_average = since(t_avg);
             const uint64_t hdr[12] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
                                       st.posesFromGuess, st.hypotheses, st.waves, graph.numEdges(), rot.iterations, rot.edgesUsed,
                                       builder.getStatistics().getCount("[A*] Touched nodes")};
@@ -80,9 +89,10 @@ int main(int argc, char** argv) {
         }
         out.write((const char*)rot.rotations.data(), (std::streamsize)(rot.rotations.size() * sizeof(Matrix3d)));
         comm.barrier();
-        std::printf("rank %u/%u transport %s mode %s edges %zu rotavg iters %u\n", env.rank, env.world,
-                    env.world == 1 ? "none" : tr == dist::Transport::Rccl ? "rccl" : "host", mode.c_str(), graph.numEdges(),
-                    rot.iterations);
+        std::printf("rank %u/%u transport %s mode %s edges %zu rotavg iters %u | seconds: %s %.4f, rotation averaging %.4f\n", env.rank,
+                    env.world, env.world == 1 ? "none" : tr == dist::Transport::Rccl ? "rccl" : "host", mode.c_str(), graph.numEdges(),
+                    rot.iterations, mode == "shard" ? "estimate + gather + average" : "scheduler run (A*, estimate, gather, commit)", sec_graph,
+                    sec_average);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "test_distributed: %s\n", e.what());
         return 1;
