@@ -10,8 +10,8 @@ P, N = 9984, 2000
 b = S.make_batch(np.arange(P), N)
 eng = Engine()
 db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=1)
-for rs in (16, 32, 64):
-    for lo in (0, 1, 2):
+for rs in (32, 36, 40, 44, 32, 36, 40, 44):
+    for lo in (2,):
         eng.set_params(round_size=rs, lo_iters=lo)
         eng.estimate_pose_batch(db); torch.cuda.synchronize()
         a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
