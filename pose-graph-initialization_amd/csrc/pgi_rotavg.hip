@@ -256,6 +256,188 @@ __global__ __launch_bounds__(1024) void rot_solve_kernel(uint32_t n_views, const
     }
 }
 
+// ---- on-chip PCG with a spanning-tree preconditioner (sparse / sequence-like view graphs, up to kTreeViews views) ------
+// Jacobi-preconditioned CG needs thousands of iterations on path-like view graphs (image sequences: kappa ~ (V / degree)^2;
+// 2 100 iterations per solve on the config-4 surrogate) where the Laplacian of the maximum-weight spanning forest -- the
+// one the initialisation already built -- as preconditioner needs ~100 (and is useless on dense graphs: 1 400 against
+// Jacobi's 19), so the host switches to this kernel when the Jacobi solve runs into its iteration cap.
+// A tree system L_T z = r is solved EXACTLY by two prefix sums (no elimination order, no level-by-level sweep -- the
+// forest of the surrogate is 1 800 levels deep): with the views numbered in depth-first preorder a subtree is a
+// contiguous range, so the flow towards the root on the edge above view k is f_k = S[k + size_k - 1] - S[k - 1]
+// (S = prefix sums of r), and z_k = sum over the ancestors-or-self u of f_u / w_u is a prefix sum over the Euler tour
+// with +g_u at u's entry and -g_u at its exit.  One workgroup per component of the (Laplacian x I3) system keeps its
+// vectors in registers (thread t owns views [t m, t m + m)), the scans and the gathered vector live in LDS; an iteration
+// is a dozen workgroup barriers.  Scans run in a fixed order: same input, same bits.
+constexpr uint32_t kTreeViews = 6144;
+constexpr int kTreeOwn = kTreeViews / 1024;
+
+__device__ inline double wave_sum_fixed(double v) {  // xor tree: the same order on every call
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+// sum over the 1024 threads, returned to all of them; red: 16 doubles of LDS
+__device__ inline double block_sum_1024(double v, double* red, int tid) {
+    v = wave_sum_fixed(v);
+    __syncthreads();  // previous use of red is over
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i];
+    return s;
+}
+// exclusive prefix (in thread order) of one value per thread; red: 16 doubles of LDS
+__device__ inline double block_prefix_1024(double v, double* red, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    double x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();  // previous use of red is over
+    if (lane == 63) red[wv] = x;
+    __syncthreads();
+    double before = 0.0;
+    for (int i = 0; i < wv; ++i) before += red[i];
+    return before + (x - v);
+}
+
+// grid = 3 (component), block = 1024.  Views are in depth-first preorder ("new" numbering); new_to_old maps back.
+__global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, uint32_t m /* views per thread */,
+                                                              const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj_edge,
+                                                              const uint32_t* __restrict__ adj_other, const int8_t* __restrict__ adj_sign,
+                                                              const uint32_t* __restrict__ parent_edge /* 0xFFFFFFFF: root */,
+                                                              const uint32_t* __restrict__ sub_size, const uint32_t* __restrict__ tour_enter,
+                                                              const uint32_t* __restrict__ tour_exit, const uint32_t* __restrict__ new_to_old,
+                                                              const double* __restrict__ omega, const double* __restrict__ w,
+                                                              uint32_t cg_iters, double cg_tol, double* __restrict__ aw,
+                                                              double* __restrict__ x_out, double* __restrict__ iters_out) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const uint32_t comp = blockIdx.x, vpad = 1024u * m;
+    double* pvec = lds;          // vpad: the vector being gathered
+    double* tour = pvec + vpad;  // 2 * vpad: prefix sums (first of r over the preorder, then over the Euler tour)
+    double* red = tour + 2 * (size_t)vpad;  // 16
+    const uint32_t k0 = (uint32_t)tid * m;
+
+    double d[kTreeOwn], winv[kTreeOwn], r[kTreeOwn], x[kTreeOwn], p[kTreeOwn], q[kTreeOwn], z[kTreeOwn];
+    uint32_t sz[kTreeOwn], ten[kTreeOwn], tex[kTreeOwn];
+    bool fr[kTreeOwn];
+#pragma unroll
+    for (int j = 0; j < kTreeOwn; ++j) {
+        d[j] = 0.0; winv[j] = 0.0; r[j] = 0.0; x[j] = 0.0; p[j] = 0.0; q[j] = 0.0; z[j] = 0.0;
+        sz[j] = 1; ten[j] = 0; tex[j] = 0; fr[j] = false;
+        const uint32_t k = k0 + (uint32_t)j;
+        if ((uint32_t)j >= m || k >= n_views) continue;
+        sz[j] = sub_size[k]; ten[j] = tour_enter[k]; tex[j] = tour_exit[k];
+        const uint32_t pe = parent_edge[k];
+        fr[j] = pe != 0xFFFFFFFFu;
+        if (!fr[j]) continue;
+        const double wp = w[pe];
+        winv[j] = wp > 0.0 ? 1.0 / wp : 0.0;
+        double dd = 0.0, bb = 0.0;
+        for (uint32_t t = adj_ptr[k]; t < adj_ptr[k + 1]; ++t) {
+            const uint32_t e = adj_edge[t];
+            const double we = w[e];
+            aw[t] = we;  // read back by this same thread only (the three workgroups write the same values)
+            dd += we;
+            bb += (double)adj_sign[t] * we * omega[3 * (size_t)e + comp];
+        }
+        d[j] = dd;
+        r[j] = bb;
+    }
+    // z = L_T^-1 r
+    auto precondition = [&]() {
+        // prefix sums of r over the preorder
+        double run = 0.0, loc[kTreeOwn];
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) { run += ((uint32_t)j < m) ? r[j] : 0.0; loc[j] = run; }
+        const double before = block_prefix_1024(run, red, tid);
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j)
+            if ((uint32_t)j < m) tour[k0 + (uint32_t)j] = before + loc[j];
+        __syncthreads();
+        double g[kTreeOwn];
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) {
+            g[j] = 0.0;
+            const uint32_t k = k0 + (uint32_t)j;
+            if ((uint32_t)j >= m || !fr[j]) continue;
+            const double f = tour[k + sz[j] - 1u] - (k ? tour[k - 1u] : 0.0);  // what the subtree of k sends to its parent
+            g[j] = f * winv[j];
+        }
+        __syncthreads();
+        // Euler tour: +g at the entry of a view, -g at its exit (every position of the tour is written exactly once)
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) {
+            const uint32_t k = k0 + (uint32_t)j;
+            if ((uint32_t)j >= m || k >= n_views) continue;
+            tour[ten[j]] = g[j];
+            tour[tex[j]] = -g[j];
+        }
+        __syncthreads();
+        // inclusive prefix sums over the tour: thread t owns positions [2 t m, 2 t m + 2 m)
+        const uint32_t t0 = 2u * k0, tn = 2u * n_views;
+        double trun = 0.0;
+        for (uint32_t i = 0; i < 2u * m; ++i) trun += (t0 + i < tn) ? tour[t0 + i] : 0.0;
+        const double tbefore = block_prefix_1024(trun, red, tid);
+        trun = tbefore;
+        for (uint32_t i = 0; i < 2u * m; ++i)
+            if (t0 + i < tn) { trun += tour[t0 + i]; tour[t0 + i] = trun; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) z[j] = ((uint32_t)j < m && fr[j]) ? tour[ten[j]] : 0.0;
+        __syncthreads();  // tour is rewritten by the next call
+    };
+    precondition();
+    double rz = 0.0;
+#pragma unroll
+    for (int j = 0; j < kTreeOwn; ++j) { p[j] = z[j]; rz += r[j] * z[j]; }
+    rz = block_sum_1024(rz, red, tid);
+    const double rz0 = rz;
+    uint32_t it = 0;
+    for (; it < cg_iters; ++it) {
+        if (!(rz > cg_tol * cg_tol * rz0)) break;  // uniform: rz is identical in every thread
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j)
+            if ((uint32_t)j < m) pvec[k0 + (uint32_t)j] = p[j];
+        __syncthreads();
+        double pAp = 0.0;
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) {
+            const uint32_t k = k0 + (uint32_t)j;
+            double y = 0.0;
+            if ((uint32_t)j < m && fr[j]) {
+                y = d[j] * p[j];
+                for (uint32_t t = adj_ptr[k]; t < adj_ptr[k + 1]; ++t) y -= aw[t] * pvec[adj_other[t]];  // roots hold p = 0
+            }
+            q[j] = y;
+            pAp += p[j] * y;
+        }
+        pAp = block_sum_1024(pAp, red, tid);
+        const double alpha = pAp > 0.0 ? rz / pAp : 0.0;
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) { x[j] += alpha * p[j]; r[j] -= alpha * q[j]; }
+        precondition();
+        double rzn = 0.0;
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) rzn += r[j] * z[j];
+        rzn = block_sum_1024(rzn, red, tid);
+        const double beta = rz > 0.0 ? rzn / rz : 0.0;
+#pragma unroll
+        for (int j = 0; j < kTreeOwn; ++j) p[j] = z[j] + beta * p[j];
+        rz = rzn;
+    }
+#pragma unroll
+    for (int j = 0; j < kTreeOwn; ++j) {
+        const uint32_t k = k0 + (uint32_t)j;
+        if ((uint32_t)j < m && k < n_views) x_out[3 * (size_t)new_to_old[k] + comp] = x[j];
+    }
+    if (tid == 0) iters_out[comp] = (double)it;
+}
+
 // ---- multi-workgroup PCG (large graphs): scalars (gamma, alpha, beta, done) resident on the device; block partials
 // are reduced in a fixed order.
 struct CgState {
@@ -570,7 +752,8 @@ static void forest_bfs_init(uint32_t V, const std::vector<std::vector<ForestEdge
 // their endpoints, the initial rotations and the root flags.
 static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t n_views, uint32_t n_edges, const uint32_t* h_src,
                         const uint32_t* h_dst, const RotEdgeDev* d_rot, const std::vector<double>& R,
-                        const std::vector<uint8_t>& is_root, double* h_R_out, uint32_t* h_iters_out) {
+                        const std::vector<uint8_t>& is_root, const std::vector<std::vector<ForestEdge>>& forest, double* h_R_out,
+                        uint32_t* h_iters_out) {
     // CSR adjacency, incidences in edge order
     std::vector<uint32_t> ptr(n_views + 1, 0), aedge(2 * (size_t)n_edges), aother(2 * (size_t)n_edges);
     std::vector<int8_t> asign(2 * (size_t)n_edges);
@@ -589,6 +772,55 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
         }
     }
     const size_t V = n_views, E = n_edges;
+    // Tree path (rot_solve_tree_kernel): views renumbered in depth-first preorder of the spanning forest, with subtree
+    // sizes, the edge to the parent and the Euler-tour positions; the adjacency again in that numbering.
+    const bool tree_ok = n_views <= kTreeViews;
+    const uint32_t own = tree_ok ? std::max<uint32_t>(1u, (n_views + 1023u) / 1024u) : 0u;
+    std::vector<uint32_t> t_n2o, t_pedge, t_size, t_enter, t_exit, t_ptr, t_edge, t_other;
+    std::vector<int8_t> t_sign;
+    if (tree_ok) {
+        std::vector<uint32_t> o2n(V, 0xFFFFFFFFu);
+        t_n2o.reserve(V); t_pedge.assign(V, 0xFFFFFFFFu); t_size.assign(V, 1u); t_enter.assign(V, 0u); t_exit.assign(V, 0u);
+        uint32_t clock = 0;
+        struct Frame { uint32_t v, next; };
+        std::vector<Frame> stack;
+        for (uint32_t root = 0; root < n_views; ++root) {
+            if (!is_root[root]) continue;
+            o2n[root] = (uint32_t)t_n2o.size();
+            t_n2o.push_back(root);
+            t_enter[o2n[root]] = clock++;
+            stack.assign(1, Frame{root, 0u});
+            while (!stack.empty()) {
+                Frame& f = stack.back();
+                if (f.next < forest[f.v].size()) {
+                    const ForestEdge& pr = forest[f.v][f.next++];
+                    const uint32_t c = pr.other & 0x7FFFFFFFu;
+                    if (o2n[c] != 0xFFFFFFFFu) continue;  // the parent
+                    o2n[c] = (uint32_t)t_n2o.size();
+                    t_n2o.push_back(c);
+                    t_pedge[o2n[c]] = pr.edge;
+                    t_enter[o2n[c]] = clock++;
+                    stack.push_back(Frame{c, 0u});
+                } else {
+                    const uint32_t k = o2n[f.v];
+                    t_size[k] = (uint32_t)t_n2o.size() - k;
+                    t_exit[k] = clock++;
+                    stack.pop_back();
+                }
+            }
+        }
+        t_ptr.assign(V + 1, 0); t_edge.resize(2 * E); t_other.resize(2 * E); t_sign.resize(2 * E);
+        for (uint32_t k = 0; k < n_views; ++k) {
+            const uint32_t u = t_n2o[k];
+            uint32_t o = t_ptr[k];
+            for (uint32_t a = ptr[u]; a < ptr[u + 1]; ++a, ++o) {
+                t_edge[o] = aedge[a];
+                t_other[o] = o2n[aother[a]];
+                t_sign[o] = asign[a];
+            }
+            t_ptr[k + 1] = o;
+        }
+    }
     // one allocation, carved
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -602,7 +834,11 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                  o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24), o_r2 = carve(V * 24), o_q2 = carve(V * 24), o_s = carve(V * 24),
                  o_s2 = carve(V * 24),
                  o_stats = carve(16), o_cg = carve(sizeof(CgState)),
-                 o_part = carve(6 * 8 * ((V + kRowsPerBlock - 1) / kRowsPerBlock + 1));
+                 o_part = carve(6 * 8 * ((V + kRowsPerBlock - 1) / kRowsPerBlock + 1)),
+                 // tree path
+                 o_tptr = carve((V + 1) * 4), o_tedge = carve(2 * E * 4), o_tother = carve(2 * E * 4), o_tsign = carve(2 * E),
+                 o_tn2o = carve(V * 4), o_tpe = carve(V * 4), o_tsz = carve(V * 4), o_ten = carve(V * 4), o_tex = carve(V * 4),
+                 o_aw = carve(2 * E * 8), o_its = carve(32);
     char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, off));
     struct Guard {
@@ -616,6 +852,22 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
     HIP_TRY(hipMemcpyAsync(d + o_aother, aother.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_asign, asign.data(), 2 * E, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + o_root, is_root.data(), V, hipMemcpyHostToDevice, st));
+    size_t tree_lds = 0;
+    if (tree_ok) {
+        HIP_TRY(hipMemcpyAsync(d + o_tptr, t_ptr.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tedge, t_edge.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tother, t_other.data(), 2 * E * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tsign, t_sign.data(), 2 * E, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tn2o, t_n2o.data(), V * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tpe, t_pedge.data(), V * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tsz, t_size.data(), V * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_ten, t_enter.data(), V * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + o_tex, t_exit.data(), V * 4, hipMemcpyHostToDevice, st));
+        tree_lds = ((size_t)3 * 1024 * own + 16) * 8;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rot_solve_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)tree_lds));
+    }
+    bool use_tree = false;  // set once the Jacobi-preconditioned solve has run into its iteration cap
     const bool trace = std::getenv("PGI_ROTAVG_TRACE") != nullptr;
     pgi_rotavg_params prm = prm_in;
     if (const char* e = std::getenv("PGI_ROTAVG_CG_ITERS")) prm.cg_iters = (uint32_t)std::max(1, std::atoi(e));  // experiments
@@ -624,7 +876,17 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
     for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
         hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_rot, n_edges,
                            (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0, sigma, (double*)(d + o_omega), (double*)(d + o_w));
-        if (n_views <= kSingleWgViews) {
+        const bool used_tree_this_iter = use_tree;
+        if (use_tree) {
+            hipLaunchKernelGGL(rot_solve_tree_kernel, dim3(3), dim3(1024), tree_lds, st, n_views, own, (const uint32_t*)(d + o_tptr),
+                               (const uint32_t*)(d + o_tedge), (const uint32_t*)(d + o_tother), (const int8_t*)(d + o_tsign),
+                               (const uint32_t*)(d + o_tpe), (const uint32_t*)(d + o_tsz), (const uint32_t*)(d + o_ten),
+                               (const uint32_t*)(d + o_tex), (const uint32_t*)(d + o_tn2o), (const double*)(d + o_omega),
+                               (const double*)(d + o_w), std::max<uint32_t>(prm.cg_iters, 1000u), 1e-10, (double*)(d + o_aw),
+                               (double*)(d + o_x), (double*)(d + o_its));
+            const uint32_t nb = (n_views + kCgBlock - 1) / kCgBlock;
+            hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), (double*)(d + o_part));
+        } else if (n_views <= kSingleWgViews) {
             uint32_t row_lanes = 16;  // as many lanes per view as keep all views in one pass of the 1024 threads
             while (row_lanes > 1 && (uint64_t)n_views * row_lanes > 1024u) row_lanes >>= 1;
             hipLaunchKernelGGL(rot_solve_kernel, dim3(1), dim3(1024), 0, st, n_views, (const uint32_t*)(d + o_ptr),
@@ -657,22 +919,26 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                 cur ^= 1;
             };
             iterate(1);
+            int done = 0;
             for (uint32_t ci = 0; ci < prm.cg_iters;) {
                 const uint32_t chunk = std::min<uint32_t>(16, prm.cg_iters - ci);  // kernels no-op once converged
                 for (uint32_t q = 0; q < chunk; ++q) iterate(0);
                 ci += chunk;
-                int done = 0;
                 HIP_TRY(hipMemcpyAsync(&done, (char*)cst + offsetof(CgState, done), sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 if (done) break;
             }
+            // not converged within the cap: the graph is sparse / sequence-like and Jacobi is the wrong preconditioner for
+            // it; the (truncated) step computed here is still used, the following solves go to the tree-preconditioned kernel
+            if (!done && tree_ok) use_tree = true;
             hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), part);
             // mean |d| = sum / V -> stats[0] (host side below)
         }
         hipLaunchKernelGGL(rot_update_kernel, dim3((n_views + 255) / 256), dim3(256), 0, st, n_views,
                            (const double*)(d + o_x), (double*)(d + o_R));
         double stats[2] = {0, 0};
-        if (n_views <= kSingleWgViews) {
+        const bool tree_now = used_tree_this_iter;
+        if (!tree_now && n_views <= kSingleWgViews) {
             HIP_TRY(hipMemcpyAsync(stats, d + o_stats, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         } else {
@@ -687,7 +953,12 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
         iters = it + 1;
         if (trace) {  // PGI_ROTAVG_TRACE=1: one line per outer iteration
             double cg_it = stats[1];
-            if (n_views > kSingleWgViews) {
+            if (tree_now) {
+                double its[3];
+                HIP_TRY(hipMemcpyAsync(its, d + o_its, 24, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                cg_it = -std::max(its[0], std::max(its[1], its[2]));  // printed negative: tree-preconditioned iterations
+            } else if (n_views > kSingleWgViews) {
                 CgState hs;
                 HIP_TRY(hipMemcpyAsync(&hs, d + o_cg, sizeof hs, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -754,7 +1025,7 @@ int pgi_rotation_average(pgi_ctx* ctx, const pgi_rot_edge* h_edges, uint32_t n_e
         ~Guard() { (void)hipFree(p); }
     } guard{d_rot};
     HIP_TRY(hipMemcpyAsync(d_rot, h_edges, (size_t)n_edges * sizeof(pgi_rot_edge), hipMemcpyHostToDevice, ctx->stream));
-    return rotavg_solve(ctx, prm, n_views, n_edges, src.data(), dst.data(), d_rot, R, is_root, h_R_out, h_iters_out);
+    return rotavg_solve(ctx, prm, n_views, n_edges, src.data(), dst.data(), d_rot, R, is_root, adj, h_R_out, h_iters_out);
 }
 
 int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint32_t* h_src, const uint32_t* h_dst,
@@ -827,7 +1098,7 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
     std::vector<uint32_t> slot(nE, 0u);  // edge -> position in the forest list
     for (size_t k = 0; k < nT; ++k) slot[tree[k]] = (uint32_t)k;
     forest_bfs_init(n_views, adj, [&](uint32_t e) { return &treeR[9 * (size_t)slot[e]]; }, R, is_root);
-    return rotavg_solve(ctx, prm, n_views, nE, src.data(), dst.data(), d_rot, R, is_root, h_R_out, h_iters_out);
+    return rotavg_solve(ctx, prm, n_views, nE, src.data(), dst.data(), d_rot, R, is_root, adj, h_R_out, h_iters_out);
 }
 
 }  // extern "C"
