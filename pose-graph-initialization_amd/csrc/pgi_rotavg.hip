@@ -876,8 +876,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
     for (uint32_t it = 0; it < prm.l1_iters + prm.irls_iters; ++it) {
         hipLaunchKernelGGL(rot_residual_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_rot, n_edges,
                            (const double*)(d + o_R), it < prm.l1_iters ? 1 : 0, sigma, (double*)(d + o_omega), (double*)(d + o_w));
-        const bool used_tree_this_iter = use_tree;
-        if (use_tree) {
+        auto solve_with_tree = [&]() {  // writes every entry of x, then the block partials of the step norm
             hipLaunchKernelGGL(rot_solve_tree_kernel, dim3(3), dim3(1024), tree_lds, st, n_views, own, (const uint32_t*)(d + o_tptr),
                                (const uint32_t*)(d + o_tedge), (const uint32_t*)(d + o_tother), (const int8_t*)(d + o_tsign),
                                (const uint32_t*)(d + o_tpe), (const uint32_t*)(d + o_tsz), (const uint32_t*)(d + o_ten),
@@ -886,6 +885,10 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                (double*)(d + o_x), (double*)(d + o_its));
             const uint32_t nb = (n_views + kCgBlock - 1) / kCgBlock;
             hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), (double*)(d + o_part));
+        };
+        bool used_tree_this_iter = use_tree;
+        if (use_tree) {
+            solve_with_tree();
         } else if (n_views <= kSingleWgViews) {
             uint32_t row_lanes = 16;  // as many lanes per view as keep all views in one pass of the 1024 threads
             while (row_lanes > 1 && (uint64_t)n_views * row_lanes > 1024u) row_lanes >>= 1;
@@ -894,6 +897,14 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                (const uint8_t*)(d + o_root), (const double*)(d + o_omega), (const double*)(d + o_w),
                                prm.cg_iters, 1e-10, row_lanes, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
                                (double*)(d + o_p), (double*)(d + o_Ap), (double*)(d + o_stats));
+            double probe[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(probe, d + o_stats, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (probe[1] >= (double)prm.cg_iters && tree_ok) {  // ran into the cap: see the multi-workgroup branch
+                use_tree = true;
+                solve_with_tree();
+                used_tree_this_iter = true;
+            }
         } else {  // multi-workgroup PCG: launches are cheap next to a one-CU solve at this size
             const uint32_t nb = (n_views + kCgBlock - 1) / kCgBlock;
             CgState* cst = (CgState*)(d + o_cg);
@@ -929,9 +940,15 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                 if (done) break;
             }
             // not converged within the cap: the graph is sparse / sequence-like and Jacobi is the wrong preconditioner for
-            // it; the (truncated) step computed here is still used, the following solves go to the tree-preconditioned kernel
+            // it.  This step is solved again, and all following ones, by the tree-preconditioned kernel, so that the
+            // iteration follows the exact-solve trajectory from the start.
             if (!done && tree_ok) use_tree = true;
-            hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), part);
+            if (use_tree) {
+                solve_with_tree();
+                used_tree_this_iter = true;
+            } else {
+                hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), part);
+            }
             // mean |d| = sum / V -> stats[0] (host side below)
         }
         hipLaunchKernelGGL(rot_update_kernel, dim3((n_views + 255) / 256), dim3(256), 0, st, n_views,

@@ -58,6 +58,53 @@ def test_hip_rotation_averaging_matches_oracle(V, k, noise, outl, comps):
     eng.close()
 
 
+def sequence_graph(V, reach, noise_deg, outlier_frac, seed, components=1):
+    """An image-sequence view graph: view i sees views i+1 .. i+reach (per component), like a video or a walk-through.
+    Its Laplacian is banded: Jacobi-preconditioned CG needs ~(V / reach) iterations times a large constant."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    Rgt = Rotation.random(V, random_state=seed).as_matrix()
+    src, dst = [], []
+    for c in range(components):
+        idx = np.arange(c, V, components)
+        for a in range(len(idx)):
+            for s_ in range(1, reach + 1):
+                if a + s_ < len(idx):
+                    i, j = (idx[a], idx[a + s_]) if rng.random() < 0.5 else (idx[a + s_], idx[a])
+                    src.append(i); dst.append(j)
+    src, dst = np.array(src), np.array(dst)
+    Rrel = np.einsum("eij,ekj->eik", Rgt[dst], Rgt[src])
+    Rrel = np.einsum("eij,ejk->eik", Rotation.from_rotvec(rng.standard_normal((len(src), 3)) * np.deg2rad(noise_deg) / np.sqrt(3)).as_matrix(), Rrel)
+    out = rng.random(len(src)) < outlier_frac
+    Rrel[out] = Rotation.random(int(out.sum()), random_state=seed + 1).as_matrix()
+    w = np.where(out, rng.uniform(0.1, 0.4, len(src)), rng.uniform(0.4, 1.0, len(src)))
+    return src, dst, Rrel, w, Rgt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,reach,comps", [(900, 3, 1), (3000, 4, 1), (5000, 3, 2)])
+def test_hip_rotation_averaging_on_sequence_graphs(V, reach, comps, capfd, monkeypatch):
+    """Sparse, banded view graphs: the Jacobi-preconditioned solve runs into its cap and the solver must switch to the
+    spanning-tree-preconditioned kernel (prefix-sum tree solves) -- same fixed point as the oracle's exact solves, in about
+    as many outer iterations, instead of a hundred truncated steps."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_ROTAVG_TRACE", "1")
+    eng = Engine()
+    src, dst, Rrel, w, Rgt = sequence_graph(V, reach, 1.0, 0.05, seed=13, components=comps)
+    R, iters = eng.rotation_average(src, dst, Rrel, w, V)
+    trace = capfd.readouterr().err
+    Ro, iters_o = RO.rotation_average(V, src, dst, Rrel, w)
+    d = np.einsum("kij,kmj->kim", R, Ro)
+    ang = np.arccos(np.clip((np.trace(d, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    print("V %d: %d outer iterations (oracle %d), max diff %.2e rad" % (V, iters, iters_o, ang.max()))
+    assert "): -" in trace                      # tree-preconditioned iterations are traced with a minus sign
+    assert ang.max() < 1e-5, (ang.max(), iters, iters_o)
+    assert abs(iters - iters_o) <= 1 and iters < 40
+    R2, iters2 = eng.rotation_average(src, dst, Rrel, w, V)   # reproducible to the bit
+    assert iters2 == iters and np.array_equal(R, R2)
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_hip_rotation_averaging_edge_cases():
     from pyposegraphbuilder import Engine, PgiError
