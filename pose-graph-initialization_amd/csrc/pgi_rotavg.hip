@@ -304,6 +304,10 @@ __device__ inline double block_prefix_1024(double v, double* red, int tid) {
     return before + (x - v);
 }
 
+struct TreeIncidence {  // one 16-byte load per incidence in the products
+    double w;
+    uint32_t other, pad;
+};
 // grid = 3 (component), block = 1024.  Views are in depth-first preorder ("new" numbering); new_to_old maps back.
 __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, uint32_t m /* views per thread */,
                                                               const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj_edge,
@@ -312,24 +316,26 @@ __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, 
                                                               const uint32_t* __restrict__ sub_size, const uint32_t* __restrict__ tour_enter,
                                                               const uint32_t* __restrict__ tour_exit, const uint32_t* __restrict__ new_to_old,
                                                               const double* __restrict__ omega, const double* __restrict__ w,
-                                                              uint32_t cg_iters, double cg_tol, double* __restrict__ aw,
+                                                              uint32_t cg_iters, double cg_tol, TreeIncidence* __restrict__ inc,
                                                               double* __restrict__ x_out, double* __restrict__ iters_out) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const uint32_t comp = blockIdx.x, vpad = 1024u * m;
-    double* pvec = lds;          // vpad: the vector being gathered
-    double* tour = pvec + vpad;  // 2 * vpad: prefix sums (first of r over the preorder, then over the Euler tour)
-    double* red = tour + 2 * (size_t)vpad;  // 16
+    double* tour = lds;          // 2 * vpad: prefix sums (first of r over the preorder, then over the Euler tour)
+    double* pvec = lds;          // vpad: the vector being gathered by the products (the scans are idle then)
+    double* xvec = tour + 2 * (size_t)vpad;  // vpad: the solution (kept out of the register file)
+    double* red = xvec + vpad;   // 16
     const uint32_t k0 = (uint32_t)tid * m;
 
-    double d[kTreeOwn], winv[kTreeOwn], r[kTreeOwn], x[kTreeOwn], p[kTreeOwn], q[kTreeOwn], z[kTreeOwn];
+    double d[kTreeOwn], winv[kTreeOwn], r[kTreeOwn], p[kTreeOwn], q[kTreeOwn], z[kTreeOwn];
     uint32_t sz[kTreeOwn], ten[kTreeOwn], tex[kTreeOwn];
     bool fr[kTreeOwn];
 #pragma unroll
     for (int j = 0; j < kTreeOwn; ++j) {
-        d[j] = 0.0; winv[j] = 0.0; r[j] = 0.0; x[j] = 0.0; p[j] = 0.0; q[j] = 0.0; z[j] = 0.0;
+        d[j] = 0.0; winv[j] = 0.0; r[j] = 0.0; p[j] = 0.0; q[j] = 0.0; z[j] = 0.0;
         sz[j] = 1; ten[j] = 0; tex[j] = 0; fr[j] = false;
         const uint32_t k = k0 + (uint32_t)j;
+        if ((uint32_t)j < m) xvec[k] = 0.0;  // only its owner ever touches an entry
         if ((uint32_t)j >= m || k >= n_views) continue;
         sz[j] = sub_size[k]; ten[j] = tour_enter[k]; tex[j] = tour_exit[k];
         const uint32_t pe = parent_edge[k];
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, 
         for (uint32_t t = adj_ptr[k]; t < adj_ptr[k + 1]; ++t) {
             const uint32_t e = adj_edge[t];
             const double we = w[e];
-            aw[t] = we;  // read back by this same thread only (the three workgroups write the same values)
+            inc[t] = TreeIncidence{we, adj_other[t], 0u};  // read back by this same thread only (the three workgroups write the same values)
             dd += we;
             bb += (double)adj_sign[t] * we * omega[3 * (size_t)e + comp];
         }
@@ -411,7 +417,19 @@ __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, 
             double y = 0.0;
             if ((uint32_t)j < m && fr[j]) {
                 y = d[j] * p[j];
-                for (uint32_t t = adj_ptr[k]; t < adj_ptr[k + 1]; ++t) y -= aw[t] * pvec[adj_other[t]];  // roots hold p = 0
+                uint32_t t = adj_ptr[k];
+                const uint32_t te = adj_ptr[k + 1];
+                for (; t + 4 <= te; t += 4) {  // four independent loads in flight (roots hold p = 0)
+                    const TreeIncidence a0 = inc[t], a1 = inc[t + 1], a2 = inc[t + 2], a3 = inc[t + 3];
+                    y -= a0.w * pvec[a0.other];
+                    y -= a1.w * pvec[a1.other];
+                    y -= a2.w * pvec[a2.other];
+                    y -= a3.w * pvec[a3.other];
+                }
+                for (; t < te; ++t) {
+                    const TreeIncidence a0 = inc[t];
+                    y -= a0.w * pvec[a0.other];
+                }
             }
             q[j] = y;
             pAp += p[j] * y;
@@ -419,7 +437,10 @@ __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, 
         pAp = block_sum_1024(pAp, red, tid);
         const double alpha = pAp > 0.0 ? rz / pAp : 0.0;
 #pragma unroll
-        for (int j = 0; j < kTreeOwn; ++j) { x[j] += alpha * p[j]; r[j] -= alpha * q[j]; }
+        for (int j = 0; j < kTreeOwn; ++j) {
+            if ((uint32_t)j < m) xvec[k0 + (uint32_t)j] += alpha * p[j];
+            r[j] -= alpha * q[j];
+        }
         precondition();
         double rzn = 0.0;
 #pragma unroll
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(1024) void rot_solve_tree_kernel(uint32_t n_views, 
 #pragma unroll
     for (int j = 0; j < kTreeOwn; ++j) {
         const uint32_t k = k0 + (uint32_t)j;
-        if ((uint32_t)j < m && k < n_views) x_out[3 * (size_t)new_to_old[k] + comp] = x[j];
+        if ((uint32_t)j < m && k < n_views) x_out[3 * (size_t)new_to_old[k] + comp] = xvec[k];
     }
     if (tid == 0) iters_out[comp] = (double)it;
 }
@@ -774,7 +795,10 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
     const size_t V = n_views, E = n_edges;
     // Tree path (rot_solve_tree_kernel): views renumbered in depth-first preorder of the spanning forest, with subtree
     // sizes, the edge to the parent and the Euler-tour positions; the adjacency again in that numbering.
-    const bool tree_ok = n_views <= kTreeViews;
+    // Only sparse graphs qualify: the forest holds V - 1 of the E edges, and on a dense graph (E / V = 21 in the k = 20
+    // benchmark) it is a far worse preconditioner than Jacobi (1 380 iterations against 19) -- there a capped first L1
+    // solve is simply a hard first step, not a reason to switch.
+    const bool tree_ok = n_views <= kTreeViews && (uint64_t)n_edges <= 8ull * n_views;
     const uint32_t own = tree_ok ? std::max<uint32_t>(1u, (n_views + 1023u) / 1024u) : 0u;
     std::vector<uint32_t> t_n2o, t_pedge, t_size, t_enter, t_exit, t_ptr, t_edge, t_other;
     std::vector<int8_t> t_sign;
@@ -838,7 +862,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                  // tree path
                  o_tptr = carve((V + 1) * 4), o_tedge = carve(2 * E * 4), o_tother = carve(2 * E * 4), o_tsign = carve(2 * E),
                  o_tn2o = carve(V * 4), o_tpe = carve(V * 4), o_tsz = carve(V * 4), o_ten = carve(V * 4), o_tex = carve(V * 4),
-                 o_aw = carve(2 * E * 8), o_its = carve(32);
+                 o_aw = carve(2 * E * sizeof(TreeIncidence)), o_its = carve(32);
     char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, off));
     struct Guard {
@@ -881,7 +905,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                (const uint32_t*)(d + o_tedge), (const uint32_t*)(d + o_tother), (const int8_t*)(d + o_tsign),
                                (const uint32_t*)(d + o_tpe), (const uint32_t*)(d + o_tsz), (const uint32_t*)(d + o_ten),
                                (const uint32_t*)(d + o_tex), (const uint32_t*)(d + o_tn2o), (const double*)(d + o_omega),
-                               (const double*)(d + o_w), std::max<uint32_t>(prm.cg_iters, 1000u), 1e-10, (double*)(d + o_aw),
+                               (const double*)(d + o_w), std::max<uint32_t>(prm.cg_iters, 1000u), 1e-10, (TreeIncidence*)(d + o_aw),
                                (double*)(d + o_x), (double*)(d + o_its));
             const uint32_t nb = (n_views + kCgBlock - 1) / kCgBlock;
             hipLaunchKernelGGL(cg_step_norm_kernel, dim3(nb), dim3(kCgBlock), 0, st, n_views, (const double*)(d + o_x), (double*)(d + o_part));
@@ -935,9 +959,18 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                 const uint32_t chunk = std::min<uint32_t>(16, prm.cg_iters - ci);  // kernels no-op once converged
                 for (uint32_t q = 0; q < chunk; ++q) iterate(0);
                 ci += chunk;
-                HIP_TRY(hipMemcpyAsync(&done, (char*)cst + offsetof(CgState, done), sizeof(int), hipMemcpyDeviceToHost, st));
+                CgState hs;
+                HIP_TRY(hipMemcpyAsync(&hs, cst, sizeof hs, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                done = hs.done;
                 if (done) break;
+                // hopeless for this preconditioner: after 64 iterations a well-conditioned (dense) graph has gained ten
+                // orders of magnitude, a sequence-like one not even three
+                if (tree_ok && ci >= 64) {
+                    bool slow = false;
+                    for (int c = 0; c < 3; ++c) slow |= hs.rz[c] > 1e-6 * hs.rz0[c];
+                    if (slow) break;
+                }
             }
             // not converged within the cap: the graph is sparse / sequence-like and Jacobi is the wrong preconditioner for
             // it.  This step is solved again, and all following ones, by the tree-preconditioned kernel, so that the

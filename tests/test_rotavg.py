@@ -106,6 +106,21 @@ def test_hip_rotation_averaging_on_sequence_graphs(V, reach, comps, capfd, monke
 
 
 @pytest.mark.gpu
+def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch):
+    """5000 views x ~21 edges per view: the first L1 solve runs into the 200-iteration cap, but the spanning forest is a
+    far worse preconditioner there (1 380 iterations against 19) -- the solver must not switch."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_ROTAVG_TRACE", "1")
+    eng = Engine()
+    src, dst, Rrel, w, Rgt, _ = RO.make_graph(5000, 20, noise_deg=1.0, outlier_frac=0.15, seed=2)
+    R, iters = eng.rotation_average(src, dst, Rrel, w, 5000)
+    trace = capfd.readouterr().err
+    assert "(L1): 200 PCG" in trace and "): -" not in trace
+    assert iters <= 12 and RO.align_error_deg(R, Rgt).mean() < 0.5
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_hip_rotation_averaging_edge_cases():
     from pyposegraphbuilder import Engine, PgiError
     eng = Engine()
