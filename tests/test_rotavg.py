@@ -82,7 +82,7 @@ def sequence_graph(V, reach, noise_deg, outlier_frac, seed, components=1):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("V,reach,comps", [(900, 3, 1), (3000, 4, 1), (5000, 3, 2)])
+@pytest.mark.parametrize("V,reach,comps", [(900, 3, 1), (3000, 4, 1), (5000, 3, 2), (6144, 5, 1)])
 def test_hip_rotation_averaging_on_sequence_graphs(V, reach, comps, capfd, monkeypatch):
     """Sparse, banded view graphs: the Jacobi-preconditioned solve runs into its cap and the solver must switch to the
     spanning-tree-preconditioned kernel (prefix-sum tree solves) -- same fixed point as the oracle's exact solves, in about
