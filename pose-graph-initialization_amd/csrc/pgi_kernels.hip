@@ -1353,6 +1353,16 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
+    {   // The first host <-> device copy of a process sets up the runtime's copy path (~20 ms, measured in the C++ driver's
+        // first upload): pay it here, where contexts are made, not inside the first batch.
+        void* dw = nullptr;
+        unsigned long long hw = 0;
+        if (hipMalloc(&dw, 256) == hipSuccess) {
+            (void)hipMemcpy(dw, &hw, sizeof hw, hipMemcpyHostToDevice);
+            (void)hipMemcpy(&hw, dw, sizeof hw, hipMemcpyDeviceToHost);
+            (void)hipFree(dw);
+        }
+    }
     return c;
 }
 

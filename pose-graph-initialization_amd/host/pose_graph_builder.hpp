@@ -494,6 +494,10 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     const bool kUseGPU, kUsePathFinding, kUseEpipolarHashing;
     const double kTraversalHeuristicsWeight, kInlierOutlierThreshold, kSimilarityThreshold;
     std::unique_ptr<Engine> engine;
+    // grow-only staging of estimatePoses: one page-locked host block and one device block, reused from wave to wave
+    // (defined in the implementation file: HIP stays out of this header)
+    struct Staging;
+    std::shared_ptr<Staging> staging;
 };
 
 namespace pose {
