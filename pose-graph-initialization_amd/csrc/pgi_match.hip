@@ -631,7 +631,9 @@ struct GuidedPair {
     // epipolar hashing (matcher.h:218-331): bins == 0 -> every destination keypoint is a candidate
     double ep0, ep1, min_angle, range;
     int32_t bins, pad;
+    uint64_t off2;  // first per-destination scratch slot of this pair (bucketed path)
 };
+constexpr int kGmMaxBuckets = 64;  // bins the bucketed scan handles (the reference uses 45); more -> the tiled scan below
 constexpr double kRadianToDegree = 180.0 / 3.14159265358979323846;
 // matcher.h:292-301 / :318-324: angle of a line normal -> bin index
 __device__ __forceinline__ int32_t epipolar_bin(double ny, double nx, double min_angle, double range, int32_t bins) {
@@ -740,36 +742,241 @@ __global__ __launch_bounds__(256) void guided_scan_kernel(const GuidedPair* __re
 }
 
 // one workgroup per pair: compaction in source order, then (only if more than max_n survive) rank by (ratio, position)
+// ---- epipolar hashing that saves the work (bins <= kGmMaxBuckets) ------------------------------------------------------
+// The tiled scan above tests every (source, destination) pair -- 64 M gates per image pair at 8000 keypoints -- and only
+// then compares bins.  Here both keypoint sets are first bucketed by bin (a stable counting sort: ascending index inside
+// a bucket, so candidates still arrive in ascending j and `best` / `second` / `count` come out the same), and a workgroup
+// of sources of ONE bin scans the destinations of that bin only: bins x fewer gates, same matches bit for bit.
+
+// rank of a lane among the lower lanes holding the same key, and whether it is the first of its group; n_same = group size
+__device__ inline uint32_t wave_group_rank(uint32_t key, bool active, bool& leader, uint32_t& n_same) {
+    uint32_t rank = 0;
+    leader = false;
+    n_same = 0;
+    uint64_t todo = __ballot(active);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t v = (uint32_t)__shfl((int)key, first);
+        const uint64_t m = __ballot(active && key == v) & todo;
+        if (active && key == v) {
+            rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            leader = rank == 0;
+            n_same = (uint32_t)__popcll(m);
+        }
+        todo &= ~m;
+    }
+    return rank;
+}
+
+// grid (pairs, 2): side 0 buckets the source keypoints, side 1 the destination keypoints (and stores their epipolar-line
+// records in bucket order).  One workgroup of 1024 threads; rounds of 1024 keypoints in index order.
+__global__ __launch_bounds__(1024) void guided_bucket_kernel(const GuidedPair* __restrict__ pairs, uint32_t* __restrict__ src_order,
+                                                             uint32_t* __restrict__ dst_order, double* __restrict__ dst_rec,
+                                                             uint32_t* __restrict__ starts /* pairs x 2 x (kGmMaxBuckets + 1) */,
+                                                             uint32_t* __restrict__ chunk_start /* pairs x (kGmMaxBuckets + 1) */) {
+    constexpr int kMaxRounds = PGI_DESC_MAX / 1024;
+    __shared__ unsigned short cnt[kMaxRounds * 16][kGmMaxBuckets];  // per (round, wavefront) and bin
+    __shared__ uint32_t bin_start[kGmMaxBuckets + 1];
+    const GuidedPair P = pairs[blockIdx.x];
+    const uint32_t side = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    const uint32_t n = side ? P.n2 : P.n1, bins = (uint32_t)P.bins;
+    const uint32_t rounds = (n + 1023u) >> 10;
+    for (uint32_t i = tid; i < (uint32_t)kMaxRounds * 16u * kGmMaxBuckets; i += 1024u) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    auto bin_of = [&](uint32_t i, double rec[4]) -> uint32_t {
+        if (side == 0) {
+            const double x1 = (double)P.kp1[2 * (size_t)i], y1 = (double)P.kp1[2 * (size_t)i + 1];
+            return (uint32_t)epipolar_bin(x1 - P.ep0, -(y1 - P.ep1), P.min_angle, P.range, P.bins);
+        }
+        const double x2 = (double)P.kp2[2 * (size_t)i], y2 = (double)P.kp2[2 * (size_t)i + 1];
+        const double rxc = (P.F[0] * x2 + P.F[3] * y2) + P.F[6];
+        const double ryc = (P.F[1] * x2 + P.F[4] * y2) + P.F[7];
+        const double rwc = (P.F[2] * x2 + P.F[5] * y2) + P.F[8];
+        rec[0] = rxc; rec[1] = ryc; rec[2] = rwc; rec[3] = rxc * rxc + ryc * ryc;
+        return (uint32_t)epipolar_bin(ryc, rxc, P.min_angle, P.range, P.bins);
+    };
+    // pass 1: how many keypoints of each bin every (round, wavefront) holds
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * 1024u + tid;
+        const bool active = i < n;
+        double rec[4];
+        const uint32_t b = active ? bin_of(i, rec) : 0u;
+        bool leader;
+        uint32_t n_same;
+        (void)wave_group_rank(b, active, leader, n_same);
+        if (active && leader) cnt[r * 16u + wv][b] = (unsigned short)n_same;
+    }
+    __syncthreads();
+    // exclusive prefix over (round, wavefront) for every bin, in place; totals -> bucket starts
+    if (tid < bins) {
+        uint32_t run = 0;
+        for (uint32_t q = 0; q < rounds * 16u; ++q) {
+            const uint32_t c = cnt[q][tid];
+            cnt[q][tid] = (unsigned short)run;
+            run += c;
+        }
+        bin_start[tid + 1] = run;  // count, turned into a prefix below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bin_start[0] = 0;
+        uint32_t chunks = 0;
+        uint32_t* cs = chunk_start + (size_t)blockIdx.x * (kGmMaxBuckets + 1);
+        for (uint32_t b = 0; b < bins; ++b) {
+            if (side == 0) { cs[b] = chunks; chunks += (bin_start[b + 1] + 255u) >> 8; }
+            bin_start[b + 1] += bin_start[b];
+        }
+        if (side == 0) cs[bins] = chunks;
+    }
+    __syncthreads();
+    uint32_t* st = starts + ((size_t)blockIdx.x * 2 + side) * (kGmMaxBuckets + 1);
+    if (tid <= bins) st[tid] = bin_start[tid];
+    // pass 2: place every keypoint (stable: rounds, wavefronts and lanes are all visited in index order)
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * 1024u + tid;
+        const bool active = i < n;
+        double rec[4] = {0, 0, 0, 0};
+        const uint32_t b = active ? bin_of(i, rec) : 0u;
+        bool leader;
+        uint32_t n_same;
+        const uint32_t rank = wave_group_rank(b, active, leader, n_same);
+        if (!active) continue;
+        const uint32_t pos = bin_start[b] + cnt[r * 16u + wv][b] + rank;
+        if (side == 0) {
+            src_order[P.off + pos] = i;
+        } else {
+            dst_order[P.off2 + pos] = i;
+            double* o = dst_rec + 4 * (P.off2 + pos);
+            o[0] = rec[0]; o[1] = rec[1]; o[2] = rec[2]; o[3] = rec[3];
+        }
+    }
+}
+
+// grid (chunks, pairs): chunk = up to 256 source keypoints of one bin against the destination keypoints of that bin
+__global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPair* __restrict__ pairs, const uint32_t* __restrict__ src_order,
+                                                                 const uint32_t* __restrict__ dst_order, const double* __restrict__ dst_rec,
+                                                                 const uint32_t* __restrict__ starts, const uint32_t* __restrict__ chunk_start,
+                                                                 int32_t* __restrict__ best_out, double* __restrict__ ratio_out) {
+    __shared__ double rec[kGmTile][4];
+    __shared__ uint32_t recj[kGmTile];
+    __shared__ uint32_t list[kGmList][256];
+    __shared__ uint32_t s_bin;
+    const GuidedPair P = pairs[blockIdx.y];
+    const uint32_t tid = threadIdx.x, bins = (uint32_t)P.bins;
+    const uint32_t* cs = chunk_start + (size_t)blockIdx.y * (kGmMaxBuckets + 1);
+    if (blockIdx.x >= cs[bins]) return;
+    if (tid == 0) {
+        uint32_t b = 0;
+        while (b + 1 < bins && cs[b + 1] <= blockIdx.x) ++b;
+        s_bin = b;
+    }
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    const uint32_t* st1 = starts + ((size_t)blockIdx.y * 2 + 0) * (kGmMaxBuckets + 1);
+    const uint32_t* st2 = starts + ((size_t)blockIdx.y * 2 + 1) * (kGmMaxBuckets + 1);
+    const uint32_t s_pos = st1[bin] + (blockIdx.x - cs[bin]) * 256u + tid;
+    const bool active = s_pos < st1[bin + 1];
+    const uint32_t i = active ? src_order[P.off + s_pos] : 0u;
+    double x1 = 0.0, y1 = 0.0;
+    if (active) { x1 = (double)P.kp1[2 * (size_t)i]; y1 = (double)P.kp1[2 * (size_t)i + 1]; }
+    const double rx = (P.F[0] * x1 + P.F[1] * y1) + P.F[2];
+    const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
+    const double b1 = rx * rx + ry * ry;
+    double best = DBL_MAX, second = DBL_MAX;
+    int32_t best_index = -1;
+    uint32_t count = 0, nlist = 0;
+    const float4* arow = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
+    auto flush = [&]() {
+        uint32_t longest = nlist;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
+        for (uint32_t c = 0; c < longest; ++c) {
+            if (c < nlist) {
+                const uint32_t j = list[c][tid];
+                const float4* brow = reinterpret_cast<const float4*>(P.d2 + (size_t)j * kD);
+                double dd = 0.0;
+                for (int k = 0; k < kD / 4; ++k) {
+                    const float4 a = arow[k], b = brow[k];
+                    const double v0 = (double)(a.x - b.x), v1 = (double)(a.y - b.y), v2 = (double)(a.z - b.z), v3 = (double)(a.w - b.w);
+                    dd = dd + v0 * v0;
+                    dd = dd + v1 * v1;
+                    dd = dd + v2 * v2;
+                    dd = dd + v3 * v3;
+                }
+                ++count;
+                if (dd < best) { second = best; best = dd; best_index = (int32_t)j; }
+            }
+        }
+        nlist = 0;
+    };
+    const uint32_t d0 = st2[bin], d1e = st2[bin + 1];
+    for (uint32_t j0 = d0; j0 < d1e; j0 += (uint32_t)kGmTile) {
+        __syncthreads();
+        const uint32_t lim = d1e - j0 < (uint32_t)kGmTile ? d1e - j0 : (uint32_t)kGmTile;
+        for (uint32_t jj = tid; jj < lim; jj += 256u) {
+            const double* o = dst_rec + 4 * (P.off2 + j0 + jj);
+            rec[jj][0] = o[0]; rec[jj][1] = o[1]; rec[jj][2] = o[2]; rec[jj][3] = o[3];
+            recj[jj] = dst_order[P.off2 + j0 + jj];
+        }
+        __syncthreads();
+        for (uint32_t jj = 0; jj < lim; ++jj) {
+            const double rxc = rec[jj][0], ryc = rec[jj][1], rwc = rec[jj][2], a1 = rec[jj][3];
+            const double r = (x1 * rxc + y1 * ryc) + rwc;
+            const double num = (r * r) * (a1 + b1), den = a1 * b1;
+            const bool surely_far = den > 0.0 && num >= 0.57 * den;
+            if (active && !surely_far) {
+                const double dist = num / den;
+                if (!(dist >= 0.75 * 0.75)) { list[nlist][tid] = recj[jj]; ++nlist; }
+            }
+            if (__any(nlist == (uint32_t)kGmList)) flush();
+        }
+    }
+    flush();
+    if (active) {
+        double corr = 1.0;
+        if (count < 20u) corr = 0.65 * 0.65;
+        if (count < 10u) corr = 0.6 * 0.6;
+        if (count < 5u) corr = 0.5 * 0.5;
+        if (count < 3u) corr = 0.25 * 0.25;
+        const double ratio = (best / second) / corr;
+        const bool keep = !(ratio < 0.00001) && best_index > -1 && (ratio < 0.8 * 0.8 || count == 1u);
+        best_out[P.off + i] = keep ? best_index : -1;
+        ratio_out[P.off + i] = ratio;
+    }
+}
+
 __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* __restrict__ pairs, const int32_t* __restrict__ best_in,
                                                              const double* __restrict__ ratio_in, uint32_t* __restrict__ ci,
                                                              uint32_t* __restrict__ cj, double* __restrict__ cr, uint32_t max_n,
                                                              uint32_t out_stride, uint32_t* __restrict__ out_src,
                                                              uint32_t* __restrict__ out_dst, double* __restrict__ out_ratio,
                                                              uint32_t* __restrict__ out_count) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry;
+    __shared__ double tile[2048];  // ratios of the rank-by-counting pass, staged 2048 at a time
     const GuidedPair P = pairs[blockIdx.x];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) carry = 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < P.n1; base += 1024u) {
+    for (uint32_t base = 0; base < P.n1; base += 1024u) {  // ordered compaction of the kept matches (ballots: three barriers a round)
         const uint32_t i = base + tid;
         const int32_t bj = i < P.n1 ? best_in[P.off + i] : -1;
-        const uint32_t v = bj >= 0 ? 1u : 0u;
-        part[tid] = v;
+        const bool v = bj >= 0;
+        const uint64_t mk = __ballot(v);
+        if (lane == 0) wtot[wv] = (uint32_t)__popcll(mk);
         __syncthreads();
-        for (uint32_t d = 1; d < 1024u; d <<= 1) {
-            const uint32_t add = tid >= d ? part[tid - d] : 0u;
-            __syncthreads();
-            part[tid] += add;
-            __syncthreads();
+        uint32_t before = carry, all = 0;
+        for (uint32_t q = 0; q < 16u; ++q) {
+            if (q < wv) before += wtot[q];
+            all += wtot[q];
         }
         if (v) {
-            const uint32_t pos = carry + part[tid] - 1u;
+            const uint32_t pos = before + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
             ci[P.off + pos] = i; cj[P.off + pos] = (uint32_t)bj; cr[P.off + pos] = ratio_in[P.off + i];
         }
         __syncthreads();
-        if (tid == 1023u) carry += part[1023];
+        if (tid == 0) carry += all;
         __syncthreads();
     }
     const uint32_t m = carry;
@@ -781,15 +988,32 @@ __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* _
         for (uint32_t k = tid; k < lim; k += 1024u) { out_src[o + k] = ci[P.off + k]; out_dst[o + k] = cj[P.off + k]; out_ratio[o + k] = cr[P.off + k]; }
         if (tid == 0) out_count[blockIdx.x] = lim;
     } else {
+        // rank by counting (ratio ascending, ties by position): every thread ranks its matches against tiles of ratios
+        // staged in LDS (the inner loop used to read them from global memory: 0.6 ms of the 0.7 ms this kernel took)
         const uint32_t lim = max_n < out_stride ? max_n : out_stride;
-        for (uint32_t k = tid; k < m; k += 1024u) {
-            const double rk = cr[P.off + k];
+        for (uint32_t k0 = 0; k0 < m; k0 += 1024u) {  // uniform trip count: the tile loads need every thread
+            const uint32_t k = k0 + tid;
+            const double rk = k < m ? cr[P.off + k] : 0.0;
             uint32_t rank = 0;
-            for (uint32_t q = 0; q < m; ++q) {
-                const double rq = cr[P.off + q];
-                rank += (rq < rk || (rq == rk && q < k)) ? 1u : 0u;
+            for (uint32_t q0 = 0; q0 < m; q0 += 2048u) {
+                __syncthreads();
+                for (uint32_t q = tid; q < 2048u && q0 + q < m; q += 1024u) tile[q] = cr[P.off + q0 + q];
+                __syncthreads();
+                const uint32_t qn = m - q0 < 2048u ? m - q0 : 2048u;
+                uint32_t q = 0;
+                for (; q + 8 <= qn; q += 8) {  // eight independent LDS reads in flight (one at a time is a latency chain)
+                    double rq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rq[u] = tile[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += (rq[u] < rk || (rq[u] == rk && q0 + q + (uint32_t)u < k)) ? 1u : 0u;
+                }
+                for (; q < qn; ++q) {
+                    const double rq = tile[q];
+                    rank += (rq < rk || (rq == rk && q0 + q < k)) ? 1u : 0u;
+                }
             }
-            if (rank < lim) { out_src[o + rank] = ci[P.off + k]; out_dst[o + rank] = cj[P.off + k]; out_ratio[o + rank] = rk; }
+            if (k < m && rank < lim) { out_src[o + rank] = ci[P.off + k]; out_dst[o + rank] = cj[P.off + k]; out_ratio[o + rank] = rk; }
         }
         if (tid == 0) out_count[blockIdx.x] = lim;
     }
@@ -1159,13 +1383,13 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<GuidedPair> hp(n_pairs);
-    uint64_t total = 0;
-    uint32_t max_n1 = 0;
+    uint64_t total = 0, total2 = 0;
+    uint32_t max_n1 = 0, max_kp = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
         const pgi_feature_view &a = h_src[p], &b = h_dst[p];
         if ((a.n && (!a.d_xy || !a.d_desc)) || (b.n && (!b.d_xy || !b.d_desc)))
             return pgi::fail(PGI_ERR_INVALID, "pgi_guided_match_batch: bad feature view");
-        GuidedPair g{a.d_xy, b.d_xy, a.d_desc, b.d_desc, a.n, b.n, {}, total, 0.0, 0.0, 0.0, 0.0, 0, 0};
+        GuidedPair g{a.d_xy, b.d_xy, a.d_desc, b.d_desc, a.n, b.n, {}, total, 0.0, 0.0, 0.0, 0.0, 0, 0, total2};
         // E = [t]x R (pose.h:50, pose_utils.h), F = K_dst^-T E K_src^-1 (matcher.h:216-217), operation order as in the oracle
         const double* R = h_pose_Rt + 12 * (size_t)p;
         const double* t = R + 9;
@@ -1213,11 +1437,18 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         }
         hp[p] = g;
         total += a.n;
+        total2 += b.n;
         max_n1 = a.n > max_n1 ? a.n : max_n1;
+        max_kp = std::max(max_kp, std::max(a.n, b.n));
     }
+    // bucketed scan (the hashing saves the work) where the bins fit its counters; otherwise the tiled scan over everything
+    const bool bucketed = n_bins > 0 && n_bins <= (uint32_t)kGmMaxBuckets && max_kp <= (uint32_t)PGI_DESC_MAX;
     const size_t pair_bytes = ((size_t)n_pairs * sizeof(GuidedPair) + 255) / 256 * 256;
     const size_t slot = ((size_t)total * 8 + 255) / 256 * 256;  // one 8-byte array of `total` entries
-    const size_t bytes = pair_bytes + 5 * slot + 256;
+    const size_t so_bytes = bucketed ? ((size_t)total * 4 + 255) / 256 * 256 : 0, do_bytes = bucketed ? ((size_t)total2 * 4 + 255) / 256 * 256 : 0,
+                 rec_bytes = bucketed ? ((size_t)total2 * 32 + 255) / 256 * 256 : 0,
+                 st_bytes = bucketed ? ((size_t)n_pairs * 3 * (kGmMaxBuckets + 1) * 4 + 255) / 256 * 256 : 0;
+    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + 256;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -1239,7 +1470,18 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     uint32_t* d_cj = (uint32_t*)(ws + pair_bytes + 4 * slot);
     HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), (size_t)n_pairs * sizeof(GuidedPair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
-    if (max_n1 > 0) {
+    if (max_n1 > 0 && bucketed) {
+        char* q = ws + pair_bytes + 5 * slot;
+        uint32_t* d_so = (uint32_t*)q; q += so_bytes;
+        uint32_t* d_do = (uint32_t*)q; q += do_bytes;
+        double* d_rec = (double*)q; q += rec_bytes;
+        uint32_t* d_starts = (uint32_t*)q;
+        uint32_t* d_chunks = d_starts + (size_t)n_pairs * 2 * (kGmMaxBuckets + 1);
+        hipLaunchKernelGGL(guided_bucket_kernel, dim3(n_pairs, 2), dim3(1024), 0, ctx->stream, d_pairs, d_so, d_do, d_rec, d_starts, d_chunks);
+        hipLaunchKernelGGL(guided_scan_binned_kernel, dim3((max_n1 + 255) / 256 + n_bins, n_pairs), dim3(256), 0, ctx->stream, d_pairs,
+                           d_so, d_do, d_rec, d_starts, d_chunks, d_best, d_rat);
+        HIP_TRY(hipGetLastError());
+    } else if (max_n1 > 0) {
         hipLaunchKernelGGL(guided_scan_kernel, dim3((max_n1 + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_best, d_rat);
         HIP_TRY(hipGetLastError());
     }
