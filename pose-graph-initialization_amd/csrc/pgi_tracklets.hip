@@ -6,8 +6,8 @@
 // destination view's track list in append order.  Observable state is therefore ONE append-only event log
 //     event = (track, view, keypoint)       "track gained the point; the view's list gained the track"
 // in the sequential order of the reference: a track's members, a view's track list and a point's track list are the
-// events with that track / view / point, in log order.  The store keeps the log and three stable re-orderings of it
-// (by track, by view, by point), rebuilt with radix sorts after every batch of add() calls.
+// events with that track / view / point, in log order.  The store keeps three stable orderings of the log (by track, by
+// view, by point); a batch's events are sorted by each key and merged in (old before new), O(new log new + total).
 //
 // add() in parallel: a match reads and extends only the track LISTS OF ITS TWO POINTS ("does track T hold P" is
 // "is T in P's list": both are appended together), so two matches are independent unless they share a point.  A batch
@@ -88,12 +88,14 @@ struct pgi_tracklets {
     uint32_t n_views = 0;
     uint32_t n_tracks = 0;
     size_t n_events = 0;
-    // canonical log
-    DevBuf ev_track, ev_key;
-    // re-orderings
-    DevBuf mem_key, trk_begin;      // members by track; offsets n_tracks + 1
-    DevBuf pt_key, pt_track;        // sorted point keys; tracks by point
-    DevBuf view_track, view_begin;  // tracks by view; offsets n_views + 1
+    // The log in its three stable orderings (each: sorted keys + payload).  A batch's events are sorted by each key and
+    // MERGED in (old before new at equal keys), into the other half of a ping-pong pair.
+    DevBuf trk_id[2], mem_key[2];   // by track: track ids (sorted), members
+    DevBuf pt_key[2], pt_track[2];  // by point: point keys (sorted), tracks
+    DevBuf view_id[2], view_track[2];  // by view: view ids (sorted), tracks
+    int cur = 0;                    // which half is current
+    DevBuf trk_begin, view_begin;   // offsets: n_tracks + 1, n_views + 1
+    DevBuf new_track, new_key;      // the running batch's events in sequential order
     DevBuf state;                   // DeviceState
     // scratch
     DevBuf sort_tmp, a64, b64, a32, b32, c32, d32;
@@ -509,6 +511,49 @@ __global__ void trk_append_kernel(const uint32_t* order, const uint32_t* nev_tra
     ev_key[i] = nev_key[e];
 }
 
+// Merge of two sorted runs by rank: an old element moves up by the number of new keys strictly below it, a new element
+// lands after every old key that is not greater (old before new at equal keys) -- two binary searches per element instead
+// of a re-sort of the whole log.
+template <class K>
+__device__ inline uint32_t lower_bound_t(const K* a, uint32_t n, K key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <class K>
+__device__ inline uint32_t upper_bound_t(const K* a, uint32_t n, K key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (!(key < a[mid])) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <class K, class V>
+__global__ void trk_merge_kernel(const K* old_k, const V* old_v, uint32_t n_old, const K* new_k, const V* new_v, uint32_t n_new, K* out_k,
+                                 V* out_v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_old) {
+        const K k = old_k[i];
+        const uint32_t pos = i + lower_bound_t<K>(new_k, n_new, k);
+        out_k[pos] = k;
+        out_v[pos] = old_v[i];
+    } else if (i < n_old + n_new) {
+        const uint32_t j = i - n_old;
+        const K k = new_k[j];
+        const uint32_t pos = j + upper_bound_t<K>(old_k, n_old, k);
+        out_k[pos] = k;
+        out_v[pos] = new_v[j];
+    }
+}
+__global__ void trk_gather32_kernel(const uint32_t* idx, const uint32_t* src, uint32_t n, uint32_t* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
 __global__ void trk_gather64_kernel(const uint32_t* idx, const uint64_t* src, uint32_t n, uint64_t* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -631,34 +676,60 @@ int read_state(pgi_tracklets* t, DeviceState& h, hipStream_t s) {
     return PGI_SUCCESS;
 }
 
-// the three re-orderings of the whole log
-int rebuild_views(pgi_tracklets* t, hipStream_t s) {
-    const size_t N = t->n_events;
-    if (!N) return PGI_SUCCESS;
-    TRK_TRY(t->a32.reserve(N * 4, s));
-    TRK_TRY(t->b32.reserve(N * 4, s));
-    TRK_TRY(t->c32.reserve(N * 4, s));
-    TRK_TRY(t->a64.reserve(N * 8, s));
-    TRK_TRY(t->mem_key.reserve(N * 8, s));
-    TRK_TRY(t->pt_key.reserve(N * 8, s));
-    TRK_TRY(t->pt_track.reserve(N * 4, s));
-    TRK_TRY(t->view_track.reserve(N * 4, s));
+// merges the batch's n_new events (new_track / new_key, sequential order) into the three orderings; t->n_events is the
+// number of events already merged
+int merge_batch(pgi_tracklets* t, uint32_t n_new, hipStream_t s) {
+    const uint32_t N0 = (uint32_t)t->n_events, N1 = N0 + n_new;
+    if (!n_new) return PGI_SUCCESS;
+    const int c = t->cur, o = c ^ 1;
+    for (DevBuf* b : {&t->a32, &t->b32, &t->c32, &t->d32}) TRK_TRY(b->reserve((size_t)n_new * 4, s));
+    TRK_TRY(t->a64.reserve((size_t)n_new * 8, s));
+    TRK_TRY(t->b64.reserve((size_t)n_new * 8, s));
+    TRK_TRY(t->trk_id[o].reserve((size_t)N1 * 4, s));
+    TRK_TRY(t->mem_key[o].reserve((size_t)N1 * 8, s));
+    TRK_TRY(t->pt_key[o].reserve((size_t)N1 * 8, s));
+    TRK_TRY(t->pt_track[o].reserve((size_t)N1 * 4, s));
+    TRK_TRY(t->view_id[o].reserve((size_t)N1 * 4, s));
+    TRK_TRY(t->view_track[o].reserve((size_t)N1 * 4, s));
     TRK_TRY(t->trk_begin.reserve(((size_t)t->n_tracks + 2) * 4, s));
     TRK_TRY(t->view_begin.reserve(((size_t)t->n_views + 2) * 4, s));
+    const uint32_t* nt = t->new_track.as<uint32_t>();
+    const uint64_t* nk = t->new_key.as<uint64_t>();
     int rc;
-    // by track: members in log order
-    if ((rc = sort_pairs_iota<uint32_t>(t, t->ev_track.as<uint32_t>(), t->a32.as<uint32_t>(), t->b32.as<uint32_t>(), N, bits_for(t->n_tracks), s))) return rc;
-    hipLaunchKernelGGL(trk_gather64_kernel, grid_for(N), dim3(NT), 0, s, t->b32.as<uint32_t>(), t->ev_key.as<uint64_t>(), (uint32_t)N, t->mem_key.as<uint64_t>());
-    hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_tracks + 1), dim3(NT), 0, s, t->a32.as<uint32_t>(), (uint32_t)N, t->n_tracks, t->trk_begin.as<uint32_t>());
-    // by point: tracks in log order
-    if ((rc = sort_pairs<uint64_t>(t, t->ev_key.as<uint64_t>(), t->pt_key.as<uint64_t>(), t->ev_track.as<uint32_t>(), t->pt_track.as<uint32_t>(), N,
-                                   32 + bits_for(t->n_views), s))) return rc;
-    // by view: tracks in log order
-    hipLaunchKernelGGL(trk_views_of_kernel, grid_for(N), dim3(NT), 0, s, t->ev_key.as<uint64_t>(), (uint32_t)N, t->c32.as<uint32_t>());
-    if ((rc = sort_pairs<uint32_t>(t, t->c32.as<uint32_t>(), t->a32.as<uint32_t>(), t->ev_track.as<uint32_t>(), t->view_track.as<uint32_t>(), N,
-                                   bits_for(t->n_views), s))) return rc;
-    hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_views + 1), dim3(NT), 0, s, t->a32.as<uint32_t>(), (uint32_t)N, t->n_views, t->view_begin.as<uint32_t>());
+    if (!N0) {  // nothing to merge with: sort straight into place
+        if ((rc = sort_pairs_iota<uint32_t>(t, nt, t->trk_id[o].as<uint32_t>(), t->b32.as<uint32_t>(), n_new, bits_for(t->n_tracks), s))) return rc;
+        hipLaunchKernelGGL(trk_gather64_kernel, grid_for(n_new), dim3(NT), 0, s, t->b32.as<uint32_t>(), nk, n_new, t->mem_key[o].as<uint64_t>());
+        if ((rc = sort_pairs<uint64_t>(t, nk, t->pt_key[o].as<uint64_t>(), nt, t->pt_track[o].as<uint32_t>(), n_new, 32 + bits_for(t->n_views), s))) return rc;
+        hipLaunchKernelGGL(trk_views_of_kernel, grid_for(n_new), dim3(NT), 0, s, nk, n_new, t->d32.as<uint32_t>());
+        if ((rc = sort_pairs<uint32_t>(t, t->d32.as<uint32_t>(), t->view_id[o].as<uint32_t>(), nt, t->view_track[o].as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
+        hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_tracks + 1), dim3(NT), 0, s, t->trk_id[o].as<uint32_t>(), N1, t->n_tracks, t->trk_begin.as<uint32_t>());
+        hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_views + 1), dim3(NT), 0, s, t->view_id[o].as<uint32_t>(), N1, t->n_views, t->view_begin.as<uint32_t>());
+        TRK_TRY(hipGetLastError());
+        TRK_TRY(hipStreamSynchronize(s));
+        t->cur = o;
+        t->n_events = N1;
+        return PGI_SUCCESS;
+    }
+    // by track: (track id, member)
+    if ((rc = sort_pairs_iota<uint32_t>(t, nt, t->a32.as<uint32_t>(), t->b32.as<uint32_t>(), n_new, bits_for(t->n_tracks), s))) return rc;
+    hipLaunchKernelGGL(trk_gather64_kernel, grid_for(n_new), dim3(NT), 0, s, t->b32.as<uint32_t>(), nk, n_new, t->a64.as<uint64_t>());
+    hipLaunchKernelGGL((trk_merge_kernel<uint32_t, uint64_t>), grid_for(N1), dim3(NT), 0, s, t->trk_id[c].as<uint32_t>(), t->mem_key[c].as<uint64_t>(), N0,
+                       t->a32.as<uint32_t>(), t->a64.as<uint64_t>(), n_new, t->trk_id[o].as<uint32_t>(), t->mem_key[o].as<uint64_t>());
+    hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_tracks + 1), dim3(NT), 0, s, t->trk_id[o].as<uint32_t>(), N1, t->n_tracks, t->trk_begin.as<uint32_t>());
+    // by point: (point key, track)
+    if ((rc = sort_pairs<uint64_t>(t, nk, t->b64.as<uint64_t>(), nt, t->c32.as<uint32_t>(), n_new, 32 + bits_for(t->n_views), s))) return rc;
+    hipLaunchKernelGGL((trk_merge_kernel<uint64_t, uint32_t>), grid_for(N1), dim3(NT), 0, s, t->pt_key[c].as<uint64_t>(), t->pt_track[c].as<uint32_t>(), N0,
+                       t->b64.as<uint64_t>(), t->c32.as<uint32_t>(), n_new, t->pt_key[o].as<uint64_t>(), t->pt_track[o].as<uint32_t>());
+    // by view: (view id, track)
+    hipLaunchKernelGGL(trk_views_of_kernel, grid_for(n_new), dim3(NT), 0, s, nk, n_new, t->d32.as<uint32_t>());
+    if ((rc = sort_pairs<uint32_t>(t, t->d32.as<uint32_t>(), t->a32.as<uint32_t>(), nt, t->b32.as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
+    hipLaunchKernelGGL((trk_merge_kernel<uint32_t, uint32_t>), grid_for(N1), dim3(NT), 0, s, t->view_id[c].as<uint32_t>(), t->view_track[c].as<uint32_t>(), N0,
+                       t->a32.as<uint32_t>(), t->b32.as<uint32_t>(), n_new, t->view_id[o].as<uint32_t>(), t->view_track[o].as<uint32_t>());
+    hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_views + 1), dim3(NT), 0, s, t->view_id[o].as<uint32_t>(), N1, t->n_views, t->view_begin.as<uint32_t>());
     TRK_TRY(hipGetLastError());
+    TRK_TRY(hipStreamSynchronize(s));
+    t->cur = o;
+    t->n_events = N1;
     return PGI_SUCCESS;
 }
 
@@ -757,7 +828,7 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     hipLaunchKernelGGL(trk_heads_kernel, grid_for(E), dim3(NT), 0, s, t->b64.as<uint64_t>(), (uint32_t)E, t->b32.as<uint32_t>());
     if ((rc = scan_u32(t, t->b32.as<uint32_t>(), t->c32.as<uint32_t>(), E, true, s))) return rc;
     hipLaunchKernelGGL(trk_segment_kernel, grid_for(E), dim3(NT), 0, s, t->b64.as<uint64_t>(), t->c32.as<uint32_t>(), (uint32_t)E,
-                       t->pt_key.as<uint64_t>(), (uint32_t)t->n_events, t->d32.as<uint32_t>(), t->seg_lo.as<uint32_t>(), t->seg_hi.as<uint32_t>());
+                       t->pt_key[t->cur].as<uint64_t>(), (uint32_t)t->n_events, t->d32.as<uint32_t>(), t->seg_lo.as<uint32_t>(), t->seg_hi.as<uint32_t>());
     hipLaunchKernelGGL(trk_rank_kernel, grid_for(E), dim3(NT), 0, s, t->a32.as<uint32_t>(), t->c32.as<uint32_t>(), t->d32.as<uint32_t>(), (uint32_t)E,
                        t->segS.as<uint32_t>(), t->segD.as<uint32_t>(), t->rankS.as<uint32_t>(), t->rankD.as<uint32_t>());
     TRK_TRY(hipGetLastError());
@@ -786,7 +857,7 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     a.seg_start = t->d32.as<uint32_t>(); a.seg_lo = t->seg_lo.as<uint32_t>(); a.seg_hi = t->seg_hi.as<uint32_t>();
     a.seg_cnt = t->seg_cnt.as<uint32_t>(); a.cursor = t->cursor.as<uint64_t>();
     a.run_start = t->run_start.as<uint32_t>(); a.run_len = t->run_len.as<uint32_t>();
-    a.pt_track = t->pt_track.as<uint32_t>();
+    a.pt_track = t->pt_track[t->cur].as<uint32_t>();
     a.n_matches = M;
     a.track_base = t->n_tracks;
     a.first_ever = t->n_events == 0 ? 1 : 0;
@@ -864,19 +935,17 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     uint32_t n_new = 0;
     TRK_TRY(hipMemcpyAsync(&n_new, &st->n_valid, 4, hipMemcpyDeviceToHost, s));
     TRK_TRY(hipStreamSynchronize(s));
-    const size_t N0 = t->n_events, N1 = N0 + n_new;
-    if (N1 >= 0xFFFFFFF0u) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: more than 2^32 events");
-    TRK_TRY(t->ev_track.reserve(N1 * 4, s, N0 * 4));
-    TRK_TRY(t->ev_key.reserve(N1 * 8, s, N0 * 8));
+    if ((size_t)t->n_events + n_new >= 0xFFFFFFF0u) return pgi::fail(PGI_ERR_TOO_LARGE, "pgi_tracklets_add_batch: more than 2^32 events");
+    TRK_TRY(t->new_track.reserve((size_t)n_new * 4 + 4, s));
+    TRK_TRY(t->new_key.reserve((size_t)n_new * 8 + 8, s));
     hipLaunchKernelGGL(trk_append_kernel, grid_for(n_new), dim3(NT), 0, s, t->a32.as<uint32_t>(), t->nev_track.as<uint32_t>(), t->nev_key.as<uint64_t>(),
-                       t->newrank.as<uint32_t>(), n_new, t->n_tracks, t->ev_track.as<uint32_t>() + N0, t->ev_key.as<uint64_t>() + N0);
+                       t->newrank.as<uint32_t>(), n_new, t->n_tracks, t->new_track.as<uint32_t>(), t->new_key.as<uint64_t>());
     TRK_TRY(hipGetLastError());
     TRK_TRY(hipStreamSynchronize(s));
     t->n_tracks += created;
-    t->n_events = N1;
-    timer.mark("order and append events");
-    rc = rebuild_views(t, s);
-    timer.mark("rebuild the three orderings");
+    timer.mark("order events");
+    rc = merge_batch(t, n_new, s);
+    timer.mark("merge into the three orderings");
     return rc;
 }
 
@@ -896,7 +965,7 @@ int pgi_tracklets_get_batch(pgi_tracklets* t, const uint32_t* h_view_src, const 
     TRK_TRY(hipMemcpyAsync(dq, h_view_src, (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
     TRK_TRY(hipMemcpyAsync(dq + n_queries, h_view_dst, (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(trk_get_kernel, dim3(n_queries), dim3(NT), 0, s, dq, dq + n_queries, t->n_views, t->view_begin.as<uint32_t>(),
-                       t->view_track.as<uint32_t>(), t->trk_begin.as<uint32_t>(), t->mem_key.as<uint64_t>(), (uint32_t)limit, out_stride, d_src_idx,
+                       t->view_track[t->cur].as<uint32_t>(), t->trk_begin.as<uint32_t>(), t->mem_key[t->cur].as<uint64_t>(), (uint32_t)limit, out_stride, d_src_idx,
                        d_dst_idx, d_count);
     TRK_TRY(hipGetLastError());
     // the query arrays are pageable host memory: the copies above have completed on return, the kernel is still queued
@@ -916,7 +985,7 @@ int pgi_tracklets_track(pgi_tracklets* t, uint64_t index, uint64_t* h_members, u
     *n_members = be[1] - be[0];
     const uint32_t n = std::min(*n_members, capacity);
     if (n && h_members) {
-        TRK_TRY(hipMemcpyAsync(h_members, t->mem_key.as<uint64_t>() + be[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TRK_TRY(hipMemcpyAsync(h_members, t->mem_key[t->cur].as<uint64_t>() + be[0], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
         TRK_TRY(hipStreamSynchronize(ctx->stream));
     }
     return PGI_SUCCESS;
