@@ -137,7 +137,9 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_ed
  * seed; internally the batch travels in chunks (a small first one, then multiples of the number of workgroups the
  * device keeps resident) through three device slots on three streams, so PCIe copies overlap the kernels and the
  * tail of one chunk's kernel overlaps the head of the next.  h_guess_Rt / h_has_guess may both be NULL.
- * h_masks: one byte per row.  Fastest with page-locked buffers (pgi_host_register). */
+ * h_masks: one byte per row.  Fastest with page-locked buffers (pgi_host_register / hipHostMalloc): when the four
+ * coordinate arrays, h_edges and h_masks are all page-locked the kernel works on them in place over PCIe (each row is read
+ * once, each result written once; no copy through HBM).  Same results either way. */
 int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h_y1, const float* h_x2,
                                  const float* h_y2, const uint64_t* h_offsets, const double* h_thr,
                                  const double* h_guess_Rt, const uint8_t* h_has_guess, uint32_t n_pairs,
@@ -145,7 +147,8 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
 
 /* Page-locks a caller-owned host buffer (hipHostRegister) so that the host-pointer entry points move it by true
  * asynchronous DMA at PCIe rate instead of through the runtime's pageable staging path; buffers that are not
- * registered keep working, slower.  Register once, reuse across calls; unregister before freeing the memory. */
+ * registered keep working, slower.  The registration also maps the buffer into the device's address space (in-place
+ * use by pgi_estimate_pose_batch_host).  Register once, reuse across calls; unregister before freeing the memory. */
 int pgi_host_register(void* h_ptr, uint64_t bytes);
 int pgi_host_unregister(void* h_ptr);
 

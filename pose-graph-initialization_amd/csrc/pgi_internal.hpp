@@ -59,6 +59,12 @@ struct pgi_ctx {
         bool used = false;
     } hslot[4];
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // high-priority input stream of the host-pointer path (copy_out: unused)
+    // page-locked buffers worked on in place (estimate_host_direct): per-pair arrays, and the mirror of rows outside LDS
+    void* d_direct = nullptr;
+    size_t direct_bytes = 0;
+    void* d_mirror = nullptr;
+    size_t mirror_bytes = 0;
+    int host_direct = 1;  // env PGI_HOST_DIRECT=0: always copy page-locked buffers through HBM
     int resident_wgs = 768;  // workgroups of K1 the device keeps resident (CUs x 3): the chunk quantum of the host path
     void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
     size_t match_ws_bytes = 0;

@@ -73,6 +73,12 @@ struct K1Args {
     unsigned long long* prof;  // kProfSlots counters (profiling builds) or nullptr
     const uint32_t* pair_list;   // size bucket: indices of the pairs of this launch (nullptr: all pairs)
     const uint32_t* pair_count;  // number of valid entries in pair_list
+    // Rows consumed in place from page-locked host memory (nullptr: the rows are at x1..y2).  K1 reads every row once
+    // while staging; rows that do not fit in LDS are copied to x1..y2 (then a device mirror) on the way.
+    const float* src_x1;
+    const float* src_y1;
+    const float* src_x2;
+    const float* src_y2;
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -498,11 +504,31 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         return;
     }
     // ---- stage the pair: coalesced SoA reads from HBM -> float4 rows in LDS ----
-    if constexpr (LDS_PTS != 0) {
-        const float nanv = __builtin_nanf("");
-        for (uint32_t i = tid; i < rows.lds_n; i += NT)
-            pts[i] = (i < n) ? make_float4(rows.x1[i], rows.y1[i], rows.x2[i], rows.y2[i])
-                             : make_float4(nanv, nanv, nanv, nanv);
+    {
+        const bool direct = a.src_x1 != nullptr;  // wave-uniform
+        const float* sx1 = direct ? a.src_x1 + o : rows.x1;
+        const float* sy1 = direct ? a.src_y1 + o : rows.y1;
+        const float* sx2 = direct ? a.src_x2 + o : rows.x2;
+        const float* sy2 = direct ? a.src_y2 + o : rows.y2;
+        if constexpr (LDS_PTS != 0) {
+            const float nanv = __builtin_nanf("");
+            for (uint32_t i = tid; i < rows.lds_n; i += NT)
+                pts[i] = (i < n) ? make_float4(sx1[i], sy1[i], sx2[i], sy2[i]) : make_float4(nanv, nanv, nanv, nanv);
+        }
+        if constexpr (LDS_PTS != 1) {
+            if (direct) {  // the rows beyond the LDS part are read many times: bring them over the bus once
+                float* mx1 = const_cast<float*>(rows.x1);
+                float* my1 = const_cast<float*>(rows.y1);
+                float* mx2 = const_cast<float*>(rows.x2);
+                float* my2 = const_cast<float*>(rows.y2);
+                for (uint32_t i = rows.lds_n + tid; i < n; i += NT) {
+                    mx1[i] = sx1[i];
+                    my1[i] = sy1[i];
+                    mx2[i] = sx2[i];
+                    my2[i] = sy2[i];
+                }
+            }
+        }
     }
     if (tid == 0) {
         sh->best_score = -1;
@@ -1351,6 +1377,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
+    if (const char* e = getenv("PGI_HOST_DIRECT")) c->host_direct = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
     {   // The first host <-> device copy of a process sets up the runtime's copy path (~20 ms, measured in the C++ driver's
@@ -1385,6 +1412,8 @@ void pgi_destroy(pgi_ctx* ctx) {
         if (ctx->hslot[k].k_done) (void)hipEventDestroy(ctx->hslot[k].k_done);
         if (ctx->hslot[k].out_done) (void)hipEventDestroy(ctx->hslot[k].out_done);
     }
+    if (ctx->d_direct) (void)hipFree(ctx->d_direct);
+    if (ctx->d_mirror) (void)hipFree(ctx->d_mirror);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     delete ctx;
@@ -1437,8 +1466,16 @@ int pgi_internal_set_profile_buffer(pgi_ctx* ctx, unsigned long long* d_buf) {
 }
 
 // enqueues K1 for a device-resident batch on `stream`; `bucket` is the caller's scratch for the size-bucket lists
+// largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
+static uint32_t k1_rows_cap(const pgi_ctx* ctx, int wgs_per_cu, size_t fixed_bytes) {
+    const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
+    return budget > fixed_bytes ? (uint32_t)(((budget - fixed_bytes) / 16) & ~(size_t)63) : 0u;
+}
+
+// `src`: four page-locked host arrays (device-visible addresses) the rows are consumed from in place; b->d_x1..d_y2 are
+// then the device mirror for rows that do not fit in LDS.
 static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks,
-                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap) {
+                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1451,13 +1488,12 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.prof = ctx->d_prof;
     a.pair_list = nullptr;
     a.pair_count = nullptr;
+    a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
+    a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t fixed = k1_fixed_lds(false), fixed_stash = k1_fixed_lds(true);
     const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
-    auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) {  // largest 64-multiple of rows that still lets wgs_per_cu workgroups share a CU
-        const size_t budget = (size_t)ctx->max_lds / (size_t)wgs_per_cu;
-        return budget > fixed_bytes ? (uint32_t)(((budget - fixed_bytes) / 16) & ~(size_t)63) : 0u;
-    };
+    auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) { return k1_rows_cap(ctx, wgs_per_cu, fixed_bytes); };
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
     const uint32_t cap4 = rows_cap(4), cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
     bool hybrid = false;
@@ -1525,6 +1561,75 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
 }
 
+// Page-locked inputs AND results: K1 works on the caller's buffers IN PLACE over PCIe.  The kernel reads every row exactly
+// once (its staging loop) and writes every result once, so a copy to HBM first only adds a pipeline with a head (the first
+// chunk's copy) and a tail (the last chunk's kernel and its results) around transfers the kernel can issue itself: a kernel
+// reading host memory moves 53 GB/s here against 57 GB/s for hipMemcpyAsync (scripts/probes/zero_copy_probe.hip), overlapped
+// with the fits of the other resident workgroups.  Only the per-pair arrays are uploaded; pairs too large for LDS copy
+// their tail rows into a device mirror while staging.  One launch sequence, nothing to bring back.
+// BASELINE config 2 host to host: 7.7-8.0 ms against 8.1-8.3 ms for the copy pipeline below (scripts/host_direct_bench.py).
+static int estimate_host_direct(pgi_ctx* ctx, const float* const* src, const uint64_t* h_offsets, const double* h_thr,
+                                const double* h_guess_Rt, const uint8_t* h_has_guess, uint32_t n_pairs, uint64_t pair_id_base,
+                                uint64_t seed, pgi_edge* map_edges, uint8_t* map_masks) {
+    const bool guesses = h_guess_Rt != nullptr;
+    const uint64_t base = h_offsets[0], rows = h_offsets[n_pairs] - base;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_off = 0, o_thr = o_off + up(((size_t)n_pairs + 1) * 8), o_guess = o_thr + up((size_t)n_pairs * 8),
+                 o_has = o_guess + up((size_t)n_pairs * 96), total = o_has + up(n_pairs);
+    pgi_ctx::HostSlot& S = ctx->hslot[0];
+    if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    if (total > ctx->direct_bytes) {
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        if (ctx->d_direct) (void)hipFree(ctx->d_direct);
+        ctx->d_direct = nullptr; ctx->direct_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_direct, total + total / 4));
+        ctx->direct_bytes = total + total / 4;
+    }
+    if (total > S.h_small_bytes) {
+        if (S.h_small) (void)hipHostFree(S.h_small);
+        S.h_small = nullptr; S.h_small_bytes = 0;
+        HIP_TRY(hipHostMalloc(&S.h_small, total + total / 4, hipHostMallocDefault));
+        S.h_small_bytes = total + total / 4;
+    }
+    char* hs = (char*)S.h_small;
+    char* d = (char*)ctx->d_direct;
+    uint64_t* ol = reinterpret_cast<uint64_t*>(hs + o_off);
+    uint32_t max_corr = 0;
+    for (uint32_t k = 0; k <= n_pairs; ++k) ol[k] = h_offsets[k] - base;
+    for (uint32_t k = 0; k < n_pairs; ++k) max_corr = std::max(max_corr, (uint32_t)(ol[k + 1] - ol[k]));
+    memcpy(hs + o_thr, h_thr, (size_t)n_pairs * 8);
+    if (guesses) {
+        memcpy(hs + o_guess, h_guess_Rt, (size_t)n_pairs * 96);
+        memcpy(hs + o_has, h_has_guess, n_pairs);
+    }
+    HIP_TRY(hipMemcpyAsync(d, hs, guesses ? o_has + n_pairs : o_thr + (size_t)n_pairs * 8, hipMemcpyHostToDevice, S.stream));
+    // the rows of pairs beyond the four-workgroup LDS capacity live partly (or wholly) outside LDS: device mirror
+    const bool need_mirror = ((max_corr + 63u) & ~63u) > k1_rows_cap(ctx, 4, k1_fixed_lds(false));
+    const float* mirror[4] = {src[0], src[1], src[2], src[3]};
+    if (need_mirror) {
+        const size_t one = up((size_t)rows * 4);
+        if (4 * one > ctx->mirror_bytes) {
+            HIP_TRY(hipStreamSynchronize(S.stream));
+            if (ctx->d_mirror) (void)hipFree(ctx->d_mirror);
+            ctx->d_mirror = nullptr; ctx->mirror_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->d_mirror, 4 * one));
+            ctx->mirror_bytes = 4 * one;
+        }
+        for (int k = 0; k < 4; ++k) mirror[k] = reinterpret_cast<const float*>((char*)ctx->d_mirror + (size_t)k * one);
+    }
+    pgi_batch b{};
+    b.d_x1 = mirror[0]; b.d_y1 = mirror[1]; b.d_x2 = mirror[2]; b.d_y2 = mirror[3];
+    b.d_offsets = reinterpret_cast<const uint64_t*>(d + o_off);
+    b.d_thr = reinterpret_cast<const double*>(d + o_thr);
+    b.d_guess_Rt = guesses ? reinterpret_cast<const double*>(d + o_guess) : nullptr;
+    b.d_has_guess = guesses ? reinterpret_cast<const uint8_t*>(d + o_has) : nullptr;
+    b.n_pairs = n_pairs; b.max_corr = max_corr; b.pair_id_base = pair_id_base; b.seed = seed;
+    const int rc = launch_estimate(ctx, ctx->prm, &b, map_edges, map_masks, S.stream, &S.d_bucket, &S.bucket_bytes, src);
+    if (rc < 0) return rc;
+    HIP_TRY(hipStreamSynchronize(S.stream));  // the results are in the caller's buffers
+    return PGI_SUCCESS;
+}
+
 // Host buffers in, host buffers out: the batch is cut into chunks that travel through two device slots on two
 // streams, so the H2D copy of chunk c+1 and the D2H copy of chunk c-1 overlap the kernel of chunk c (PCIe-inclusive
 // throughput ~ max(copy, compute) instead of their sum).  Pair ids are global, so the result equals the one-launch one.
@@ -1553,19 +1658,50 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     // (results always return on the chunk's kernel stream, two launches behind the front: measured faster than an
     // immediate copy on a dedicated stream even for page-locked result buffers, 8.6 ms vs 9.0-13 ms)
     const bool pinned = pin_in;
+    if (pinned && ctx->host_direct && page_locked(h_edges) && page_locked(h_masks)) {  // work on the caller's buffers in place
+        void* hp[6] = {const_cast<float*>(h_x1), const_cast<float*>(h_y1), const_cast<float*>(h_x2), const_cast<float*>(h_y2), h_edges, h_masks};
+        void* dp[6] = {};
+        bool mapped = true;
+        for (int k = 0; k < 6 && mapped; ++k)
+            if (hipHostGetDevicePointer(&dp[k], hp[k], 0) != hipSuccess || !dp[k]) {
+                (void)hipGetLastError();  // page-locked but not mapped into the device's address space: copy instead
+                mapped = false;
+            }
+        if (mapped) {
+            const float* src[4] = {static_cast<const float*>(dp[0]), static_cast<const float*>(dp[1]), static_cast<const float*>(dp[2]),
+                                   static_cast<const float*>(dp[3])};
+            return estimate_host_direct(ctx, src, h_offsets, h_thr, h_guess_Rt, h_has_guess, n_pairs, pair_id_base, seed,
+                                        static_cast<pgi_edge*>(dp[4]), static_cast<uint8_t*>(dp[5]));
+        }
+    }
     // Chunks are multiples of the number of resident workgroups (no chunk ends in a mostly empty last wave of
     // workgroups).  Page-locked: PCIe (~57 GB/s) is only ~1.3x faster than K1 consumes rows, so equal, small chunks keep
     // the copy front just ahead of the kernels and expose only the first chunk's copy.  Pageable: the runtime stages
     // every copy on the calling thread, so fewer, larger chunks (a small first one) amortise that better.
     const uint32_t quantum = (uint32_t)std::max(64, ctx->resident_wgs);
     uint32_t first_q = pinned ? 2 : 1, rest_q = pinned ? 2 : 3;
+    bool chunks_from_env = false;
     if (const char* e = getenv("PGI_HOST_CHUNKS")) {  // "first,rest" in quanta (experiments)
         unsigned a = 0, b2 = 0;
-        if (sscanf(e, "%u,%u", &a, &b2) == 2 && a && b2) { first_q = a; rest_q = b2; }
+        if (sscanf(e, "%u,%u", &a, &b2) == 2 && a && b2) { first_q = a; rest_q = b2; chunks_from_env = true; }
+    }
+    std::vector<uint32_t> ramp;  // PGI_HOST_CHUNK_PAIRS="a,b,c": pairs of the first chunks, the last value repeats (experiments)
+    if (const char* e = getenv("PGI_HOST_CHUNK_PAIRS")) {
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const unsigned long v = strtoul(q, &end, 10);
+            if (end == q) break;
+            if (v) ramp.push_back((uint32_t)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
     }
     std::vector<uint32_t> cuts(1, 0u);
     for (uint32_t p = 0; p < n_pairs;) {
-        const uint32_t want = (cuts.size() == 1 ? first_q : rest_q) * quantum;
+        uint32_t want = (cuts.size() == 1 ? first_q : rest_q) * quantum;
+        // page-locked inputs: short first chunks (the kernels start sooner), then 1.5 quanta -- 8.1-8.2 ms against 8.25-8.6 ms
+        // for equal chunks of two quanta on BASELINE config 2 (scripts/host_direct_bench.py ramp ...)
+        if (pinned && !chunks_from_env) want = cuts.size() == 1 ? quantum / 2 : cuts.size() == 2 ? quantum : quantum + quantum / 2;
+        if (!ramp.empty()) want = ramp[std::min(cuts.size() - 1, ramp.size() - 1)];
         uint32_t q = p;
         const uint64_t r0 = h_offsets[p];
         while (q < n_pairs && q - p < want && (q == p || h_offsets[q + 1] - r0 <= 8000000ull)) ++q;
@@ -1573,7 +1709,8 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         cuts.push_back(q);
         p = q;
     }
-    // the kernel of the last chunk is pure tail (nothing left to overlap it with): keep that chunk to one quantum
+    // the kernel of the last chunk is pure tail (nothing left to overlap it with): keep that chunk to one quantum (shorter
+    // ramp-down chunks were slower: a chunk's kernel lasts as long as its slowest pair, whatever its size)
     if (pinned && cuts.size() >= 3) {
         const uint32_t a0 = cuts[cuts.size() - 2], b0 = cuts.back();
         if (b0 - a0 >= quantum + quantum / 2) cuts.insert(cuts.end() - 1, b0 - quantum);
@@ -1822,7 +1959,7 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
 
 int pgi_host_register(void* h_ptr, uint64_t bytes) {
     if (!h_ptr || !bytes) return fail(PGI_ERR_INVALID, "null argument");
-    HIP_TRY(hipHostRegister(h_ptr, (size_t)bytes, hipHostRegisterDefault));
+    HIP_TRY(hipHostRegister(h_ptr, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));  // mapped: K1 may read it in place
     return PGI_SUCCESS;
 }
 

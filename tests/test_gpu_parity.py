@@ -491,6 +491,49 @@ def test_host_buffer_batch_equals_device_batch():
         eng.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_page_locked_host_batch_equals_device_batch(direct, monkeypatch):
+    """Page-locked inputs and results: K1 works on them in place over PCIe (rows beyond the LDS part go through a device
+    mirror); PGI_HOST_DIRECT=0 pipelines copies through HBM instead.  Both must equal one launch on resident data -- every size class (LDS,
+    hybrid, two-workgroup LDS, rows from L2), with and without guesses, uniform small pairs (no mirror) and ragged ones."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_HOST_DIRECT", direct)
+    rng = np.random.default_rng(77)
+    eng = Engine()
+    try:
+        for case, (P, choices) in enumerate([(2600, [5, 40, 64, 300, 700, 1300, 1500, 2100, 2600, 4100, 9000]), (900, [200, 640, 1000])]):
+            sizes = rng.choice(choices, P)
+            b = S.make_batch(np.arange(7000, 7000 + P), sizes)
+            guesses = np.zeros((P, 12))
+            has = (rng.random(P) < 0.2).astype(np.uint8)
+            for i in np.nonzero(has)[0]:
+                guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
+            for use_guess in ([True, False] if case == 0 else [False]):
+                kw = dict(guesses=guesses, has_guess=has) if use_guess else {}
+                db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=3, pair_id_base=55, **kw)
+                e, m = eng.estimate_pose_batch(db)
+                ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+                xs = [np.array(b[k], np.float32) for k in ("x1", "y1", "x2", "y2")]
+                out = (np.zeros(P, ref.dtype), np.zeros(len(ref_m), np.uint8))
+                eng.pin(*xs, *out)
+                try:
+                    for rep in range(2):   # the second call reuses the mirror and the staging block
+                        out[0][:] = 0
+                        out[1][:] = 7
+                        got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=55, out=out, **kw)
+                        assert np.array_equal(got_m, ref_m)
+                        for k in ref.dtype.names:
+                            assert np.array_equal(got[k], ref[k]), k
+                    # page-locked inputs, pageable results: the copy pipeline
+                    got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=55, **kw)
+                    assert np.array_equal(got_m, ref_m) and np.array_equal(got["E"], ref["E"])
+                finally:
+                    eng.unpin(*xs, *out)
+    finally:
+        eng.close()
+
+
 def test_rotation_guided_guess_mode_matches_oracle(eng):
     """guess_mode = 1 (BASELINE config 5): keep the guess's rotation, re-estimate the translation direction
     from 32 two-point hypotheses, local optimisation, accept at min_inliers, else the robust fit -- bit-identical to the
