@@ -1382,13 +1382,22 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
     {   // The first host <-> device copy of a process sets up the runtime's copy path (~20 ms, measured in the C++ driver's
         // first upload): pay it here, where contexts are made, not inside the first batch.
-        void* dw = nullptr;
+        // Small pageable copies and large page-locked ones take different routes inside the runtime: warm both.
+        constexpr size_t kWarm = 1u << 20;
+        void *dw = nullptr, *pw = nullptr;
         unsigned long long hw = 0;
-        if (hipMalloc(&dw, 256) == hipSuccess) {
+        if (hipMalloc(&dw, kWarm) == hipSuccess) {
             (void)hipMemcpy(dw, &hw, sizeof hw, hipMemcpyHostToDevice);
             (void)hipMemcpy(&hw, dw, sizeof hw, hipMemcpyDeviceToHost);
+            if (hipHostMalloc(&pw, kWarm, hipHostMallocDefault) == hipSuccess) {
+                memset(pw, 0, kWarm);
+                (void)hipMemcpy(dw, pw, kWarm, hipMemcpyHostToDevice);
+                (void)hipMemcpy(pw, dw, kWarm, hipMemcpyDeviceToHost);
+                (void)hipHostFree(pw);
+            }
             (void)hipFree(dw);
         }
+        (void)hipGetLastError();
     }
     return c;
 }
