@@ -70,6 +70,10 @@ struct pgi_ctx {
     size_t match_ws_bytes = 0;
     uint32_t* d_match_cnt = nullptr;  // per-pair flagged-row counters of the last screened match (forward, then backward)
     uint32_t match_cnt_pairs = 0;
+    void* h_match_stage[2] = {nullptr, nullptr};  // page-locked mirrors of the screened matcher's pair tables, used in turn
+    size_t match_stage_bytes[2] = {0, 0};
+    hipEvent_t match_stage_ev[2] = {nullptr, nullptr};  // their last uploads
+    int match_stage_next = 0;
     int match_screen = 1;  // bf16 screening + exact f32 verification when the views carry the data (env PGI_MATCH_SCREEN)
     int match_waves = 4;  // wavefronts per matching workgroup (4 or 8; env PGI_MATCH_WAVES)
     int lds_min_wgs = 2;  // stage rows in LDS only if this many workgroups still fit per CU

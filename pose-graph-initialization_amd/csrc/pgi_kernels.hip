@@ -1421,6 +1421,10 @@ void pgi_destroy(pgi_ctx* ctx) {
         if (ctx->hslot[k].k_done) (void)hipEventDestroy(ctx->hslot[k].k_done);
         if (ctx->hslot[k].out_done) (void)hipEventDestroy(ctx->hslot[k].out_done);
     }
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->h_match_stage[k]) (void)hipHostFree(ctx->h_match_stage[k]);
+        if (ctx->match_stage_ev[k]) (void)hipEventDestroy(ctx->match_stage_ev[k]);
+    }
     if (ctx->d_direct) (void)hipFree(ctx->d_direct);
     if (ctx->d_mirror) (void)hipFree(ctx->d_mirror);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);

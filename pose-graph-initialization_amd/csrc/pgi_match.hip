@@ -207,13 +207,17 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
                                                             uint32_t* __restrict__ out_dst, double* __restrict__ out_ratio,
                                                             uint32_t* __restrict__ out_count) {
     extern __shared__ unsigned long long keys[];
-    __shared__ uint32_t s_count;
+    __shared__ uint32_t s_count, s_valid;
     const MatchPair P = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     uint32_t np = 2;
     while (np < P.n_a) np <<= 1;
-    if (tid == 0) s_count = 0u;
+    if (tid == 0) { s_count = 0u; s_valid = 0u; }
+    __syncthreads();
     const bool both = P.n_a >= 2u && P.n_b >= 2u;  // feature_utils.h:167-168
+    // Only the rows that pass the ratio and mutual tests are sorted (about a third on the bench): they are compacted to
+    // the front first -- in any order, a key is unique (it carries its row) and the sort defines the output order -- and
+    // the bitonic network runs over the next power of two of their number instead of over every row.
     for (uint32_t i = tid; i < np; i += 1024u) {
         unsigned long long key = ~0ull;
         if (i < P.n_a && both) {
@@ -233,8 +237,18 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
                 rowpart[P.row_off + i].j1 = m.j1;  // merged best column, read back after the sort
             }
         }
-        keys[i] = key;
+        const bool valid = key != ~0ull;
+        const unsigned long long bal = __ballot(valid);
+        uint32_t base = 0;
+        if ((tid & 63u) == 0u && bal) base = atomicAdd(&s_valid, (uint32_t)__popcll(bal));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (valid) keys[base + (uint32_t)__popcll(bal & ((1ull << (tid & 63u)) - 1ull))] = key;
     }
+    __syncthreads();
+    const uint32_t n_valid = s_valid;
+    np = 2;
+    while (np < n_valid) np <<= 1;
+    for (uint32_t i = n_valid + tid; i < np; i += 1024u) keys[i] = ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= np; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(1024) void match_select_kernel(const MatchPair* __r
 //                        column's position rides in the low mantissa bits of the key, so min / med3 carry it along.
 //   desc_verify_kernel   exact f32 chain (the specification) for the stored candidates only -> RowBest; flagged rows
 //                        go to a list.
-//   desc_exact_rows_kernel  flagged rows: full exact scan, one wavefront per row.
+//   desc_exact_rows_kernel  flagged rows: full exact scan, four rows per 1024-thread workgroup.
+//   needed_columns_kernel   the columns the mutual test will read: the column-wise direction only visits those.
 // The column-wise nearest neighbour is the row problem with the images swapped (identical bits: products and the
 // norm sum commute), so the pipeline runs twice and feeds the unchanged selection kernel.
 //
@@ -307,6 +322,10 @@ struct ScreenPair {
     const float *na, *nb;
     uint32_t n_a, n_a_pad, n_b, n_b_pad;
     uint64_t row_off;                 // first row slot of this pair (ScreenRow / RowBest / keys)
+    // Restricted pass (the column-wise direction): only the rows listed in row_list[row_off ..] (ascending, *row_count of
+    // them) are screened and verified; ScreenRow slots are then positions in the list.  nullptr: every row.
+    const uint32_t* row_list;
+    const uint32_t* row_count;
 };
 struct ScreenRow {
     uint32_t count, flagged;
@@ -327,10 +346,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     const uint32_t x = wgid % wgs_per_pair, rb = x / splits, split = x % splits;
     constexpr uint32_t kRows = NW * 32u;
     if (rb * kRows >= P.n_a_pad) return;
+    const uint32_t n_listed = P.row_list ? *P.row_count : 0u;
+    if (P.row_list && rb * kRows >= n_listed) return;  // (workgroup-uniform)
     const uint32_t tiles = P.n_b_pad / kTileJ;
     const uint32_t t0 = (uint32_t)((uint64_t)tiles * split / splits), t1 = (uint32_t)((uint64_t)tiles * (split + 1) / splits);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
     const uint32_t row_base = rb * kRows + w * 32u;
+    // slot -> row of A (slots past the end of a list repeat row 0: computed, never read)
+    auto row_of = [&](uint32_t slot) { return P.row_list ? (slot < n_listed ? P.row_list[P.row_off + slot] : 0u) : slot; };
 
     // largest column norm (for eps): every wavefront scans the norm array once
     float nbmax = 0.0f;
@@ -340,9 +363,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     if (lane == 0) s_nbmax[w] = nbmax;
     // A fragments: lane (c, h) holds A[row_base + c][16 ks + 8 h .. +7] for the eight k-steps
     f16x8 a[kD / 16];
+    const uint32_t a_row = row_of(row_base + c);
 #pragma unroll
     for (int ks = 0; ks < kD / 16; ++ks)
-        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + f16_offset(row_base + c, 16u * (uint32_t)ks + 8u * h));
+        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + f16_offset(a_row, 16u * (uint32_t)ks + 8u * h));
     // Per lane and row: the three smallest KEYS seen so far, b1 <= b2 <= b3, as unsigned integers.  A key is the bit
     // pattern of the approximate squared distance d~ = max(0, na + nb - 2 s~) -- non-negative floats order like their bit
     // patterns -- with the column's position inside this lane's stream (code = 2 * (tile - t0) + sub, 9 bits: at most
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     uint32_t b1[16], b2[16], b3[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        nar[r] = P.na[row_base + mfma_row(r, h)];
+        nar[r] = P.na[row_of(row_base + mfma_row(r, h))];
         b1[r] = kKeyInf; b2[r] = kKeyInf; b3[r] = kKeyInf;
     }
     auto med3u = [](uint32_t x, uint32_t y, uint32_t z) {
@@ -497,6 +521,22 @@ __device__ __forceinline__ float exact_d2(const float* __restrict__ ai, const fl
     return d2 > 0.0f ? d2 : 0.0f;
 }
 
+// the same chain with A read from its transposed copy (128 x n_pad): neighbouring lanes hold neighbouring rows, so the A side
+// of a wavefront's load is one or two cache lines instead of 64 (the row-major read cost the vector L1 a tag per lane)
+__device__ __forceinline__ float exact_d2_ta(const float* __restrict__ at_i, uint32_t n_a_pad, const float* __restrict__ bj, float na, float nb) {
+    float s = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < kD; k += 4) {
+        const float4 y = *reinterpret_cast<const float4*>(bj + k);
+        s = fmaf(at_i[(size_t)k * n_a_pad], y.x, s);
+        s = fmaf(at_i[(size_t)(k + 1) * n_a_pad], y.y, s);
+        s = fmaf(at_i[(size_t)(k + 2) * n_a_pad], y.z, s);
+        s = fmaf(at_i[(size_t)(k + 3) * n_a_pad], y.w, s);
+    }
+    const float d2 = (na + nb) - 2.0f * s;
+    return d2 > 0.0f ? d2 : 0.0f;
+}
+
 // one thread per row: exact distances of the screened candidates -> (b1, j1, b2); flagged rows are queued.
 // as_keys = 1 writes the column-best key (d2 bits, row index) of the swapped problem instead of a RowBest.
 __global__ __launch_bounds__(256) void desc_verify_kernel(const ScreenPair* __restrict__ pairs, const ScreenRow* __restrict__ scr,
@@ -504,20 +544,22 @@ __global__ __launch_bounds__(256) void desc_verify_kernel(const ScreenPair* __re
                                                          unsigned long long* __restrict__ keys, uint32_t as_keys,
                                                          uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
     const ScreenPair P = pairs[blockIdx.y];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= P.n_a || i >= max_rows) return;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= P.n_a || slot >= max_rows) return;
+    if (P.row_list && slot >= *P.row_count) return;
+    const uint32_t i = P.row_list ? P.row_list[P.row_off + slot] : slot;
     bool flagged = false;
     float b1 = INFINITY, b2 = INFINITY;
     uint32_t j1 = 0u, seen = 0u;
-    const float* ai = P.arm + (size_t)i * kD;
+    const float* at_i = P.at + i;
     const float nai = P.na[i];
     for (uint32_t s = 0; s < splits; ++s) {
-        const ScreenRow* r = scr + (size_t)s * split_stride + P.row_off + i;
+        const ScreenRow* r = scr + (size_t)s * split_stride + P.row_off + slot;
         flagged |= r->flagged != 0u;
         const uint32_t cnt = r->count;
         for (uint32_t q = 0; q < cnt; ++q) {
             const uint32_t j = r->j[q];
-            const float d2 = exact_d2(ai, P.brm + (size_t)j * kD, nai, P.nb[j]);
+            const float d2 = exact_d2_ta(at_i, P.n_a_pad, P.brm + (size_t)j * kD, nai, P.nb[j]);
             if (d2 < b1 || (d2 == b1 && j < j1)) { b2 = b1; b1 = d2; j1 = j; }
             else if (d2 < b2) { b2 = d2; }
             ++seen;
@@ -533,18 +575,30 @@ __global__ __launch_bounds__(256) void desc_verify_kernel(const ScreenPair* __re
     else { RowBest rb; rb.b1 = b1; rb.b2 = b2; rb.j1 = j1; rb.pad = 0u; rowbest[P.row_off + i] = rb; }
 }
 
-// flagged rows: the full exact scan.  A workgroup takes four queued rows of one pair at a time; its 256 threads own the
-// columns j = tid, tid + 256, ..., so every B value loaded feeds four chains and B is streamed once per four rows.
-__global__ __launch_bounds__(256) void desc_exact_rows_kernel(const ScreenPair* __restrict__ pairs, const uint32_t* __restrict__ fb_list,
-                                                             const uint32_t* __restrict__ fb_count, RowBest* __restrict__ rowbest,
-                                                             unsigned long long* __restrict__ keys, uint32_t as_keys) {
+// flagged rows: the full exact scan.  A workgroup takes four queued rows of one pair at a time; its 1024 threads own the
+// columns j = tid, tid + 1024, ..., two of them per step, so every B value loaded feeds four chains and B is streamed once
+// per four rows.  Few rows are flagged (a handful per pair), so the kernel is a latency chain, not a throughput problem:
+// sixteen wavefronts with two independent column streams each keep 4 x 8 times more loads in flight than the first version
+// (256 threads, one column at a time: 265 us for 396 rows of 56 pairs).
+constexpr uint32_t kExactThreads = 1024u, kExactWaves = kExactThreads / 64u;
+__global__ __launch_bounds__(1024) void desc_exact_rows_kernel(const ScreenPair* __restrict__ fwd, const ScreenPair* __restrict__ bwd, uint32_t n_pairs,
+                                                              const uint32_t* __restrict__ fb_fwd, const uint32_t* __restrict__ fb_bwd,
+                                                              const uint32_t* __restrict__ fb_count, RowBest* __restrict__ rowbest,
+                                                              unsigned long long* __restrict__ keys, uint32_t y_base) {
     __shared__ float arow[4][kD];
-    __shared__ float mb1[4][4], mb2[4][4];
-    __shared__ uint32_t mj1[4][4];
+    __shared__ float mb1[4][kExactWaves], mb2[4][kExactWaves];
+    __shared__ uint32_t mj1[4][kExactWaves];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const ScreenPair P = pairs[blockIdx.y];
-    const uint32_t total = fb_count[blockIdx.y];
-    for (uint32_t e = blockIdx.x * 4u; e < total; e += gridDim.x * 4u) {
+    const uint32_t y = blockIdx.y + y_base;      // [0, n_pairs): forward problem, [n_pairs, 2 n_pairs): the swapped one
+    const uint32_t as_keys = y >= n_pairs ? 1u : 0u;  // the swapped problem writes column-best keys
+    const ScreenPair P = as_keys ? bwd[y - n_pairs] : fwd[y];
+    const uint32_t* fb_list = as_keys ? fb_bwd : fb_fwd;
+    const uint32_t total = fb_count[y];  // forward counters, then backward
+    // Only the first one or two groups of a pair have rows.  Workgroups go to the eight XCDs round robin by linear id, so
+    // with group = blockIdx.x every pair's work landed on XCDs 0 and 1 (105 working groups on 64 CUs: 330 us); rotating the
+    // assignment by the pair index spreads them over the chip.
+    const uint32_t gx = (blockIdx.x + gridDim.x - y % gridDim.x) % gridDim.x;
+    for (uint32_t e = gx * 4u; e < total; e += gridDim.x * 4u) {
         uint32_t row[4];
         float nai[4], b1[4], b2[4];
         uint32_t j1[4];
@@ -557,24 +611,33 @@ __global__ __launch_bounds__(256) void desc_exact_rows_kernel(const ScreenPair* 
             if (tid < (uint32_t)kD) arow[q][tid] = P.arm[(size_t)row[q] * kD + tid];
         }
         __syncthreads();
-        for (uint32_t j = tid; j < P.n_b; j += 256u) {
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        for (uint32_t j = tid; j < P.n_b; j += 2u * kExactThreads) {
+            const uint32_t jb = j + kExactThreads;
+            const bool two = jb < P.n_b;
+            const uint32_t jbc = two ? jb : j;  // a lone last column is computed twice and used once
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
             for (int k = 0; k < kD; ++k) {
-                const float bv = P.bt[(size_t)k * P.n_b_pad + j];
-                s0 = fmaf(arow[0][k], bv, s0);
-                s1 = fmaf(arow[1][k], bv, s1);
-                s2 = fmaf(arow[2][k], bv, s2);
-                s3 = fmaf(arow[3][k], bv, s3);
-            }
-            const float nbj = P.nb[j];
-            const float sv[4] = {s0, s1, s2, s3};
+                const float bv = P.bt[(size_t)k * P.n_b_pad + j], bw = P.bt[(size_t)k * P.n_b_pad + jbc];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float d2 = (nai[q] + nbj) - 2.0f * sv[q];
+                for (int q = 0; q < 4; ++q) {
+                    s[q] = fmaf(arow[q][k], bv, s[q]);
+                    t[q] = fmaf(arow[q][k], bw, t[q]);
+                }
+            }
+            const float nbj = P.nb[j], nbk = P.nb[jbc];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // ascending columns: the first minimum keeps the lowest index
+                float d2 = (nai[q] + nbj) - 2.0f * s[q];
                 d2 = d2 > 0.0f ? d2 : 0.0f;
                 if (d2 < b1[q]) { b2[q] = b1[q]; b1[q] = d2; j1[q] = j; }
                 else if (d2 < b2[q]) { b2[q] = d2; }
+                float e2 = (nai[q] + nbk) - 2.0f * t[q];
+                e2 = e2 > 0.0f ? e2 : 0.0f;
+                if (two) {
+                    if (e2 < b1[q]) { b2[q] = b1[q]; b1[q] = e2; j1[q] = jb; }
+                    else if (e2 < b2[q]) { b2[q] = e2; }
+                }
             }
         }
 #pragma unroll
@@ -596,7 +659,7 @@ __global__ __launch_bounds__(256) void desc_exact_rows_kernel(const ScreenPair* 
         if (tid < 4u && e + tid < total) {
             float x1 = mb1[tid][0], x2 = mb2[tid][0];
             uint32_t xj = mj1[tid][0];
-            for (int ww = 1; ww < 4; ++ww) {
+            for (uint32_t ww = 1; ww < kExactWaves; ++ww) {
                 const float o1 = mb1[tid][ww], o2 = mb2[tid][ww];
                 const uint32_t oj = mj1[tid][ww];
                 const bool take = o1 < x1 || (o1 == x1 && oj < xj);
@@ -609,6 +672,45 @@ __global__ __launch_bounds__(256) void desc_exact_rows_kernel(const ScreenPair* 
             else { RowBest rb; rb.b1 = x1; rb.b2 = x2; rb.j1 = xj; rb.pad = 0u; rowbest[P.row_off + r] = rb; }
         }
     }
+}
+
+// Which columns does the mutual test look at?  Only the best column j1 of a row that passes the ratio test
+// (match_select_kernel reads colbest[j1] for nothing else), about a third of the columns on the bench and fewer on real
+// images -- so the column-wise direction screens and verifies only those.  One workgroup per pair: flags in LDS, then an
+// ordered compaction into row_list (ascending) and its length.
+__global__ __launch_bounds__(1024) void needed_columns_kernel(const MatchPair* __restrict__ pairs, const RowBest* __restrict__ rowbest,
+                                                              uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    extern __shared__ unsigned char need[];  // n_b_pad flags
+    __shared__ uint32_t wsum[16];
+    const MatchPair P = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (uint32_t j = tid; j < P.n_b_pad; j += 1024u) need[j] = 0;
+    __syncthreads();
+    if (P.n_a >= 2u && P.n_b >= 2u)
+        for (uint32_t i = tid; i < P.n_a; i += 1024u) {
+            const RowBest m = rowbest[P.row_off + i];
+            if ((double)sqrtf(m.b1) < 0.90 * (double)sqrtf(m.b2)) need[m.j1] = 1;  // the test of match_select_kernel
+        }
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < P.n_b_pad; j0 += 1024u) {  // n_b_pad is a multiple of 64: whole wavefronts
+        const uint32_t j = j0 + tid;
+        const bool on = j < P.n_b && need[j] != 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wsum[w] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t ww = 0; ww < 16u; ++ww) {
+            const uint32_t v = wsum[ww];
+            before += ww < w ? v : 0u;
+            all += v;
+        }
+        if (on) list[P.col_off + base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
+        base += all;
+        __syncthreads();
+    }
+    if (tid == 0) count[blockIdx.x] = base;
 }
 
 __global__ __launch_bounds__(256) void desc_round_f16_kernel(const float* __restrict__ desc, uint32_t n, uint32_t n_pad,
@@ -1106,17 +1208,35 @@ int pgi_desc_prepare_screen(pgi_ctx* ctx, const float* d_desc, uint32_t n, float
 static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_desc_view* h_dst, uint32_t n_pairs, uint32_t max_matches,
                           uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio, uint32_t* d_counts) {
     constexpr uint32_t NWS = PGI_SCREEN_WAVES, kRowsWg = NWS * 32u;
-    std::vector<MatchPair> hp(n_pairs);
-    std::vector<ScreenPair> fwd(n_pairs), bwd(n_pairs);
+    // the three pair tables are built in a page-locked block that mirrors their place in the workspace: one asynchronous
+    // copy, no wait (three copies out of local vectors plus the synchronisation they need cost 0.1 ms per call)
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_hp = 0, o_fwd = o_hp + up(n_pairs * sizeof(MatchPair)), o_bwd = o_fwd + up(n_pairs * sizeof(ScreenPair)),
+                 o_sf = o_bwd + up(n_pairs * sizeof(ScreenPair));
+    // (two blocks in turn: the copy of a call is queued behind the previous call's kernels, so waiting for the block used
+    // last time would make the host wait for the GPU on every call)
+    const int sb_i = ctx->match_stage_next;
+    ctx->match_stage_next ^= 1;
+    if (ctx->match_stage_ev[sb_i]) HIP_TRY(hipEventSynchronize(ctx->match_stage_ev[sb_i]));  // the copy out of this block, two calls ago
+    if (o_sf > ctx->match_stage_bytes[sb_i]) {
+        if (ctx->h_match_stage[sb_i]) (void)hipHostFree(ctx->h_match_stage[sb_i]);
+        ctx->h_match_stage[sb_i] = nullptr; ctx->match_stage_bytes[sb_i] = 0;
+        HIP_TRY(hipHostMalloc(&ctx->h_match_stage[sb_i], o_sf + o_sf / 2, hipHostMallocDefault));
+        ctx->match_stage_bytes[sb_i] = o_sf + o_sf / 2;
+    }
+    if (!ctx->match_stage_ev[sb_i]) HIP_TRY(hipEventCreateWithFlags(&ctx->match_stage_ev[sb_i], hipEventDisableTiming));
+    char* hst = (char*)ctx->h_match_stage[sb_i];
+    MatchPair* hp = reinterpret_cast<MatchPair*>(hst + o_hp);
+    ScreenPair *fwd = reinterpret_cast<ScreenPair*>(hst + o_fwd), *bwd = reinterpret_cast<ScreenPair*>(hst + o_bwd);
     uint64_t rows_total = 0, cols_total = 0, rb_f = 0, rb_b = 0;
     uint32_t max_rb_f = 0, max_rb_b = 0, min_tiles_f = ~0u, min_tiles_b = ~0u, max_na = 0, max_nb = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
         const pgi_desc_view &a = h_src[p], &b = h_dst[p];
         hp[p] = MatchPair{a.d_desc_t, a.d_norm, b.d_desc_t, b.d_norm, a.n, a.n_pad, b.n, b.n_pad, rows_total, cols_total};
         fwd[p] = ScreenPair{a.d_desc_f16, b.d_desc_f16, a.d_desc_rm, b.d_desc_rm, a.d_desc_t, b.d_desc_t, a.d_norm, b.d_norm,
-                            a.n, a.n_pad, b.n, b.n_pad, rows_total};
+                            a.n, a.n_pad, b.n, b.n_pad, rows_total, nullptr, nullptr};
         bwd[p] = ScreenPair{b.d_desc_f16, a.d_desc_f16, b.d_desc_rm, a.d_desc_rm, b.d_desc_t, a.d_desc_t, b.d_norm, a.d_norm,
-                            b.n, b.n_pad, a.n, a.n_pad, cols_total};
+                            b.n, b.n_pad, a.n, a.n_pad, cols_total, nullptr, nullptr};  // (row list: filled in below)
         if (a.n && b.n) {
             rb_f += a.n_pad / kRowsWg; rb_b += b.n_pad / kRowsWg;
             max_rb_f = std::max(max_rb_f, a.n_pad / kRowsWg); max_rb_b = std::max(max_rb_b, b.n_pad / kRowsWg);
@@ -1132,13 +1252,16 @@ static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_de
         if (min_tiles != ~0u && s > min_tiles) s = min_tiles;
         return s < 1 ? 1u : s;
     };
+    // The column-wise direction only looks at the columns the mutual test will ask about (needed_columns_kernel).  Its
+    // splits are chosen as for the full problem: splitting further to make up for the missing row blocks cost more in
+    // candidate lists than it gained in balance (2.82 ms against 2.56 ms).  PGI_MATCH_RESTRICT=0: every column (experiments).
+    static const bool restrict_cols = [] { const char* e = getenv("PGI_MATCH_RESTRICT"); return !(e && e[0] == '0'); }();
     const uint32_t sf = pick_splits(rb_f, min_tiles_f), sb = pick_splits(rb_b, min_tiles_b);
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t o_hp = 0, o_fwd = o_hp + up(n_pairs * sizeof(MatchPair)), o_bwd = o_fwd + up(n_pairs * sizeof(ScreenPair)),
-                 o_sf = o_bwd + up(n_pairs * sizeof(ScreenPair)), o_sb = o_sf + up((size_t)rows_total * sf * sizeof(ScreenRow)),
+    const size_t o_sb = o_sf + up((size_t)rows_total * sf * sizeof(ScreenRow)),
                  o_rows = o_sb + up((size_t)cols_total * sb * sizeof(ScreenRow)), o_keys = o_rows + up((size_t)rows_total * sizeof(RowBest)),
                  o_fb = o_keys + up((size_t)cols_total * 8), o_cnt = o_fb + up((size_t)(rows_total + cols_total) * sizeof(uint32_t)),
-                 bytes = o_cnt + up((size_t)2 * n_pairs * sizeof(uint32_t)) + 256;
+                 o_list = o_cnt + up((size_t)2 * n_pairs * sizeof(uint32_t)), o_lcnt = o_list + up((size_t)cols_total * sizeof(uint32_t)),
+                 bytes = o_lcnt + up((size_t)n_pairs * sizeof(uint32_t)) + 256;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -1159,12 +1282,16 @@ static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_de
     uint32_t* d_cnt = (uint32_t*)(ws + o_cnt);
     ctx->d_match_cnt = d_cnt;
     ctx->match_cnt_pairs = n_pairs;
-    HIP_TRY(hipMemcpyAsync(d_hp, hp.data(), n_pairs * sizeof(MatchPair), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_fwd, fwd.data(), n_pairs * sizeof(ScreenPair), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_bwd, bwd.data(), n_pairs * sizeof(ScreenPair), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors are local buffers
+    uint32_t* d_list = (uint32_t*)(ws + o_list);
+    uint32_t* d_lcnt = (uint32_t*)(ws + o_lcnt);
+    if (restrict_cols)
+        for (uint32_t p = 0; p < n_pairs; ++p) { bwd[p].row_list = d_list; bwd[p].row_count = d_lcnt + p; }
+    HIP_TRY(hipMemcpyAsync(ws + o_hp, hst, o_sf, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->match_stage_ev[sb_i], ctx->stream));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)2 * n_pairs * sizeof(uint32_t), ctx->stream));
     if (cols_total) HIP_TRY(hipMemsetAsync(d_keys, 0xFF, (size_t)cols_total * 8, ctx->stream));  // columns of empty pairs stay "no best"
+    // (Running the forward direction's verification and re-scan on a second stream underneath the backward screen was tried:
+    // the screen slowed down by as much as the small kernels took, 3.57 ms against 3.66 ms -- they compete for the same L2.)
     auto direction = [&](const ScreenPair* d_pairs, ScreenRow* d_scr, uint32_t splits, uint32_t max_rb, uint64_t stride, uint32_t max_rows,
                          uint32_t as_keys, uint32_t* fb, uint32_t* cnt) {
         if (max_rb == 0) return;
@@ -1177,11 +1304,22 @@ static int match_screened(pgi_ctx* ctx, const pgi_desc_view* h_src, const pgi_de
                                per_pair, stride);
         hipLaunchKernelGGL(desc_verify_kernel, dim3((max_rows + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_scr, splits, stride,
                            max_rows, d_rows, d_keys, as_keys, fb, cnt);
-        hipLaunchKernelGGL(desc_exact_rows_kernel, dim3(n_pairs < 16 ? 64 : 16, n_pairs), dim3(256), 0, ctx->stream, d_pairs, fb, cnt, d_rows,
-                           d_keys, as_keys);
+    };
+    // exact re-scan of the flagged rows: y in [0, n_pairs) is the forward problem, [n_pairs, 2 n_pairs) the swapped one
+    auto rescan = [&](uint32_t y_base, uint32_t ny) {
+        hipLaunchKernelGGL(desc_exact_rows_kernel, dim3(n_pairs < 16 ? 64 : 16, ny), dim3(kExactThreads), 0, ctx->stream, d_fwd, d_bwd, n_pairs, d_fb,
+                           d_fb + rows_total, d_cnt, d_rows, d_keys, y_base);
     };
     direction(d_fwd, d_sf, sf, max_rb_f, rows_total, max_na, 0u, d_fb, d_cnt);
-    direction(d_bwd, d_sb, sb, max_rb_b, cols_total, max_nb, 1u, d_fb + rows_total, d_cnt + n_pairs);
+    if (restrict_cols && max_rb_f && max_rb_b) {
+        rescan(0u, n_pairs);  // the rows' results are final: which columns will the mutual test read?
+        hipLaunchKernelGGL(needed_columns_kernel, dim3(n_pairs), dim3(1024), (size_t)pgi_desc_padded(max_nb), ctx->stream, d_hp, d_rows, d_list, d_lcnt);
+        direction(d_bwd, d_sb, sb, max_rb_b, cols_total, max_nb, 1u, d_fb + rows_total, d_cnt + n_pairs);
+        rescan(n_pairs, n_pairs);
+    } else {
+        direction(d_bwd, d_sb, sb, max_rb_b, cols_total, max_nb, 1u, d_fb + rows_total, d_cnt + n_pairs);
+        if (max_rb_f || max_rb_b) rescan(0u, 2 * n_pairs);  // both directions in one launch
+    }
     HIP_TRY(hipGetLastError());
     uint32_t np = 2;
     while (np < max_na) np <<= 1;

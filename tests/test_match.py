@@ -88,6 +88,20 @@ def test_gpu_match_tiny_and_empty_sets(eng):
 
 
 @pytest.mark.gpu
+def test_gpu_match_restricted_column_pass_extremes(eng):
+    """The column-wise direction only visits the columns some ratio-passing row points at.  One batch with the extremes:
+    unrelated sets (hardly a row passes: a list of a few columns), an image against itself (every column listed, several row blocks), a
+    permuted copy, and ordinary overlap -- with list lengths that are not multiples of the 256-row block."""
+    rng = np.random.default_rng(12)
+    R1 = np.abs(rng.standard_normal((700, 128))).astype(np.float32)
+    R2 = np.abs(rng.standard_normal((900, 128))).astype(np.float32)
+    A, B, _ = S.make_descriptors(rng, 1100, 1000, overlap=0.4)
+    Ap = A[rng.permutation(len(A))]
+    got = _check(eng, [R1, R2, A, B, Ap], [(0, 1), (2, 2), (2, 4), (4, 2), (2, 3), (3, 2), (1, 0), (0, 3)])
+    assert len(got[0][0]) <= 3 and len(got[1][0]) == len(A) and len(got[2][0]) == len(A)
+
+
+@pytest.mark.gpu
 def test_gpu_match_full_size_properties(eng):
     """SIFT-sized sets (8000 keypoints, the reference's -maxkp default region): size-independent properties --
     sortedness, injectivity (mutual best), symmetry of the matched set under swapping the images, and agreement
