@@ -569,16 +569,19 @@ __global__ void trk_offsets_kernel(const uint32_t* sorted, uint32_t n, uint32_t 
 }
 
 // (7) getCorrespondences (point_track.h:568-631): one workgroup per query walks the destination view's track list
-__global__ void __launch_bounds__(NT) trk_get_kernel(const uint32_t* q_src, const uint32_t* q_dst, uint32_t n_views, const uint32_t* view_begin,
+// (1024 lanes: a wave of queries is a few dozen workgroups, each a chain of dependent loads per list chunk -- the wider the
+// chunk, the shorter the chain: 128 queries of scripts/tracklets_bench.py 0.98 -> 0.62 ms against 256 lanes)
+constexpr int kGetThreads = 1024;
+__global__ void __launch_bounds__(kGetThreads) trk_get_kernel(const uint32_t* q_src, const uint32_t* q_dst, uint32_t n_views, const uint32_t* view_begin,
                                                      const uint32_t* view_track, const uint32_t* trk_begin, const uint64_t* mem_key,
                                                      uint32_t limit, uint32_t out_stride, uint32_t* out_src, uint32_t* out_dst,
                                                      uint32_t* out_cnt) {
-    __shared__ uint32_t wt[NT / 64 + 1];
+    __shared__ uint32_t wt[kGetThreads / 64 + 1];
     const uint32_t q = blockIdx.x, vs = q_src[q], vd = q_dst[q];
     uint32_t base = 0;
     if (vs < n_views && vd < n_views) {
         const uint32_t b = view_begin[vd], e = view_begin[vd + 1];
-        for (uint32_t c = b; c < e && base < limit; c += NT) {
+        for (uint32_t c = b; c < e && base < limit; c += kGetThreads) {
             const uint32_t i = c + threadIdx.x;
             bool touches = false;
             uint32_t ps = 0, pd = 0;
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(NT) trk_get_kernel(const uint32_t* q_src, cons
                 }
             }
             uint32_t total;
-            const uint32_t r = base + block_rank(touches, wt, total);
+            const uint32_t r = base + block_rank<kGetThreads / 64>(touches, wt, total);
             if (touches && r < limit) {
                 out_src[(size_t)q * out_stride + r] = ps;
                 out_dst[(size_t)q * out_stride + r] = pd;
@@ -964,7 +967,7 @@ int pgi_tracklets_get_batch(pgi_tracklets* t, const uint32_t* h_view_src, const 
     uint32_t* dq = t->pair_off.as<uint32_t>();
     TRK_TRY(hipMemcpyAsync(dq, h_view_src, (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
     TRK_TRY(hipMemcpyAsync(dq + n_queries, h_view_dst, (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(trk_get_kernel, dim3(n_queries), dim3(NT), 0, s, dq, dq + n_queries, t->n_views, t->view_begin.as<uint32_t>(),
+    hipLaunchKernelGGL(trk_get_kernel, dim3(n_queries), dim3(kGetThreads), 0, s, dq, dq + n_queries, t->n_views, t->view_begin.as<uint32_t>(),
                        t->view_track[t->cur].as<uint32_t>(), t->trk_begin.as<uint32_t>(), t->mem_key[t->cur].as<uint64_t>(), (uint32_t)limit, out_stride, d_src_idx,
                        d_dst_idx, d_count);
     TRK_TRY(hipGetLastError());
