@@ -960,9 +960,8 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
                                                                  const uint32_t* __restrict__ dst_order, const double* __restrict__ dst_rec,
                                                                  const uint32_t* __restrict__ starts, const uint32_t* __restrict__ chunk_start,
                                                                  int32_t* __restrict__ best_out, double* __restrict__ ratio_out) {
-    __shared__ double rec[kGmTile][4];
-    __shared__ uint32_t recj[kGmTile];
-    __shared__ uint32_t list[kGmList][256];
+    __shared__ float4 recf[kGmTile];  // the epipolar-line records rounded to f32: the cheap first look below
+    __shared__ uint32_t list[kGmList][256];  // positions (in the bin-sorted destination order) that survived it
     __shared__ uint32_t s_bin;
     const GuidedPair P = pairs[blockIdx.y];
     const uint32_t tid = threadIdx.x, bins = (uint32_t)P.bins;
@@ -985,6 +984,7 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
     const double rx = (P.F[0] * x1 + P.F[1] * y1) + P.F[2];
     const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
     const double b1 = rx * rx + ry * ry;
+    const float x1f = (float)x1, y1f = (float)y1, b1f = (float)b1;  // (x1, y1 are f32 values: exact)
     double best = DBL_MAX, second = DBL_MAX;
     int32_t best_index = -1;
     uint32_t count = 0, nlist = 0;
@@ -994,8 +994,21 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)longest, m); longest = o > longest ? o : longest; }
         for (uint32_t c = 0; c < longest; ++c) {
-            if (c < nlist) {
-                const uint32_t j = list[c][tid];
+            bool cand = false;
+            uint32_t j = 0;
+            if (c < nlist) {  // the exact gate (matcher.h:286-301 as restated in the oracle), on the survivors only
+                const uint32_t pos = list[c][tid];
+                const double* o = dst_rec + 4 * (P.off2 + pos);
+                const double rxc = o[0], ryc = o[1], rwc = o[2], a1 = o[3];
+                const double r = (x1 * rxc + y1 * ryc) + rwc;
+                const double num = (r * r) * (a1 + b1), den = a1 * b1;
+                const bool surely_far = den > 0.0 && num >= 0.57 * den;
+                if (!surely_far) {
+                    const double dist = num / den;
+                    if (!(dist >= 0.75 * 0.75)) { cand = true; j = dst_order[P.off2 + pos]; }
+                }
+            }
+            if (cand) {
                 const float4* brow = reinterpret_cast<const float4*>(P.d2 + (size_t)j * kD);
                 double dd = 0.0;
                 for (int k = 0; k < kD / 4; ++k) {
@@ -1018,19 +1031,25 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
         const uint32_t lim = d1e - j0 < (uint32_t)kGmTile ? d1e - j0 : (uint32_t)kGmTile;
         for (uint32_t jj = tid; jj < lim; jj += 256u) {
             const double* o = dst_rec + 4 * (P.off2 + j0 + jj);
-            rec[jj][0] = o[0]; rec[jj][1] = o[1]; rec[jj][2] = o[2]; rec[jj][3] = o[3];
-            recj[jj] = dst_order[P.off2 + j0 + jj];
+            recf[jj] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
         }
         __syncthreads();
         for (uint32_t jj = 0; jj < lim; ++jj) {
-            const double rxc = rec[jj][0], ryc = rec[jj][1], rwc = rec[jj][2], a1 = rec[jj][3];
-            const double r = (x1 * rxc + y1 * ryc) + rwc;
-            const double num = (r * r) * (a1 + b1), den = a1 * b1;
-            const bool surely_far = den > 0.0 && num >= 0.57 * den;
-            if (active && !surely_far) {
-                const double dist = num / den;
-                if (!(dist >= 0.75 * 0.75)) { list[nlist][tid] = recj[jj]; ++nlist; }
-            }
+            // First look in f32.  When the epipole lies outside the image nearly all keypoints share a few angular bins and a
+            // source keypoint meets thousands of destination ones here, almost all of them far from its epipolar line; the
+            // double-precision gate ran at half rate for every one of them.  With q the f32-rounded record,
+            // |rf - r| <= 5 * 2^-24 * S for S = |x1 rxc| + |y1 ryc| + |rwc| (three rounded inputs, two fused operations), so
+            // t = |rf| - 2^-20 S is a lower bound of |r| with a factor-three margin, and t^2 (a1 + b1) >= 0.60 a1 b1 in f32
+            // (relative error ~1e-6) implies r^2 (a1 + b1) >= 0.57 a1 b1 in f64 -- a pair the exact gate rejects.  NaN,
+            // infinity or an underflowing denominator make the comparison false: such a pair goes to the exact gate, which
+            // runs in flush() on the survivors (a few per cent), in the same order as before.
+            const float4 q = recf[jj];
+            const float rf = fmaf(x1f, q.x, fmaf(y1f, q.y, q.z));
+            const float sabs = fmaf(fabsf(x1f), fabsf(q.x), fmaf(fabsf(y1f), fabsf(q.y), fabsf(q.z)));
+            const float tl = fabsf(rf) - 9.5367431640625e-7f * sabs;
+            const float denf = q.w * b1f;
+            const bool far32 = tl > 0.0f && denf > 1.0e-30f && (tl * tl) * (q.w + b1f) >= 0.60f * denf;
+            if (active && !far32) { list[nlist][tid] = j0 + jj; ++nlist; }
             if (__any(nlist == (uint32_t)kGmList)) flush();
         }
     }
