@@ -45,7 +45,7 @@ def main():
     write_b = c["WRITE_SIZE"] * 1024
     wc = c["SQ_WAVE_CYCLES"]
     out = {
-        "kernel": "pgi::estimate_pose_kernel<2, false> (hybrid rows: 1344 in LDS, 656 from L2)", "pairs": 10000, "corrs": 2000,
+        "kernel": "pgi::estimate_pose_kernel<2, false> (hybrid rows: 1280 in LDS, 720 from L2)", "pairs": 10000, "corrs": 2000,
         "source": "rocprofv3 --kernel-trace --pmc ... (separate passes, scripts/profile_k1_r02.sh); sums / dispatches; "
                   "summaries in profiles/r02_k1_rocprofv3_summary.txt",
         "kernel_us_trace_avg": avg_us, "dispatches": calls,

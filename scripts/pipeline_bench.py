@@ -28,6 +28,8 @@ with tempfile.TemporaryDirectory() as d:
     print("views %d, keypoints/view ~%d, pairs %d, wave %d" % (V, np.mean([len(v["xy"]) for v in views]), len(pairs), wave))
     r = subprocess.run([os.path.join(ROOT, "pose-graph-initialization_amd", "test_pipeline"), fin, fout], capture_output=True, text=True)
     print(r.stdout, r.stderr[-6000:])
+    if os.environ.get("PGI_PIPELINE_STDERR"):  # the driver's full stderr (e.g. with PGI_TRACKLETS_TIMING=1)
+        open(os.environ["PGI_PIPELINE_STDERR"], "w").write(r.stderr)
     # the tracklet store in HBM (mode 2) and the host store (mode 3) must give the same graph, counter for counter
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_feature_pipeline import parse
