@@ -378,19 +378,23 @@ def main():
             calls.append((a_, b_, (torch.as_tensor(perm[a_][vis].astype(np.int32)).to(eng.device), torch.as_tensor(dd.astype(np.int32)).to(eng.device)),
                           torch.as_tensor(mk).to(eng.device)))
             n_match += int(mk.sum())
-        for rep in range(2):  # first pass warms buffers and code objects
+        trk_times = []
+        for rep in range(4):  # first pass warms buffers and code objects
             trk = DeviceTracklets(eng, Vt)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             trk.add_batch(calls)
             torch.cuda.synchronize()
             t_trk = time.perf_counter() - t0
+            trk_times.append(t_trk)
             info_t = trk.info()
             t0 = time.perf_counter()
             qres = trk.get_correspondences_batch([(c_[0], c_[1]) for c_ in calls], 5000, raw=True)
             torch.cuda.synchronize()
             t_q = time.perf_counter() - t0
             trk.close()
+        print("tracklets add (s):", ["%.4f" % v for v in trk_times], file=sys.stderr)
+        t_trk = float(np.median(trk_times[1:]))
         out["tracklets"] = {"pairs": len(calls), "inlier_matches": n_match, "add_ms": round(1e3 * t_trk, 2),
                             "ns_per_match": round(1e9 * t_trk / n_match, 1), "tracks": info_t["tracks"], "events": info_t["events"],
                             "round_launches": info_t["rounds"], "query_ms": round(1e3 * t_q, 2),
