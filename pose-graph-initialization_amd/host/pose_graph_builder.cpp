@@ -28,6 +28,45 @@ struct DevBuf {
         return static_cast<T*>(p);
     }
 };
+// Device memory of one processFeatures wave: blocks handed out by bumping an offset and recycled at the start of the next
+// wave (two dozen hipMalloc / hipFree pairs per wave cost more than most of the wave's kernels).
+struct DevPool {
+    std::vector<std::pair<void*, size_t>> blocks;
+    size_t used = 0;  // within the last block
+    ~DevPool() { for (auto& b : blocks) (void)hipFree(b.first); }
+    void* take(size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        if (blocks.empty() || used + bytes > blocks.back().second) {
+            const size_t nb = std::max(bytes, blocks.empty() ? (size_t)16 << 20 : 2 * blocks.back().second);
+            void* q = nullptr;
+            if (hipMalloc(&q, nb) != hipSuccess) throw PgiError("hipMalloc failed");
+            blocks.emplace_back(q, nb);
+            used = 0;
+        }
+        void* r = static_cast<char*>(blocks.back().first) + used;
+        used += bytes;
+        return r;
+    }
+    void reset() {  // the device must be idle on these blocks
+        if (blocks.size() > 1) {  // one block of the combined size from now on
+            size_t total = 0;
+            for (auto& b : blocks) { total += b.second; (void)hipFree(b.first); }
+            blocks.clear();
+            void* q = nullptr;
+            if (hipMalloc(&q, total) != hipSuccess) throw PgiError("hipMalloc failed");
+            blocks.emplace_back(q, total);
+        }
+        used = 0;
+    }
+};
+struct WaveBuf {  // DevBuf's interface over pool memory
+    void* p;
+    WaveBuf(DevPool& pool, size_t bytes) : p(pool.take(bytes)) {}
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
 void h2d(void* d, const void* h, size_t n) {
     if (n && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) throw PgiError("hipMemcpy H2D failed");
 }
@@ -409,27 +448,42 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     // features resident in HBM for the whole run: keypoints, row-major descriptors (guided matching) and the
     // transposed copy + norms (brute-force matching)
     const size_t V = views.size();
-    std::vector<std::unique_ptr<DevBuf>> dxy(V), ddesc(V), ddt(V), dnorm(V), drm(V), df16(V);
+    // (one device block for all views: six allocations per view cost more than the uploads -- a quarter of a 40-view run)
     std::vector<pgi_desc_view> descView(V);
     std::vector<pgi_keypoint_view> kpView(V);
     std::vector<pgi_feature_view> featView(V);
+    struct ViewLayout { size_t xy, desc, dt, norm, rm, f16; };
+    std::vector<ViewLayout> lay(V);
+    size_t arenaBytes = 0;
+    auto take = [&](size_t bytes) { const size_t o = arenaBytes; arenaBytes += (bytes + 255) & ~(size_t)255; return o; };
     for (size_t v = 0; v < V; ++v) {
         const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
         if (views[v].descriptors.size() != (size_t)n * PGI_DESC_DIM) throw PgiError("processFeatures: descriptors must be n x 128");
-        dxy[v].reset(new DevBuf((size_t)n * 8));
-        ddesc[v].reset(new DevBuf((size_t)n * PGI_DESC_DIM * 4));
-        ddt[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 4));
-        dnorm[v].reset(new DevBuf((size_t)n_pad * 4));
-        h2d(dxy[v]->p, views[v].keypoints.data(), (size_t)n * 8);
-        h2d(ddesc[v]->p, views[v].descriptors.data(), (size_t)n * PGI_DESC_DIM * 4);
-        drm[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 4));
-        df16[v].reset(new DevBuf((size_t)n_pad * PGI_DESC_DIM * 2));
-        Engine::check(pgi_desc_prepare(ctx, ddesc[v]->as<float>(), n, ddt[v]->as<float>(), dnorm[v]->as<float>()));
-        Engine::check(pgi_desc_prepare_screen(ctx, ddesc[v]->as<float>(), n, drm[v]->as<float>(), df16[v]->as<uint16_t>()));
+        lay[v].xy = take((size_t)n * 8);
+        lay[v].desc = take((size_t)n * PGI_DESC_DIM * 4);
+        lay[v].dt = take((size_t)n_pad * PGI_DESC_DIM * 4);
+        lay[v].norm = take((size_t)n_pad * 4);
+        lay[v].rm = take((size_t)n_pad * PGI_DESC_DIM * 4);
+        lay[v].f16 = take((size_t)n_pad * PGI_DESC_DIM * 2);
+    }
+    DevBuf arena(std::max<size_t>(arenaBytes, 256));
+    char* const ab = arena.as<char>();
+    for (size_t v = 0; v < V; ++v) {
+        const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
+        float* xy = reinterpret_cast<float*>(ab + lay[v].xy);
+        float* desc = reinterpret_cast<float*>(ab + lay[v].desc);
+        float* dt = reinterpret_cast<float*>(ab + lay[v].dt);
+        float* norm = reinterpret_cast<float*>(ab + lay[v].norm);
+        float* rm = reinterpret_cast<float*>(ab + lay[v].rm);
+        uint16_t* f16 = reinterpret_cast<uint16_t*>(ab + lay[v].f16);
+        h2d(xy, views[v].keypoints.data(), (size_t)n * 8);
+        h2d(desc, views[v].descriptors.data(), (size_t)n * PGI_DESC_DIM * 4);
+        Engine::check(pgi_desc_prepare(ctx, desc, n, dt, norm));
+        Engine::check(pgi_desc_prepare_screen(ctx, desc, n, rm, f16));
         const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
-        descView[v] = pgi_desc_view{ddt[v]->as<float>(), dnorm[v]->as<float>(), n, n_pad, drm[v]->as<float>(), df16[v]->as<uint16_t>()};
-        kpView[v] = pgi_keypoint_view{dxy[v]->as<float>(), n, 0, f, f, cx, cy};
-        featView[v] = pgi_feature_view{dxy[v]->as<float>(), ddesc[v]->as<float>(), n, 0, f, f, cx, cy, views[v].width, views[v].height};
+        descView[v] = pgi_desc_view{dt, norm, n, n_pad, rm, f16};
+        kpView[v] = pgi_keypoint_view{xy, n, 0, f, f, cx, cy};
+        featView[v] = pgi_feature_view{xy, desc, n, 0, f, f, cx, cy, views[v].width, views[v].height};
     }
     std::stable_sort(cand.begin(), cand.end(), [](const CandidatePair& a, const CandidatePair& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
@@ -453,9 +507,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
 
     typedef std::chrono::steady_clock Clock;
     auto since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
+    DevPool pool;
     auto processWave = [&](const std::vector<CandidatePair>& wave) {
         const size_t P = wave.size();
         if (!P) return;
+        Engine::check(pgi_synchronize(ctx));  // the previous wave's kernels are done with the pool
+        pool.reset();
         Clock::time_point tick = Clock::now();
         // (1) quick matching from tracklets for pairs the graph already connects (:493-518)
         std::vector<Matches> matches(P);
@@ -466,16 +523,16 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         const uint32_t qstride = (uint32_t)kMaximumTrackletNumber + 1;
         std::vector<size_t> queryOf(P, (size_t)-1);
         std::vector<uint32_t> qcnt;
-        std::unique_ptr<DevBuf> qsrc, qdst, qcntDev;
+        std::unique_ptr<WaveBuf> qsrc, qdst, qcntDev;
         if (deviceTracks) {
             std::vector<uint32_t> qs, qd;
             for (size_t i = 0; i < P; ++i)
                 if (visible[i]) { queryOf[i] = qs.size(); qs.push_back((uint32_t)wave[i].src); qd.push_back((uint32_t)wave[i].dst); }
             if (!qs.empty()) {
                 const size_t Q = qs.size();
-                qsrc.reset(new DevBuf(Q * (size_t)qstride * 4));
-                qdst.reset(new DevBuf(Q * (size_t)qstride * 4));
-                qcntDev.reset(new DevBuf(Q * 4));
+                qsrc.reset(new WaveBuf(pool, Q * (size_t)qstride * 4));
+                qdst.reset(new WaveBuf(pool, Q * (size_t)qstride * 4));
+                qcntDev.reset(new WaveBuf(pool, Q * 4));
                 Engine::check(pgi_tracklets_get_batch(store.t, qs.data(), qd.data(), (uint32_t)Q, (uint32_t)kMaximumTrackletNumber, qstride,
                                                       qsrc->as<uint32_t>(), qdst->as<uint32_t>(), qcntDev->as<uint32_t>()));
                 Engine::check(pgi_synchronize(ctx));
@@ -519,7 +576,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             const size_t i = order[k];
             mm = std::max(mm, fromHost[i] ? (uint32_t)matchCount[i] : (uint32_t)views[wave[i].src].size());
         }
-        DevBuf dsrc(P * (size_t)mm * 4), ddst(P * (size_t)mm * 4), dratio(P * (size_t)mm * 8), dcnt(P * 4);
+        WaveBuf dsrc(pool, P * (size_t)mm * 4), ddst(pool, P * (size_t)mm * 4), dratio(pool, P * (size_t)mm * 8), dcnt(pool, P * 4);
         std::vector<uint32_t> hsrc(P * (size_t)mm), hdst(P * (size_t)mm), hcnt(P, 0);
         // (2) descriptor matching for the others, one launch sequence (:521-546)
         if (Pn) {
@@ -582,8 +639,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         std::vector<pgi_keypoint_view> ka(P), kb(P);
         for (size_t k = 0; k < P; ++k) { ka[k] = kpView[wave[order[k]].src]; kb[k] = kpView[wave[order[k]].dst]; }
         const size_t cap = P * (size_t)mm;
-        DevBuf dx1(cap * 4), dy1(cap * 4), dx2(cap * 4), dy2(cap * 4), doff((P + 1) * 8), dthr(P * 8), dguess(P * 96), dhas(P),
-            dedges(P * sizeof(pgi_edge)), dmasks(cap);
+        WaveBuf dx1(pool, cap * 4), dy1(pool, cap * 4), dx2(pool, cap * 4), dy2(pool, cap * 4), doff(pool, (P + 1) * 8), dthr(pool, P * 8),
+            dguess(pool, P * 96), dhas(pool, P), dedges(pool, P * sizeof(pgi_edge)), dmasks(pool, cap);
         Engine::check(pgi_build_correspondences(ctx, ka.data(), kb.data(), (uint32_t)P, mm, dsrc.as<uint32_t>(), ddst.as<uint32_t>(),
                                                 dcnt.as<uint32_t>(), 0, kInlierOutlierThreshold, 0, dx1.as<float>(), dy1.as<float>(),
                                                 dx2.as<float>(), dy2.as<float>(), doff.as<uint64_t>(), dthr.as<double>()));
@@ -647,7 +704,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 for (int c = 0; c < 9; ++c) Eg[9 * k + c] = E[c];
                 tau2[k] = (1.5 * thr[k]) * (1.5 * thr[k]);
             }
-            DevBuf dE(P * 72), dtau(P * 8), dscore(P * 4);
+            WaveBuf dE(pool, P * 72), dtau(pool, P * 8), dscore(pool, P * 4);
             h2d(dE.p, Eg.data(), P * 72);
             h2d(dtau.p, tau2.data(), P * 8);
             Engine::check(pgi_score_pose_batch(ctx, &b, dE.as<double>(), dtau.as<double>(), dscore.as<uint32_t>(), nullptr));
@@ -698,11 +755,11 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         const uint32_t gstride = (uint32_t)std::max<size_t>(1, kMaximumPointNumberForEpipolarHashing);
         constexpr uint32_t kEpipolarBins = 45;  // HashingBasedMatcherWithPose<false, 45> (pose_graph_builder.h:738)
         std::vector<uint32_t> gsrc, gdst, gcnt;
-        std::unique_ptr<DevBuf> ds, dd, dr, dc;
+        std::unique_ptr<WaveBuf> ds, dd, dr, dc;
         if (!guidedOf.empty()) {
             const size_t G = guidedOf.size();
-            ds.reset(new DevBuf(G * (size_t)gstride * 4)); dd.reset(new DevBuf(G * (size_t)gstride * 4));
-            dr.reset(new DevBuf(G * (size_t)gstride * 8)); dc.reset(new DevBuf(G * 4));
+            ds.reset(new WaveBuf(pool, G * (size_t)gstride * 4)); dd.reset(new WaveBuf(pool, G * (size_t)gstride * 4));
+            dr.reset(new WaveBuf(pool, G * (size_t)gstride * 8)); dc.reset(new WaveBuf(pool, G * 4));
             Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds->as<uint32_t>(),
                                                  dd->as<uint32_t>(), dr->as<double>(), dc->as<uint32_t>()));
             Engine::check(pgi_synchronize(ctx));
