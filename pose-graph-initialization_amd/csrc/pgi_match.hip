@@ -1072,10 +1072,9 @@ __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* _
                                                              uint32_t* __restrict__ cj, double* __restrict__ cr, uint32_t max_n,
                                                              uint32_t out_stride, uint32_t* __restrict__ out_src,
                                                              uint32_t* __restrict__ out_dst, double* __restrict__ out_ratio,
-                                                             uint32_t* __restrict__ out_count) {
+                                                             uint32_t* __restrict__ out_count, uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry;
-    __shared__ double tile[2048];  // ratios of the rank-by-counting pass, staged 2048 at a time
     const GuidedPair P = pairs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) carry = 0u;
@@ -1104,39 +1103,54 @@ __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* _
     __threadfence_block();
     __syncthreads();
     const size_t o = (size_t)blockIdx.x * out_stride;
+    if (tid == 0) kept_out[blockIdx.x] = m;
     if (max_n == 0u || m <= max_n) {
         const uint32_t lim = m < out_stride ? m : out_stride;
         for (uint32_t k = tid; k < lim; k += 1024u) { out_src[o + k] = ci[P.off + k]; out_dst[o + k] = cj[P.off + k]; out_ratio[o + k] = cr[P.off + k]; }
         if (tid == 0) out_count[blockIdx.x] = lim;
-    } else {
-        // rank by counting (ratio ascending, ties by position): every thread ranks its matches against tiles of ratios
-        // staged in LDS (the inner loop used to read them from global memory: 0.6 ms of the 0.7 ms this kernel took)
-        const uint32_t lim = max_n < out_stride ? max_n : out_stride;
-        for (uint32_t k0 = 0; k0 < m; k0 += 1024u) {  // uniform trip count: the tile loads need every thread
-            const uint32_t k = k0 + tid;
-            const double rk = k < m ? cr[P.off + k] : 0.0;
-            uint32_t rank = 0;
-            for (uint32_t q0 = 0; q0 < m; q0 += 2048u) {
-                __syncthreads();
-                for (uint32_t q = tid; q < 2048u && q0 + q < m; q += 1024u) tile[q] = cr[P.off + q0 + q];
-                __syncthreads();
-                const uint32_t qn = m - q0 < 2048u ? m - q0 : 2048u;
-                uint32_t q = 0;
-                for (; q + 8 <= qn; q += 8) {  // eight independent LDS reads in flight (one at a time is a latency chain)
-                    double rq[8];
+    } else if (tid == 0) {
+        out_count[blockIdx.x] = max_n < out_stride ? max_n : out_stride;  // guided_rank_kernel fills the rows
+    }
+}
+
+// More kept matches than the cut allows: rank by counting (ratio ascending, ties by position) and keep ranks below the cut.
+// grid (kRankSplit, pairs): a pair's matches are ranked 1024 at a time, each slice by its own workgroup -- one workgroup per
+// pair left three quarters of the chip idle while it walked through the slices (0.5 ms per wave of 64 pairs).
+constexpr uint32_t kRankSplit = 4;
+__global__ __launch_bounds__(1024) void guided_rank_kernel(const GuidedPair* __restrict__ pairs, const uint32_t* __restrict__ kept,
+                                                           const uint32_t* __restrict__ ci, const uint32_t* __restrict__ cj,
+                                                           const double* __restrict__ cr, uint32_t max_n, uint32_t out_stride,
+                                                           uint32_t* __restrict__ out_src, uint32_t* __restrict__ out_dst,
+                                                           double* __restrict__ out_ratio) {
+    __shared__ double tile[2048];  // ratios staged 2048 at a time
+    const GuidedPair P = pairs[blockIdx.y];
+    const uint32_t tid = threadIdx.x, m = kept[blockIdx.y];
+    if (max_n == 0u || m <= max_n) return;
+    const size_t o = (size_t)blockIdx.y * out_stride;
+    const uint32_t lim = max_n < out_stride ? max_n : out_stride;
+    for (uint32_t k0 = blockIdx.x * 1024u; k0 < m; k0 += gridDim.x * 1024u) {  // uniform trip count: the tile loads need every thread
+        const uint32_t k = k0 + tid;
+        const double rk = k < m ? cr[P.off + k] : 0.0;
+        uint32_t rank = 0;
+        for (uint32_t q0 = 0; q0 < m; q0 += 2048u) {
+            __syncthreads();
+            for (uint32_t q = tid; q < 2048u && q0 + q < m; q += 1024u) tile[q] = cr[P.off + q0 + q];
+            __syncthreads();
+            const uint32_t qn = m - q0 < 2048u ? m - q0 : 2048u;
+            uint32_t q = 0;
+            for (; q + 8 <= qn; q += 8) {  // eight independent LDS reads in flight (one at a time is a latency chain)
+                double rq[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) rq[u] = tile[q + u];
+                for (int u = 0; u < 8; ++u) rq[u] = tile[q + u];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) rank += (rq[u] < rk || (rq[u] == rk && q0 + q + (uint32_t)u < k)) ? 1u : 0u;
-                }
-                for (; q < qn; ++q) {
-                    const double rq = tile[q];
-                    rank += (rq < rk || (rq == rk && q0 + q < k)) ? 1u : 0u;
-                }
+                for (int u = 0; u < 8; ++u) rank += (rq[u] < rk || (rq[u] == rk && q0 + q + (uint32_t)u < k)) ? 1u : 0u;
             }
-            if (k < m && rank < lim) { out_src[o + rank] = ci[P.off + k]; out_dst[o + rank] = cj[P.off + k]; out_ratio[o + rank] = rk; }
+            for (; q < qn; ++q) {
+                const double rq = tile[q];
+                rank += (rq < rk || (rq == rk && q0 + q < k)) ? 1u : 0u;
+            }
         }
-        if (tid == 0) out_count[blockIdx.x] = lim;
+        if (k < m && rank < lim) { out_src[o + rank] = ci[P.off + k]; out_dst[o + rank] = cj[P.off + k]; out_ratio[o + rank] = rk; }
     }
 }
 
@@ -1605,7 +1619,8 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     const size_t so_bytes = bucketed ? ((size_t)total * 4 + 255) / 256 * 256 : 0, do_bytes = bucketed ? ((size_t)total2 * 4 + 255) / 256 * 256 : 0,
                  rec_bytes = bucketed ? ((size_t)total2 * 32 + 255) / 256 * 256 : 0,
                  st_bytes = bucketed ? ((size_t)n_pairs * 3 * (kGmMaxBuckets + 1) * 4 + 255) / 256 * 256 : 0;
-    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + 256;
+    const size_t kept_bytes = ((size_t)n_pairs * 4 + 255) / 256 * 256;
+    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + 256;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -1642,8 +1657,12 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         hipLaunchKernelGGL(guided_scan_kernel, dim3((max_n1 + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, d_pairs, d_best, d_rat);
         HIP_TRY(hipGetLastError());
     }
+    uint32_t* d_kept = (uint32_t*)(ws + pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes);
     hipLaunchKernelGGL(guided_select_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_best, d_rat, d_ci, d_cj, d_cr, max_n,
-                       out_stride, d_match_src, d_match_dst, d_ratio, d_counts);
+                       out_stride, d_match_src, d_match_dst, d_ratio, d_counts, d_kept);
+    if (max_n != 0u)  // pairs with more kept matches than the cut: rank them
+        hipLaunchKernelGGL(guided_rank_kernel, dim3(kRankSplit, n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_kept, d_ci, d_cj, d_cr, max_n,
+                           out_stride, d_match_src, d_match_dst, d_ratio);
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
 }
