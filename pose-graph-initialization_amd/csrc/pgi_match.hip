@@ -1040,15 +1040,16 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
             // double-precision gate ran at half rate for every one of them.  With q the f32-rounded record,
             // |rf - r| <= 5 * 2^-24 * S for S = |x1 rxc| + |y1 ryc| + |rwc| (three rounded inputs, two fused operations), so
             // t = |rf| - 2^-20 S is a lower bound of |r| with a factor-three margin, and t^2 (a1 + b1) >= 0.60 a1 b1 in f32
-            // (relative error ~1e-6) implies r^2 (a1 + b1) >= 0.57 a1 b1 in f64 -- a pair the exact gate rejects.  NaN,
-            // infinity or an underflowing denominator make the comparison false: such a pair goes to the exact gate, which
+            // (relative error ~1e-6) implies r^2 (a1 + b1) >= 0.57 a1 b1 in f64 -- a pair the exact gate rejects.  NaN, an
+            // overflowing sum or an underflowing denominator make the test false: such a pair goes to the exact gate, which
             // runs in flush() on the survivors (a few per cent), in the same order as before.
             const float4 q = recf[jj];
             const float rf = fmaf(x1f, q.x, fmaf(y1f, q.y, q.z));
             const float sabs = fmaf(fabsf(x1f), fabsf(q.x), fmaf(fabsf(y1f), fabsf(q.y), fabsf(q.z)));
             const float tl = fabsf(rf) - 9.5367431640625e-7f * sabs;
             const float denf = q.w * b1f;
-            const bool far32 = tl > 0.0f && denf > 1.0e-30f && (tl * tl) * (q.w + b1f) >= 0.60f * denf;
+            const float sumf = q.w + b1f;
+            const bool far32 = tl > 0.0f && denf > 1.0e-30f && denf < 1.0e30f && sumf < 1.0e30f && (tl * tl) * sumf >= 0.60f * denf;  // (finite right-hand side)
             if (active && !far32) { list[nlist][tid] = j0 + jj; ++nlist; }
             if (__any(nlist == (uint32_t)kGmList)) flush();
         }

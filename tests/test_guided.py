@@ -167,3 +167,36 @@ def test_gpu_guided_match_binned_equals_literal_restatement(eng, max_n):
     if not max_n:
         print("binned vs exhaustive kernel: %d of %d matches differ (%.2f %%)" % (differ, total, 100.0 * differ / max(total, 1)))
         assert 0 < differ < 0.05 * total
+
+
+@pytest.mark.gpu
+def test_gpu_guided_match_binned_unusual_geometry(eng):
+    """The binned scan looks at every (source, destination) pair of a bin in f32 first and runs the exact gate only on the
+    survivors: the f32 look must never drop a pair the exact gate would pass.  Geometries that move the operands across
+    ranges -- image coordinates 40x larger and 20x smaller than usual (focal length and size scaled along), an epipole
+    inside the image (forward motion: bins evenly filled), and an almost pure rotation (tiny baseline: tiny epipolar
+    normals) -- against the literal restatement."""
+    views, poses, cam = scene(35, 2000, 2000)
+    cases = []
+    for scale in (40.0, 0.05):
+        vs = [dict(v, xy=(v["xy"] * np.float32(scale)).astype(np.float32)) for v in views]
+        cases.append((vs, (cam[0] * scale, cam[1] * scale, cam[2] * scale), [rel_pose(poses, 0, 1), rel_pose(poses, 1, 2)], [(0, 1), (1, 2)]))
+    fwd = (np.eye(3), np.array([0.02, -0.01, 1.0]))
+    tiny = (rel_pose(poses, 0, 2)[0], rel_pose(poses, 0, 2)[1] * 1e-6)
+    cases.append((views, cam, [fwd, tiny], [(0, 1), (0, 2)]))
+    checked = 0
+    for vs, cm, rts, pairs in cases:
+        feats = [eng.upload_features(v["xy"], v["desc"], *cm) for v in vs]
+        rt = np.array([np.r_[R.ravel(), t] for R, t in rts])
+        got = eng.guided_match_batch(feats, pairs, rt, max_n=0, n_bins=45)
+        for (s, d), (R, t), (gi, gj, gr) in zip(pairs, rts, got):
+            E = np.zeros(9)
+            O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+            k = [cm[0], cm[0], cm[1] / 2.0, cm[2] / 2.0]
+            F = O.fundamental_from_essential(E, k, k)
+            size = (int(cm[1]), int(cm[2]))
+            oi, oj, orr, frag = O.ref_guided_match_binned(F, vs[s]["xy"], vs[d]["xy"], vs[s]["desc"], vs[d]["desc"], size, size)
+            keep_o, keep_g = ~frag[oi].astype(bool), ~frag[gi].astype(bool)
+            assert np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o]), (cm, s, d)
+            checked += len(oi)
+    assert checked > 500
