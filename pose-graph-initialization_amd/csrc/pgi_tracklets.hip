@@ -96,6 +96,8 @@ struct pgi_tracklets {
     int cur = 0;                    // which half is current
     DevBuf trk_begin, view_begin;   // offsets: n_tracks + 1, n_views + 1
     DevBuf new_track, new_key;      // the running batch's events in sequential order
+    DevBuf iota;                    // 0, 1, 2, ... (value input of the index sorts)
+    DevBuf wide_in, wide_out;       // 32-bit keys widened for the 64-bit sort
     DevBuf state;                   // DeviceState
     // scratch
     DevBuf sort_tmp, a64, b64, a32, b32, c32, d32;
@@ -626,6 +628,11 @@ int bits_for(uint64_t n) {  // bits needed to hold values 0..n-1
 
 inline dim3 grid_for(size_t n, int block = NT) { return dim3((unsigned)((n + block - 1) / block)); }
 
+__global__ void trk_iota_kernel(uint32_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 // stable sort of (key, value) pairs by the low `bits` of the key
 template <class K>
 int sort_pairs(pgi_tracklets* t, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits, hipStream_t s) {
@@ -635,14 +642,36 @@ int sort_pairs(pgi_tracklets* t, const K* kin, K* kout, const uint32_t* vin, uin
     TRK_TRY(rocprim::radix_sort_pairs(t->sort_tmp.p, tmp, kin, kout, vin, vout, n, 0u, (unsigned)bits, s));
     return PGI_SUCCESS;
 }
+// 32-bit keys travel through the 64-bit sort (widened, then narrowed again): one instantiation of the library's sort kernels
+// instead of two -- they are most of this file's code object, whose load is paid by the first add of a process
+__global__ void trk_widen_kernel(const uint32_t* in, uint32_t n, uint64_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void trk_narrow_kernel(const uint64_t* in, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+int sort_pairs_u32(pgi_tracklets* t, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, int bits, hipStream_t s) {
+    if (!n) return PGI_SUCCESS;
+    TRK_TRY(t->wide_in.reserve(n * 8, s));
+    TRK_TRY(t->wide_out.reserve(n * 8, s));
+    hipLaunchKernelGGL(trk_widen_kernel, grid_for(n), dim3(NT), 0, s, kin, (uint32_t)n, t->wide_in.as<uint64_t>());
+    const int rc = sort_pairs<uint64_t>(t, t->wide_in.as<uint64_t>(), t->wide_out.as<uint64_t>(), vin, vout, n, bits, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(trk_narrow_kernel, grid_for(n), dim3(NT), 0, s, t->wide_out.as<uint64_t>(), (uint32_t)n, kout);
+    return PGI_SUCCESS;
+}
+
+// values = 0, 1, 2, ...: an explicit index array, so that this is the SAME library instantiation as sort_pairs (a counting
+// iterator as the value input is a second copy of every sort kernel: the code object of this file was 6.3 MB, and loading
+// it cost the first add of a process 17 ms)
 template <class K>
 int sort_pairs_iota(pgi_tracklets* t, const K* kin, K* kout, uint32_t* vout, size_t n, int bits, hipStream_t s) {
-    rocprim::counting_iterator<uint32_t> iota(0u);
-    size_t tmp = 0;
-    TRK_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, iota, vout, n, 0u, (unsigned)bits, s));
-    TRK_TRY(t->sort_tmp.reserve(tmp, s));
-    TRK_TRY(rocprim::radix_sort_pairs(t->sort_tmp.p, tmp, kin, kout, iota, vout, n, 0u, (unsigned)bits, s));
-    return PGI_SUCCESS;
+    TRK_TRY(t->iota.reserve(n * 4, s));
+    if (n) hipLaunchKernelGGL(trk_iota_kernel, grid_for(n), dim3(NT), 0, s, t->iota.as<uint32_t>(), (uint32_t)n);
+    if constexpr (sizeof(K) == 4) return sort_pairs_u32(t, kin, kout, t->iota.as<uint32_t>(), vout, n, bits, s);
+    else return sort_pairs<K>(t, kin, kout, t->iota.as<uint32_t>(), vout, n, bits, s);
 }
 int scan_u32(pgi_tracklets* t, const uint32_t* in, uint32_t* out, size_t n, bool inclusive, hipStream_t s) {
     size_t tmp = 0;
@@ -704,7 +733,7 @@ int merge_batch(pgi_tracklets* t, uint32_t n_new, hipStream_t s) {
         hipLaunchKernelGGL(trk_gather64_kernel, grid_for(n_new), dim3(NT), 0, s, t->b32.as<uint32_t>(), nk, n_new, t->mem_key[o].as<uint64_t>());
         if ((rc = sort_pairs<uint64_t>(t, nk, t->pt_key[o].as<uint64_t>(), nt, t->pt_track[o].as<uint32_t>(), n_new, 32 + bits_for(t->n_views), s))) return rc;
         hipLaunchKernelGGL(trk_views_of_kernel, grid_for(n_new), dim3(NT), 0, s, nk, n_new, t->d32.as<uint32_t>());
-        if ((rc = sort_pairs<uint32_t>(t, t->d32.as<uint32_t>(), t->view_id[o].as<uint32_t>(), nt, t->view_track[o].as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
+        if ((rc = sort_pairs_u32(t, t->d32.as<uint32_t>(), t->view_id[o].as<uint32_t>(), nt, t->view_track[o].as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
         hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_tracks + 1), dim3(NT), 0, s, t->trk_id[o].as<uint32_t>(), N1, t->n_tracks, t->trk_begin.as<uint32_t>());
         hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_views + 1), dim3(NT), 0, s, t->view_id[o].as<uint32_t>(), N1, t->n_views, t->view_begin.as<uint32_t>());
         TRK_TRY(hipGetLastError());
@@ -725,7 +754,7 @@ int merge_batch(pgi_tracklets* t, uint32_t n_new, hipStream_t s) {
                        t->b64.as<uint64_t>(), t->c32.as<uint32_t>(), n_new, t->pt_key[o].as<uint64_t>(), t->pt_track[o].as<uint32_t>());
     // by view: (view id, track)
     hipLaunchKernelGGL(trk_views_of_kernel, grid_for(n_new), dim3(NT), 0, s, nk, n_new, t->d32.as<uint32_t>());
-    if ((rc = sort_pairs<uint32_t>(t, t->d32.as<uint32_t>(), t->a32.as<uint32_t>(), nt, t->b32.as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
+    if ((rc = sort_pairs_u32(t, t->d32.as<uint32_t>(), t->a32.as<uint32_t>(), nt, t->b32.as<uint32_t>(), n_new, bits_for(t->n_views), s))) return rc;
     hipLaunchKernelGGL((trk_merge_kernel<uint32_t, uint32_t>), grid_for(N1), dim3(NT), 0, s, t->view_id[c].as<uint32_t>(), t->view_track[c].as<uint32_t>(), N0,
                        t->a32.as<uint32_t>(), t->b32.as<uint32_t>(), n_new, t->view_id[o].as<uint32_t>(), t->view_track[o].as<uint32_t>());
     hipLaunchKernelGGL(trk_offsets_kernel, grid_for((size_t)t->n_views + 1), dim3(NT), 0, s, t->view_id[o].as<uint32_t>(), N1, t->n_views, t->view_begin.as<uint32_t>());
