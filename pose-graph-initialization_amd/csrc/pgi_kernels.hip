@@ -735,6 +735,7 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         const double trunc = 1.5 * thr;
         const float tau2 = prm.guess_quirk ? (float)trunc : (float)(trunc * trunc);
         if (w == 0) {  // all-inlier refit of the guess (:1013-1020) on wave 0; the others wait
+            __builtin_amdgcn_s_setprio(3);  // (the workgroup's critical path, as in the round loop)
             int rs0;
             uint32_t rn0;
             float rE0[9];
@@ -746,6 +747,7 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c) sh->loE[c] = rE0[c];
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const uint32_t ni = sh->lo_ni;
@@ -913,6 +915,9 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                                                               wscr_all + W_DOUBLES, sh, td);
                 }
                 if (w == 0) {  // n-point refits while they improve (only wave 0 touches the best from here to A)
+                    // The refits are the workgroup's critical path (the other wavefronts finish the next round's passes
+                    // and then wait at barrier A): let this wavefront issue ahead of its SIMD's other wavefronts.
+                    __builtin_amdgcn_s_setprio(3);
                     for (uint32_t it = 0; it < prm.lo_iters; ++it) {
                         float bE[9];
 #pragma unroll
@@ -938,6 +943,7 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                         }
                         wave_sync();
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 deferred = true;
             } else if (terminated(hyps)) {

@@ -21,7 +21,7 @@ for rho, N, thr, fb in ((0.5, 2000, 7.5e-4, 0), (0.5, 600, 7.5e-4, 0), (0.5, 300
     for i, e in enumerate(engs):
         e.set_params(fixed_budget=fb)
     dbs = [e.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=1) for e in engs]
-    for rnd in range(5):
+    for rnd in range(int(os.environ.get("AB_ROUNDS", "5"))):
         for i, e in enumerate(engs):
             a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); ed, m = e.estimate_pose_batch(dbs[i]); z.record(); torch.cuda.synchronize()
