@@ -181,8 +181,8 @@ int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr_aos, const uint64_t* d
                        uint32_t* d_counts, uint8_t* d_masks);
 
 /* ---- getPoseFromEssentialMatrix, batched -------------------------------- */
-/* d_E: n_pairs x 9; d_masks: rows voting (NULL = all rows).  Writes R, t,
- * votes, cand of d_edges (other fields untouched). */
+/* d_E: n_pairs x 9; d_masks: rows voting (NULL, or pgi_params.vote_all_rows = 1:
+ * all rows).  Writes R, t, votes, cand of d_edges (other fields untouched). */
 int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* batch, const double* d_E,
                         const uint8_t* d_masks, pgi_edge* d_edges);
 

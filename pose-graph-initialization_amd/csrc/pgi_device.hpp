@@ -696,21 +696,37 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
 
 // ---- 3x3 SVD (one-sided Jacobi) and the four-candidate decomposition ----------------------------------
 // pose_utils.h:144-169: R1 = U D V^T, R2 = U D^T V^T, t = U[:,2]; det fixes as :157-163.
-PGI_DEV void svd3(const double E[9], double U[9], double S[3], double V[9]) {
-    double G[9];
+// Executed by ONE wavefront with the matrices spread over lanes 0..2: lane l owns row l of G (= E V) and row l of V,
+// three doubles each.  A rotation needs two whole columns; they travel by v_readlane (constant source lanes, results
+// wave-uniform), every lane derives the same (c, s) and updates its own row.  Element for element the operations and
+// their order are those of the oracle's scalar pgo_svd3 / pgo_decompose, so the bits are the same -- but the live set
+// is ~50 VGPRs instead of ~130 (the scalar form, run by one thread inside K1's epilogue, was the source of r02's
+// 553 spilled VGPRs), and the row updates cost a third of the instructions.
+PGI_DEV double readlane_d(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+PGI_DEV double pick3(int o, const double a[3]) { return o == 0 ? a[0] : (o == 1 ? a[1] : a[2]); }
+// E32: the model (9 floats, LDS or global); Rt (LDS or global, 21 doubles): R1[9] R2[9] t[3]; candidates
+// 0:(R1,+t) 1:(R1,-t) 2:(R2,+t) 3:(R2,-t)  (pose_utils.h:182,201).  Call with the whole wavefront; no barrier inside.
+template <class T>
+PGI_DEV void decompose_wave(const T* Esrc, double* Rt, int lane) {
+    const int l = lane < 3 ? lane : 0;  // lanes >= 3 shadow lane 0 (never read, never written out)
+    double g[3], v[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        G[i] = E[i];
-        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int c = 0; c < 3; ++c) {
+        g[c] = (double)Esrc[3 * l + c];
+        v[c] = (c == l) ? 1.0 : 0.0;
     }
     for (int sw = 0; sw < kSvdSweeps; ++sw) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
-            const double al = fma(G[p], G[p], fma(G[3 + p], G[3 + p], G[6 + p] * G[6 + p]));
-            const double be = fma(G[q], G[q], fma(G[3 + q], G[3 + q], G[6 + q] * G[6 + q]));
-            const double ga = fma(G[p], G[q], fma(G[3 + p], G[3 + q], G[6 + p] * G[6 + q]));
-            if (ga == 0.0) continue;
+            const double p0 = readlane_d(g[p], 0), p1 = readlane_d(g[p], 1), p2 = readlane_d(g[p], 2);
+            const double q0 = readlane_d(g[q], 0), q1 = readlane_d(g[q], 1), q2 = readlane_d(g[q], 2);
+            const double al = fma(p0, p0, fma(p1, p1, p2 * p2));
+            const double be = fma(q0, q0, fma(q1, q1, q2 * q2));
+            const double ga = fma(p0, q0, fma(p1, q1, p2 * q2));
+            if (ga == 0.0) continue;  // wave-uniform
             // one division + two square roots per rotation (as in the 9x9 Jacobi)
             const double da = be - al, db = 2.0 * ga;
             const double h = sqrt(fma(da, da, db * db));
@@ -718,74 +734,56 @@ PGI_DEV void svd3(const double E[9], double U[9], double S[3], double V[9]) {
             const double r = sqrt(fma(d, d, db * db));
             const double inv = 1.0 / r;
             const double c = d * inv, s = (da >= 0.0 ? db : -db) * inv;
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const double gp = G[3 * l + p], gq = G[3 * l + q];
-                G[3 * l + p] = fma(c, gp, -(s * gq));
-                G[3 * l + q] = fma(s, gp, c * gq);
-                const double vp = V[3 * l + p], vq = V[3 * l + q];
-                V[3 * l + p] = fma(c, vp, -(s * vq));
-                V[3 * l + q] = fma(s, vp, c * vq);
-            }
+            const double gp = g[p], gq = g[q];
+            g[p] = fma(c, gp, -(s * gq));
+            g[q] = fma(s, gp, c * gq);
+            const double vp = v[p], vq = v[q];
+            v[p] = fma(c, vp, -(s * vq));
+            v[q] = fma(s, vp, c * vq);
         }
     }
     double sg[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) sg[j] = sqrt(fma(G[j], G[j], fma(G[3 + j], G[3 + j], G[6 + j] * G[6 + j])));
+    for (int j = 0; j < 3; ++j) {
+        const double c0 = readlane_d(g[j], 0), c1 = readlane_d(g[j], 1), c2 = readlane_d(g[j], 2);
+        sg[j] = sqrt(fma(c0, c0, fma(c1, c1, c2 * c2)));
+    }
     // stable selection sort (descending) as three compare-exchanges on (a,b) = (0,1),(0,2),(1,2)
     int o0 = 0, o1 = 1, o2 = 2;
     double s0 = sg[0], s1 = sg[1], s2 = sg[2];
     if (s1 > s0) { double ts = s0; s0 = s1; s1 = ts; int to = o0; o0 = o1; o1 = to; }
     if (s2 > s0) { double ts = s0; s0 = s2; s2 = ts; int to = o0; o0 = o2; o2 = to; }
     if (s2 > s1) { double ts = s1; s1 = s2; s2 = ts; int to = o1; o1 = o2; o2 = to; }
-    S[0] = s0; S[1] = s1; S[2] = s2;
-    double Gs[9], Vs[9];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double g0 = G[3 * l + c], v0 = V[3 * l + c];
-            if (o0 == c) { Gs[3 * l + 0] = g0; Vs[3 * l + 0] = v0; }
-            if (o1 == c) { Gs[3 * l + 1] = g0; Vs[3 * l + 1] = v0; }
-            if (o2 == c) { Gs[3 * l + 2] = g0; Vs[3 * l + 2] = v0; }
-        }
-    }
-    const double i0 = 1.0 / S[0], i1 = 1.0 / S[1];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        U[3 * l + 0] = Gs[3 * l + 0] * i0;
-        U[3 * l + 1] = Gs[3 * l + 1] * i1;
-    }
-    const double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+    const double gs0 = pick3(o0, g), gs1 = pick3(o1, g);
+    double vs[3] = {pick3(o0, v), pick3(o1, v), pick3(o2, v)};
+    const double i0 = 1.0 / s0, i1 = 1.0 / s1;
+    const double ul0 = gs0 * i0, ul1 = gs1 * i1;  // this lane's row of U, columns 0 and 1
+    const double u0[3] = {readlane_d(ul0, 0), readlane_d(ul0, 1), readlane_d(ul0, 2)};
+    const double u1[3] = {readlane_d(ul1, 0), readlane_d(ul1, 1), readlane_d(ul1, 2)};
     double u2[3];
-    cross3(u0, u1, u2);
-    U[2] = u2[0]; U[5] = u2[1]; U[8] = u2[2];
-    const double v0[3] = {Vs[0], Vs[3], Vs[6]}, v1[3] = {Vs[1], Vs[4], Vs[7]};
+    cross3(u0, u1, u2);  // third column of U, whole in every lane
+    const double v0[3] = {readlane_d(vs[0], 0), readlane_d(vs[0], 1), readlane_d(vs[0], 2)};
+    const double v1[3] = {readlane_d(vs[1], 0), readlane_d(vs[1], 1), readlane_d(vs[1], 2)};
+    double v2[3] = {readlane_d(vs[2], 0), readlane_d(vs[2], 1), readlane_d(vs[2], 2)};
     double vc[3];
     cross3(v0, v1, vc);
-    const double dv = fma(vc[0], Vs[2], fma(vc[1], Vs[5], vc[2] * Vs[8]));
-    if (dv < 0.0) { Vs[2] = -Vs[2]; Vs[5] = -Vs[5]; Vs[8] = -Vs[8]; }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
-}
-
-// candidates 0:(R1,+t) 1:(R1,-t) 2:(R2,+t) 3:(R2,-t)  (pose_utils.h:182,201)
-PGI_DEV void decompose_candidates(const double E[9], double R1[9], double R2[9], double t[3]) {
-    double U[9], S[3], V[9];
-    svd3(E, U, S, V);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double a = U[3 * i + 1] * V[3 * j + 0];
-            const double b = U[3 * i + 0] * V[3 * j + 1];
-            const double c = U[3 * i + 2] * V[3 * j + 2];
-            R1[3 * i + j] = (b - a) + c;
-            R2[3 * i + j] = (a - b) + c;
-        }
-    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+    const double dv = fma(vc[0], v2[0], fma(vc[1], v2[1], vc[2] * v2[2]));
+    if (dv < 0.0) { v2[0] = -v2[0]; v2[1] = -v2[1]; v2[2] = -v2[2]; }
+    const double ul2 = pick3(l, u2);
+    double t[3] = {u2[0], u2[1], u2[2]};
     const double tn = 1.0 / sqrt(fma(t[0], t[0], fma(t[1], t[1], t[2] * t[2])));
     t[0] = t[0] * tn; t[1] = t[1] * tn; t[2] = t[2] * tn;
+    if (lane < 3) {  // row l of R1 = U D V^T and of R2 = U D^T V^T
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double a = ul1 * v0[j];
+            const double b = ul0 * v1[j];
+            const double c = ul2 * v2[j];
+            Rt[3 * l + j] = (b - a) + c;
+            Rt[9 + 3 * l + j] = (a - b) + c;
+        }
+        Rt[18 + l] = pick3(l, t);
+    }
 }
 
 // depth signs of lambda2*x2 = lambda1*R*x1 + t: bit0 = (R,+t) in front of both, bit1 = (R,-t)

@@ -114,6 +114,13 @@ PGI_DEV void edge_clear(pgi_edge* e) {
     for (int i = 0; i < (int)(sizeof(pgi_edge) / 8); ++i) d[i] = 0.0;
 }
 
+// lane index recomputed on the spot (volatile: never merged with -- and kept live from -- an earlier computation)
+PGI_DEV int fresh_lane_id() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 PGI_DEV float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Score queue models [m_begin, m_end) in blocks of four; keeps the first maximum that beats
@@ -138,6 +145,7 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
             for (int c = 0; c < 9; ++c) e[mm >> 1][c][mm & 1] = queue[9 * m + c];  // VGPRs: no constant-bus moves
         }
         const int bar = __builtin_amdgcn_readfirstlane(max(floor_score, b_score));  // wave-uniform
+        const bool two = m_end - m0 > 2;  // wave-uniform: the second packed pair holds real models (else: copies of the last)
         uint32_t sc[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
         uint32_t alive = 0xFu;
         bool dead = false;
@@ -149,9 +157,10 @@ PGI_DEV void score_queue(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, c
             } else {
                 if (base + 64 < npad) pnext = rows.lds[base + 64 + lane];
             }
-            uint32_t c3v[4];
+            uint32_t c3v[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
+                if (pr == 1 && !two) continue;
                 f32x2 r2, den;
                 sampson_terms2(e[pr], p.x, p.y, p.z, p.w, r2, den);
                 const f32x2 t = den * thr2, t0 = t * 0.25f, t1 = t * 0.5625f, t3 = t * 2.25f;
@@ -403,12 +412,14 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
 
 // n-point refit of model E's inlier set (bound tau2), executed by ONE wavefront (wave 0) without any
 // workgroup barrier: normal matrix -> 9x9 Jacobi -> Nister back-end -> score the <= 10 roots.
-// Outputs the inlier count and the best refit model that beats `floor_score` (r_score = -1: none).
+// Outputs the inlier count and the best refit model that beats `floor_score` (r_score = -1: none): the model stays in
+// wave 0's queue (LDS) at index r_idx -- the caller copies it from there (nine registers carried out of here were
+// spilled around the round loop).
 // LDS: A, V and the triangle scratch alias wave 0's unused solver groups; the queue is wave 0's.
 template <int LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
                              float thr2, double* wscr0, WgShared* sh, int lane, int floor_score, uint32_t n_bar,
-                             int& r_score, uint32_t& r_ninl, float rE[9], Prof& prof, int ni_pre = -1,
+                             int& r_score, uint32_t& r_ninl, int& r_idx, Prof& prof, int ni_pre = -1,
                              uint32_t lin_pct = 0u) {
     double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
     double* loV = loA + 81;                    // 81 (ends at W_REGA + 228 <= W_DOUBLES)
@@ -416,6 +427,7 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     float* queue0 = reinterpret_cast<float*>(wscr0 + W_REGA);
     r_score = -1;
     r_ninl = 0;
+    r_idx = -1;
     prof.mark<11>();
     const uint32_t ni = ni_pre >= 0 ? (uint32_t)ni_pre  // the workgroup already built A (first refit after a merge)
                                     : normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane);
@@ -449,14 +461,9 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     }
     wave_sync();
     prof.mark<20>();
-    int b_idx = -1;
     uint32_t b_hyp = 0;
     score_queue<LDS_PTS>(rows, n, npad, queue0, nullptr, 0, cnt, thr2, lane, floor_score, n_bar, r_score, r_ninl, b_hyp,
-                         b_idx);
-    if (b_idx >= 0) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) rE[c] = queue0[9 * b_idx + c];
-    }
+                         r_idx);
     wave_sync();
     prof.mark<21>();
     return ni;
@@ -465,7 +472,8 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
 template <int LDS_PTS, bool GUESS>
 __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index: uniform, lives in an SGPR
     uint32_t pair = blockIdx.x;
     if (a.pair_list) {  // this launch serves one size bucket (its own LDS size => its own occupancy)
         if (blockIdx.x >= *a.pair_count) return;
@@ -556,9 +564,8 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
     }
 
     uint32_t out_iters = 0, out_lo = 0, out_used_guess = 0, out_score = 0;
-    float finalE[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) finalE[c] = 0.f;
+    // (the final model is never carried in registers: it sits in LDS -- sh->loE after an accepted guess refit, sh->bestE in
+    // every other path -- and the epilogue reads it there)
     float mask_tau2 = thr2;
     bool success = false, have_model = false;
     uint32_t guess_ninl = 0;
@@ -585,22 +592,20 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                 for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
                 const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
                 const uint32_t cur_ninl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->best_ninl);
-                int r_score;
+                int r_score, r_idx;
                 uint32_t r_ninl;
-                float rE[9];
                 int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                 asm volatile("" : "+v"(ln));
-                const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best, cur_ninl, r_score,
-                                                         r_ninl, rE, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct);
+                const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best, cur_ninl,
+                                                                r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct);
                 if (ni < 5) break;
                 if (lane == 0) sh->lo_runs += 1;
                 if (!(r_score > cur_best)) break;
                 if (lane == 0) {
                     sh->best_score = r_score;
                     sh->best_ninl = r_ninl;
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
                 }
+                if (ln < 9) sh->bestE[ln] = reinterpret_cast<const float*>(wscr_all + W_REGA)[9 * r_idx + ln];
                 wave_sync();
             }
         }
@@ -694,8 +699,6 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                 out_iters = 32;
                 out_lo = sh->lo_runs;
                 out_score = (uint32_t)sh->best_score;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) finalE[c] = sh->bestE[c];
             }
         }
         if (!guided_done) {  // nothing usable: the robust fit starts from scratch
@@ -736,25 +739,20 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         const float tau2 = prm.guess_quirk ? (float)trunc : (float)(trunc * trunc);
         if (w == 0) {  // all-inlier refit of the guess (:1013-1020) on wave 0; the others wait
             __builtin_amdgcn_s_setprio(3);  // (the workgroup's critical path, as in the round loop)
-            int rs0;
+            int rs0, ri0;
             uint32_t rn0;
-            float rE0[9];
-            const uint32_t ni0 = refit_wave0<LDS_PTS>(rows, n, npad, Ef, tau2, thr2, wscr_all, sh, lane, -1, 0u, rs0, rn0, rE0, prof);
+            const uint32_t ni0 = refit_wave0<LDS_PTS>(rows, n, npad, Ef, tau2, thr2, wscr_all, sh, lane, -1, 0u, rs0, rn0, ri0, prof);
             if (lane == 0) {
                 sh->lo_ni = ni0;
                 sh->lo_score = rs0;
                 sh->lo_ninl = rn0;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) sh->loE[c] = rE0[c];
             }
+            if (ri0 >= 0 && lane < 9) sh->loE[lane] = reinterpret_cast<const float*>(wscr_all + W_REGA)[9 * ri0 + lane];
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const uint32_t ni = sh->lo_ni;
         const int r_score = sh->lo_score;
-        float rE[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) rE[c] = sh->loE[c];
         if (ni >= 5 && r_score >= 0 && ni >= prm.min_inliers) {
             success = true;
             have_model = true;
@@ -763,8 +761,6 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
             out_score = (uint32_t)r_score;
             guess_ninl = ni;
             mask_tau2 = tau2;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) finalE[c] = rE[c];
             // the mask of the guess path is the guess's inlier set (:1000-1009)
             if (tid == 0) {
 #pragma unroll
@@ -847,10 +843,15 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         bool deferred = false;  // an LO may be running on wave 0; its termination test is pending
         auto terminated = [&](uint32_t at_hyps) {
             if (prm.fixed_budget || sh->best_score < 0 || sh->best_ninl < 5) return false;
-            const double rho = (double)sh->best_ninl / (double)n;
+            // (opaque copies: (double)n and 1 - confidence are loop invariants the compiler would otherwise hoist out of
+            // the round loop and keep -- spilled -- across it)
+            uint32_t nn = n;
+            double conf = prm.confidence;
+            asm volatile("" : "+s"(nn), "+s"(conf));
+            const double rho = (double)sh->best_ninl / (double)nn;
             const double r5 = ((rho * rho) * (rho * rho)) * rho;
             const double q = 1.0 - r5;
-            return pow_uint(q, at_hyps) <= 1.0 - prm.confidence;
+            return pow_uint(q, at_hyps) <= 1.0 - conf;
         };
         while (hyps < budget) {
             for (;;) {
@@ -909,8 +910,9 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                     float bE0[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
-                    int td = tid;
-                    asm volatile("" : "+v"(td));
+                    // thread id rebuilt from the wave index (uniform) and a fresh lane count: no VGPR carried -- and
+                    // spilled -- across the round loop for this once-per-improvement step
+                    const int td = (w << 6) + fresh_lane_id();
                     ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ,
                                                               wscr_all + W_DOUBLES, sh, td);
                 }
@@ -924,23 +926,21 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                         for (int c = 0; c < 9; ++c) bE[c] = sh->bestE[c];
                         const int cur_best = __builtin_amdgcn_readfirstlane(sh->best_score);
                         const uint32_t cur_ninl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->best_ninl);
-                        int r_score;
+                        int r_score, r_idx;
                         uint32_t r_ninl;
-                        float rE[9];
                         int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                         asm volatile("" : "+v"(ln));
                         const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best,
-                                                                 cur_ninl, r_score, r_ninl, rE, prof, it == 0 ? ni_first : -1,
-                                                                 prm.lo_linear_pct);
+                                                                       cur_ninl, r_score, r_ninl, r_idx, prof,
+                                                                       it == 0 ? ni_first : -1, prm.lo_linear_pct);
                         if (ni < 5) break;
                         if (lane == 0) sh->lo_runs += 1;
                         if (!(r_score > cur_best)) break;
                         if (lane == 0) {
                             sh->best_score = r_score;
                             sh->best_ninl = r_ninl;
-#pragma unroll
-                            for (int c = 0; c < 9; ++c) sh->bestE[c] = rE[c];
                         }
+                        if (ln < 9) sh->bestE[ln] = reinterpret_cast<const float*>(wscr_all + W_REGA)[9 * r_idx + ln];
                         wave_sync();
                     }
                     __builtin_amdgcn_s_setprio(0);
@@ -954,18 +954,17 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         out_lo = sh->lo_runs;
         out_iters = hyps;
         have_model = sh->best_score >= 0;
-        if (have_model) {
-            out_score = (uint32_t)sh->best_score;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) finalE[c] = sh->bestE[c];
-        }
+        if (have_model) out_score = (uint32_t)sh->best_score;
     }
 
     prof.mark<23>();
+    // thread / lane ids rebuilt here (wave index is uniform, the lane count is recomputed): the epilogue then keeps no
+    // VGPR alive across the whole fit
+    const int ew = w, etid = (ew << 6) + fresh_lane_id(), elane = etid & 63;
     // ---- epilogue: mask, count, decomposition (pose_graph_builder.h:1057-1075) ----
     if (!have_model) {
-        for (uint32_t i = tid; i < n; i += NT) mask[i] = 0;
-        if (tid == 0) {
+        for (uint32_t i = etid; i < n; i += NT) mask[i] = 0;
+        if (etid == 0) {
             edge_clear(edge);
             edge->status = PGI_EDGE_FEW_INLIERS;
             edge->iters = out_iters;
@@ -973,21 +972,27 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         }
         return;
     }
-    float maskE[9];
+    const float* finalE = success ? sh->loE : sh->bestE;  // LDS
+    float maskE[9];  // the guess path masks with the guess itself (:1000-1009), parked in sh->bestE
 #pragma unroll
-    for (int c = 0; c < 9; ++c) maskE[c] = success ? sh->bestE[c] : finalE[c];
-    double Ed[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) Ed[c] = (double)finalE[c];
-    if (tid == 0) {
-        double R1[9], R2[9], t[3];
-        decompose_candidates(Ed, R1, R2, t);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            sh->Rt[c] = R1[c];
-            sh->Rt[9 + c] = R2[c];
+    for (int c = 0; c < 9; ++c) maskE[c] = sh->bestE[c];
+    // Wave 0 decomposes the model (3x3 SVD spread over three lanes, pgi_device.hpp) while waves 1..3 write the inlier
+    // mask; the cheirality vote needs both and follows the barrier.
+    uint32_t mc = 0;
+    if (ew == 0) {
+        decompose_wave(finalE, sh->Rt, elane);
+    } else {
+        for (uint32_t base = 0; base < npad; base += NT - 64) {
+            const uint32_t i = base + (uint32_t)(etid - 64);
+            const float nanv = __builtin_nanf("");
+            const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
+            float r2, den;
+            sampson_terms(maskE, p.x, p.y, p.z, p.w, r2, den);
+            const bool in = r2 < mask_tau2 * den;
+            if (i < n) mask[i] = in ? 1 : 0;
+            mc += __popcll(__ballot(in));
         }
-        sh->Rt[18] = t[0]; sh->Rt[19] = t[1]; sh->Rt[20] = t[2];
+        if (elane == 0) atomicAdd(&sh->mask_cnt, mc);
     }
     __syncthreads();
     double R1[9], R2[9], tt[3];
@@ -997,16 +1002,14 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         R2[c] = sh->Rt[9 + c];
     }
     tt[0] = sh->Rt[18]; tt[1] = sh->Rt[19]; tt[2] = sh->Rt[20];
-    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, mc = 0;
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     for (uint32_t base = 0; base < npad; base += NT) {
-        const uint32_t i = base + tid;
+        const uint32_t i = base + etid;
         const float nanv = __builtin_nanf("");
         const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
         float r2, den;
         sampson_terms(maskE, p.x, p.y, p.z, p.w, r2, den);
         const bool in = r2 < mask_tau2 * den;
-        if (i < n) mask[i] = in ? 1 : 0;
-        mc += __popcll(__ballot(in));
         const bool voter = (i < n) && (prm.vote_all_rows || in);
         uint32_t b1 = 0, b2 = 0;
         if (voter) {
@@ -1021,19 +1024,18 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
         v2 += __popcll(__ballot(b2 & 1u));
         v3 += __popcll(__ballot(b2 & 2u));
     }
-    if (lane == 0) {
+    if (elane == 0) {
         atomicAdd(&sh->votes[0], v0);
         atomicAdd(&sh->votes[1], v1);
         atomicAdd(&sh->votes[2], v2);
         atomicAdd(&sh->votes[3], v3);
-        atomicAdd(&sh->mask_cnt, mc);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (etid == 0) {
         edge_clear(edge);
         const uint32_t n_inl = success ? guess_ninl : sh->mask_cnt;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) edge->E[c] = Ed[c];
+        for (int c = 0; c < 9; ++c) edge->E[c] = (double)finalE[c];
         edge->n_inl = n_inl;
         edge->score = out_score;
         edge->iters = out_iters;
@@ -1076,11 +1078,24 @@ __global__ __launch_bounds__(256) void bucket_pairs_kernel(const uint64_t* __res
                                                            uint32_t cap1, uint32_t cap2, uint32_t cap3, uint32_t* __restrict__ lists,
                                                            uint32_t* __restrict__ counts) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint32_t n = (uint32_t)(off[p + 1] - off[p]);
-    const int b = n <= cap0 ? 0 : n <= cap1 ? 1 : n <= cap2 ? 2 : n <= cap3 ? 3 : 4;
-    const uint32_t i = atomicAdd(&counts[b], 1u);  // order inside a bucket is irrelevant: results are per pair
-    lists[(size_t)b * n_pairs + i] = p;
+    const int lane = threadIdx.x & 63;
+    int b = -1;
+    if (p < n_pairs) {
+        const uint32_t n = (uint32_t)(off[p + 1] - off[p]);
+        b = n <= cap0 ? 0 : n <= cap1 ? 1 : n <= cap2 ? 2 : n <= cap3 ? 3 : 4;
+    }
+    // One atomic per wavefront and class (r02: one per pair -- 10 000 same-address atomics were 116 us of every launch):
+    // the lanes of a class are counted by ballot, lane 0 reserves the block, every lane takes its rank inside it.
+    // The order inside a bucket is irrelevant: results are per pair.
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint64_t m = __ballot(b == k);
+        if (!m) continue;  // wave-uniform
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&counts[k], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (b == k) lists[(size_t)k * n_pairs + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1209,17 +1224,8 @@ __global__ __launch_bounds__(256) void decompose_kernel(const float* __restrict_
     const uint32_t pair = blockIdx.x;
     const uint64_t o = off[pair];
     const uint32_t n = (uint32_t)(off[pair + 1] - o);
-    if (tid == 0) {
-        double Ed[9], R1[9], R2[9], t[3];
-        for (int c = 0; c < 9; ++c) Ed[c] = Ein[9 * (size_t)pair + c];
-        decompose_candidates(Ed, R1, R2, t);
-        for (int c = 0; c < 9; ++c) {
-            Rt[c] = R1[c];
-            Rt[9 + c] = R2[c];
-        }
-        Rt[18] = t[0]; Rt[19] = t[1]; Rt[20] = t[2];
-        votes[0] = votes[1] = votes[2] = votes[3] = 0;
-    }
+    if (tid < 64) decompose_wave(Ein + 9 * (size_t)pair, Rt, tid);
+    if (tid == 0) votes[0] = votes[1] = votes[2] = votes[3] = 0;
     __syncthreads();
     double R1[9], R2[9], tt[3];
     for (int c = 0; c < 9; ++c) {
@@ -2015,6 +2021,7 @@ int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, con
     if (!ctx || !b || !d_E || !d_edges) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->prm.vote_all_rows) d_masks = nullptr;  // the reference's population (pose_utils.h:203), as in K1's epilogue
     hipLaunchKernelGGL(decompose_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->d_x1, b->d_y1, b->d_x2,
                        b->d_y2, b->d_offsets, d_E, d_masks, d_edges);
     HIP_TRY(hipGetLastError());

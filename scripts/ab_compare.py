@@ -13,7 +13,7 @@ for path in libs:
     L._lib = None
     L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
     engs.append(Engine())
-P = 8192
+P = int(os.environ.get("AB_P", "8192"))
 for rho, N, thr, fb in ((0.5, 2000, 7.5e-4, 0), (0.5, 600, 7.5e-4, 0), (0.5, 300, 7.5e-4, 0), (0.5, 1200, 7.5e-4, 0)):
     b = S.make_batch(np.arange(P), N, inlier_ratio=rho)
     res = {i: [] for i in range(len(engs))}
