@@ -33,6 +33,33 @@ def algorithmic_bytes_per_edge(n):
     return 17 * n + EDGE_RECORD_BYTES
 
 
+def replay_profile(kind, P, N, L):
+    """Counters of the newest committed PMC profile of kernel `kind` ("k1" / "k2"): profiles/rNN_<kind>_pmc.json.
+    They are REPLAYED, not measured in this run, and only while the profile was taken from the very kernel sources the
+    loaded library was built from (sha256 over csrc/pgi_kernels.hip + pgi_device.hpp, written by scripts/k1_pmc_json.py).
+    Returns (profile dict or None, file name or None, reason or None)."""
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % kind)),
+                   key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not cands:
+        return None, None, "no profiles/r*_%s_pmc.json" % kind
+    f = cands[-1]
+    name = "profiles/" + os.path.basename(f)
+    try:
+        tj = json.load(open(f))
+    except Exception as ex:  # noqa: BLE001
+        return None, name, "unreadable: %s" % ex
+    if tj.get("pairs") != P or tj.get("corrs") != N:
+        return None, name, "profiled on another workload (%s x %s)" % (tj.get("pairs"), tj.get("corrs"))
+    sha = tj.get("source_sha256")
+    if not sha:
+        return None, name, "profile carries no source hash (taken before round 3)"
+    if sha != L.kernel_source_sha256():
+        return None, name, "kernel sources changed since the profile was taken (hash mismatch): re-run scripts/profile_k1.sh"
+    return tj, name, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +73,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-256 / score_pose lines")
+    ap.add_argument("--no-variants", action="store_true", help="skip the SURVEY 8d variants (ragged, inlier ratios, 0.4 px) and the graph-level runs")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: fail (non-zero exit) unless the exchange runs through pgi_allgather_edges over RCCL")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -90,17 +120,31 @@ def main():
     # the path's one exchange step goes through the C ABI (pgi_allgather_edges: RCCL inside libpgi.so on the engine's
     # stream, bootstrapped here by shipping the 128-byte unique id through torch.distributed); if that cannot be set up
     # the bench falls back to torch.distributed's own all-gather and says so in the JSON line
-    comm, exchange = None, "none (single GPU)"
+    comm, exchange, comm_info = None, "none (single GPU)", None
+    counts_uneven, gathered_uneven = None, None
     if world > 1:
         from pyposegraphbuilder import distributed as D
         try:
             comm = D.Communicator(eng, transport="rccl")
-            exchange = "pgi_allgather_edges (RCCL inside libpgi.so)"
+            exchange = "pgi_allgather_edges (RCCL inside libpgi.so): equal blocks ncclAllGather + an uneven table by grouped ncclSend/ncclRecv"
         except Exception as ex:  # noqa: BLE001
+            if args.require_rccl:
+                raise SystemExit("bench.py --require-rccl: the C-ABI RCCL communicator could not be set up: %s" % ex)
             comm, exchange = None, "torch.distributed all_gather_into_tensor (C-ABI communicator unavailable: %s)" % ex
+        if comm is not None:
+            cw, cr, ck = eng.comm_info()   # what libpgi.so itself reports: world, this rank, transport kind
+            comm_info = {"rccl_ranks": int(cw) if ck == "rccl" else 0, "transport": ck, "rccl_version": comm.rccl_version}
+            if args.require_rccl and (ck != "rccl" or cw != world):
+                raise SystemExit("bench.py --require-rccl: libpgi.so reports transport %s with %d rank(s), expected rccl with %d" % (ck, cw, world))
+            # the uneven-block path (config 4's row-balanced shards are ragged): rank r contributes the records of a
+            # row-balanced block of a ragged pair list; exchanged by grouped ncclSend/ncclRecv, no padding
+            rag = np.random.default_rng(5).integers(50, 4001, world * (P // 2))   # half a step's records: every block stays below P
+            counts_uneven = [hi - lo for lo, hi in D.shard_bounds(rag, world)]
+            assert max(counts_uneven) <= P and len(set(counts_uneven)) > 1 or world == 1
+            gathered_uneven = torch.empty((sum(counts_uneven), EDGE_RECORD_BYTES), dtype=torch.uint8, device=eng.device)
     counts = [P] * world
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
@@ -111,8 +155,15 @@ def main():
         if world > 1:  # the path's one exchange: per-edge records to every rank (RCCL over xGMI)
             if comm is not None:
                 comm.allgather_edges(edges, counts, out=gathered)
+                if i is not None:
+                    ev[i][2].record()
+                comm.allgather_edges(edges[:counts_uneven[rank]], counts_uneven, out=gathered_uneven)
+                if i is not None:
+                    ev[i][3].record()
             else:
                 dist.all_gather_into_tensor(gathered, edges)
+                if i is not None:
+                    ev[i][2].record()
 
     def fence():
         if world > 1:
@@ -131,7 +182,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))  # HIP events on the launch stream
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))  # HIP events on the launch stream
+    allgather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if world > 1 else None
+    allgather_uneven_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) if comm is not None else None
 
     got = eng.edges_to_numpy(edges)
     masks_host = masks.cpu().numpy()  # the secondary runs below reuse the device buffers
@@ -142,22 +195,15 @@ def main():
     value = world * P * args.steps / dt
     bytes_per_launch = P * algorithmic_bytes_per_edge(N)
     achieved_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic, pmc = None, None
-    # PMC figures are REPLAYED from the committed profile of this exact workload (scripts/profile_k1_r02.sh ->
-    # profiles/r02_k1_pmc.json); they are not measured inside this run
-    tf = os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
-    roofline_compute = None
-    if os.path.exists(tf):
-        try:
-            tj = json.load(open(tf))
-            if tj.get("pairs") == P and tj.get("corrs") == N and not args.fixed_budget:
-                traffic = tj.get("hbm_bytes_per_launch")
-                pmc = {"wave_lifetime_split": tj.get("wave_lifetime_split"),
-                       "executed_flop_per_launch": tj.get("executed_flop_per_launch"),
-                       "source": "replayed from profiles/r02_k1_pmc.json (rocprofv3 PMC passes of this workload)"}
-                roofline_compute = dict(tj.get("roofline_compute", {}), source="replayed from profiles/r02_k1_pmc.json")
-        except Exception:
-            traffic, pmc, roofline_compute = None, None, None
+    traffic, pmc, roofline_compute, traffic_kernel_us = None, None, None, None
+    tj, prof_name, prof_reason = (None, None, "fixed-budget run") if args.fixed_budget else replay_profile("k1", P, N, L)
+    if tj:
+        traffic = tj.get("hbm_bytes_per_launch")
+        traffic_kernel_us = tj.get("kernel_us_trace_avg")
+        pmc = {"wave_lifetime_split": tj.get("wave_lifetime_split"),
+               "executed_flop_per_launch": tj.get("executed_flop_per_launch"),
+               "source": "replayed from %s (rocprofv3 PMC passes of this workload, git %s)" % (prof_name, tj.get("git_head"))}
+        roofline_compute = dict(tj.get("roofline_compute", {}), source="replayed from " + prof_name)
     out = {
         "metric": "pose-graph edges/sec (essential+decompose)",
         "value": round(value, 1), "unit": "edges/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -174,13 +220,23 @@ def main():
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "kernel": "estimate_pose_kernel", "kernel_ms": round(kern_ms, 3),
                      "bytes_per_edge": algorithmic_bytes_per_edge(N),
-                     "traffic_source": "replayed from profiles/r02_k1_pmc.json" if traffic else None,
+                     "traffic_kernel_us": traffic_kernel_us,   # the profiled kernel's average, next to this run's kernel_ms
+                     "traffic_over_algorithmic": round(traffic / bytes_per_launch, 3) if traffic else None,
+                     "traffic_source": ("replayed from %s; source hash matches the loaded build" % prof_name) if traffic
+                                       else "none: %s" % prof_reason,
                      "note": "K1 stages rows once into LDS: VALU / LDS-latency bound by design (SURVEY 8d), see 'valu'"},
         "quality": {"rot_err_auc_at_5deg": round(auc5, 4), "edges_ok": int(ok.sum()),
                     "median_rot_err_deg": round(float(np.median(errs)), 4), "mean_hypotheses": float(got["iters"].mean()),
                     "mean_lo_refits": float(got["lo_runs"].mean())},
         "setup": {"gen_s": round(gen_s, 1)},
     }
+    if world > 1:
+        out["exchange"] = dict(comm_info or {"rccl_ranks": 0, "transport": "torch.distributed", "rccl_version": 0},
+                               allgather_ms=round(allgather_ms, 4),
+                               allgather_uneven_ms=round(allgather_uneven_ms, 4) if allgather_uneven_ms is not None else None,
+                               records_per_rank=P, uneven_counts=counts_uneven,
+                               note="per step, inside the timed region: one equal-block gather of the step's records and one "
+                                    "uneven gather (row-balanced shards of a ragged list); HIP events on the engine's stream")
     # compute side (the kernel is VALU / LDS-latency bound, not HBM bound): measured by PMC, not estimated
     if pmc:
         out["valu"] = pmc
@@ -275,6 +331,12 @@ def main():
         out["score_pose_k2"] = {"kernel_ms": round(ms, 4), "achieved_GBs": round(k2_bytes / (ms * 1e-3) / 1e9, 1),
                                 "frac_hbm": round(k2_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 "pair_scores_per_s": round(P / (ms * 1e-3), 1)}
+        k2j, k2name, k2why = replay_profile("k2", P, N, L)
+        out["score_pose_k2"].update(
+            {"traffic": k2j["hbm_bytes_per_launch"], "traffic_kernel_us": k2j["kernel_us_trace_avg"],
+             "traffic_over_algorithmic": round(k2j["hbm_bytes_per_launch"] / k2_bytes, 3),
+             "traffic_source": "replayed from %s; source hash matches the loaded build" % k2name} if k2j
+            else {"traffic": None, "traffic_source": "none: %s" % k2why})
         # descriptor matching, the step that feeds the path: 8 images x 8000 keypoints, all 56 ordered
         # pairs.  (i) the all-f32 kernel against the f32-input MFMA peak (useful flop = 2*K*K*128 per pair);
         # (ii) the default screened path (f16 matrix-core screen + exact f32 verification, identical output)
@@ -400,6 +462,84 @@ def main():
                             "round_launches": info_t["rounds"], "query_ms": round(1e3 * t_q, 2),
                             "correspondences_returned": int(qres[2].sum().item())}
 
+    if rank == 0 and world == 1 and not args.no_variants and not args.fixed_budget:
+        # ---- SURVEY 8d's other settings of config 2 (same kernel, same 10 000 pairs; never `value`) -------------------
+        def run_variant(batch, thr_v, reps=3):
+            dbv = eng.upload(batch["x1"], batch["y1"], batch["x2"], batch["y2"], batch["offsets"], thr_v, seed=seed, pair_id_base=pair_base)
+            ev_, mv_ = eng.estimate_pose_batch(dbv)
+            torch.cuda.synchronize()
+            a_, z_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(reps):
+                ev_, mv_ = eng.estimate_pose_batch(dbv)
+            z_.record()
+            torch.cuda.synchronize()
+            ms_ = a_.elapsed_time(z_) / reps
+            gv = eng.edges_to_numpy(ev_)
+            okv = gv["status"] == 1
+            Pv = len(gv)
+            ev_deg = np.array([S.rot_err_deg(gv["R"][i].reshape(3, 3), batch["R"][i]) if okv[i] else np.inf for i in range(Pv)])
+            rows_v = int(batch["offsets"][-1])
+            return {"edges_per_s": round(Pv / (ms_ * 1e-3), 1), "kernel_ms": round(ms_, 3), "rows": rows_v,
+                    "rows_per_s": round(rows_v / (ms_ * 1e-3), 1), "rot_err_auc_at_5deg": round(S.auc_at(ev_deg, 5.0), 4),
+                    "edges_ok": int(okv.sum()), "mean_hypotheses": round(float(gv["iters"].mean()), 1)}
+        variants = {}
+        t0 = time.time()
+        variants["thr_0.4px"] = dict(run_variant(b, 0.4 / S.FOCAL_PX), note="the reference's default threshold (examples/cpp_example.cpp:51)")
+        ids_v = np.arange(pair_base, pair_base + P)
+        sizes_v = S.ragged_sizes(ids_v)
+        variants["ragged_N_U50_4000"] = dict(run_variant(S.make_batch(ids_v, sizes_v), thr),
+                                             note="N ~ U{50..4000} per pair: bucketed on the device into occupancy classes, one launch per class")
+        for rho_v in (0.3, 0.7):
+            variants["inlier_ratio_%.1f" % rho_v] = run_variant(S.make_batch(ids_v, N, inlier_ratio=rho_v), thr)
+        variants["seconds_incl_generation"] = round(time.time() - t0, 1)
+        out["variants"] = variants
+        # ---- graph level (BASELINE configs 3 / 4 / 5 on their surrogates; 1DSfM data is on neither box): the C++ host layer
+        # (tests/cpp/test_distributed.cpp: PoseGraphBuilder::estimateAndAverage / run + averageRotations) as a child process,
+        # its own wall clock, warm repetition; global rotation error after gauge alignment, AUC@5 of the estimated edges
+        from pyposegraphbuilder import scenes as SC
+        import tempfile
+        graphs = {}
+        if os.path.exists(SC.EXE):
+            with tempfile.TemporaryDirectory() as tmpd:
+                for name, label in (("v340", "config 3 surrogate: 340 views"), ("v5000", "configs 4/5 surrogate: 5000 views")):
+                    g, wave = SC.make_scene(name)
+                    V_g, P_g = len(g["R_gt"]), len(g["pairs"])
+                    scene_path = os.path.join(tmpd, name + ".bin")
+                    SC.write_scene(scene_path, g, wave, sim_kind=2)
+                    entry = {"what": label, "views": V_g, "candidate_pairs": P_g, "rows": int(g["batch"]["offsets"][-1]), "wave": wave}
+                    lut = {(int(i), int(j)): e for e, (i, j) in enumerate(g["pairs"])}
+                    for mode in ("shard", "waves", "waves_guided"):
+                        prefix = os.path.join(tmpd, "%s_%s" % (name, mode))
+                        so = SC.run_ranks([SC.EXE, scene_path, prefix, mode], 1, extra_env={"PGI_DRIVER_REPS": "2"})[0]
+                        sec_graph, sec_avg = SC.seconds_of(so)
+                        blob = open(prefix + ".0", "rb").read()
+                        gerr = SC.align_error_deg(SC.rotations_of(blob, V_g), g["R_gt"])
+                        m = {"seconds": round(sec_graph + sec_avg, 4), "seconds_graph": round(sec_graph, 4),
+                             "seconds_rotation_averaging": round(sec_avg, 4) if mode != "shard" else "inside seconds_graph",
+                             "global_rot_err_deg_mean": round(float(gerr.mean()), 4), "global_rot_err_deg_median": round(float(np.median(gerr)), 4)}
+                        if mode == "shard":
+                            hdr, ed = SC.read_shard(blob, P_g)
+                            oke = ed["status"] == 1
+                            eerr = np.array([S.rot_err_deg(ed["R"][e].reshape(3, 3), g["batch"]["R"][e]) if oke[e] else np.inf for e in range(P_g)])
+                            keep = ~g["wrong"]   # wrongly retrieved pairs have no true pose: recall is over the real pairs
+                            m.update(edges=int(hdr[1]), edge_rot_err_auc_at_5deg=round(S.auc_at(eerr[keep], 5.0), 4),
+                                     pairs_per_s=round(P_g / sec_graph, 1))
+                        else:
+                            stt, ged = SC.read_waves(blob)
+                            eerr = np.array([S.rot_err_deg(r["R"].reshape(3, 3), g["batch"]["R"][lut[(int(r["src"]), int(r["dst"]))]]) for r in ged])
+                            real = int((~g["wrong"]).sum())
+                            m.update(edges=int(stt["graph_edges"]), waves=int(stt["waves"]), poses_from_guess=int(stt["poses_from_guess"]),
+                                     quirk_only_guesses=int(stt["quirk_only_guesses"]), hypotheses=int(stt["hypotheses"]),
+                                     edge_rot_err_auc_at_5deg=round(float(np.sum(5.0 - eerr[eerr < 5.0]) / (5.0 * real)), 4),
+                                     pairs_per_s=round(P_g / sec_graph, 1))
+                        entry[{"shard": "config4_shard_estimate_gather_average", "waves": "config5_astar_waves_reference_guesses",
+                               "waves_guided": "config5_astar_waves_rotation_guided"}[mode]] = m
+                    graphs[name] = entry
+        else:
+            graphs["skipped"] = "host driver %s not built" % SC.EXE
+        out["graphs"] = graphs
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),
         # same inputs / seeds / mode, all host cores, bounded sample; also re-checks parity on that sample
@@ -426,13 +566,28 @@ def main():
                                "sample": "first %d pairs of the same batch (%.1f s); build CPU restatement, not OpenCV" % (m, t_cpu),
                                "gpu_matches_on_sample": parity}
     if world > 1:
-        # every rank must hold every rank's records after the exchange (checked outside the timed region)
-        g = eng.edges_to_numpy(gathered)
-        mine = g[rank * P:(rank + 1) * P]
-        okx = bool(np.array_equal(mine["E"], got["E"]) and np.array_equal(mine["n_inl"], got["n_inl"]))
+        # every rank must hold EVERY rank's records after the exchange (checked outside the timed region): the owners
+        # publish byte checksums of their blocks through torch.distributed, every rank checks all blocks of its copies
+        def checksum(t):
+            return int(t.to(torch.int64).sum().item()) if t.numel() else 0
+        mine_sums = torch.tensor([checksum(edges), checksum(edges[:counts_uneven[rank]]) if comm is not None else 0],
+                                 dtype=torch.int64, device=eng.device)
+        all_sums = [torch.zeros_like(mine_sums) for _ in range(world)]
+        dist.all_gather(all_sums, mine_sums)
+        okx = bool(torch.equal(gathered[rank * P:(rank + 1) * P], edges))
+        o_u = 0
+        for r in range(world):
+            okx = okx and checksum(gathered[r * P:(r + 1) * P]) == int(all_sums[r][0].item())
+            if comm is not None:
+                okx = okx and checksum(gathered_uneven[o_u:o_u + counts_uneven[r]]) == int(all_sums[r][1].item())
+                o_u += counts_uneven[r]
         flag = torch.tensor([1 if okx else 0], dtype=torch.int32, device=eng.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         out["exchange_verified"] = bool(flag.item())
+        if args.require_rccl and not out["exchange_verified"]:
+            if rank == 0:
+                print(json.dumps(out))
+            raise SystemExit("bench.py --require-rccl: a rank holds records that differ from their owner's")
     if rank == 0:
         print(json.dumps(out))
     if comm is not None:

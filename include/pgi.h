@@ -135,8 +135,8 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_ed
 
 /* Host buffers in, host buffers out (synchronous).  Same result as pgi_estimate_pose_batch on the same rows, ids and
  * seed; internally the batch travels in chunks (a small first one, then multiples of the number of workgroups the
- * device keeps resident) through three device slots on three streams, so PCIe copies overlap the kernels and the
- * tail of one chunk's kernel overlaps the head of the next.  h_guess_Rt / h_has_guess may both be NULL.
+ * device keeps resident) through four device slots, two alternating kernel streams and one high-priority copy stream,
+ * so PCIe copies overlap the kernels and the tail of one chunk's kernel overlaps the head of the next.  h_guess_Rt / h_has_guess may both be NULL.
  * h_masks: one byte per row.  Fastest with page-locked buffers (pgi_host_register / hipHostMalloc): when the four
  * coordinate arrays, h_edges and h_masks are all page-locked the kernel works on them in place over PCIe (each row is read
  * once, each result written once; no copy through HBM).  Same results either way. */
@@ -230,8 +230,11 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
  * replicated rotation averaging / the next scheduler wave.  Two transports:
  *   RCCL  (production: one GPU per rank, xGMI): rank 0 calls pgi_comm_unique_id, the caller ships the
  *         128 bytes to the other ranks (any bootstrap: TCP, torch.distributed, MPI), every rank calls
- *         pgi_comm_init_rccl.  Uneven blocks are gathered without padding as one grouped set of
- *         ncclBroadcast(root = r) calls on the context stream (asynchronous).
+ *         pgi_comm_init_rccl.  Equal blocks: one ncclAllGather.  Uneven blocks are gathered without padding
+ *         as one group of point-to-point ncclSend / ncclRecv (every rank pushes its block to its world-1 peers
+ *         over world-1 different xGMI links) on the context stream (asynchronous).  pgi_comm_init_rccl is
+ *         a collective: call pgi_comm_rccl_probe on every rank first and agree on the result, so that no rank
+ *         enters it alone (host/distributed.cpp attach(), pyposegraphbuilder.distributed.Communicator do).
  *   host  (ranks sharing a device -- RCCL refuses that -- and CPU-side tests): the caller supplies an
  *         all-gather-v over host memory; the records make a D2H / H2D hop (synchronous).
  * Without a communicator (single process) pgi_allgather_edges degenerates to a device copy. */
@@ -239,6 +242,9 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
 /* gathers send_bytes from every rank into recv (rank order); recv_bytes[r] = bytes of rank r; 0 = ok */
 typedef int (*pgi_allgatherv_fn)(void* user, const void* h_send, uint64_t send_bytes, void* h_recv,
                                  const uint64_t* recv_bytes, uint32_t world);
+/* 0 iff librccl could be opened and carries every entry point this library needs (no collective, no device
+ * call); *version (optional) = ncclGetVersion's code, e.g. 22606, or 0 when unknown */
+int pgi_comm_rccl_probe(int* version);
 int pgi_comm_unique_id(uint8_t id[PGI_COMM_ID_BYTES]);
 int pgi_comm_init_rccl(pgi_ctx* ctx, uint32_t world, uint32_t rank, const uint8_t id[PGI_COMM_ID_BYTES]);
 int pgi_comm_init_host(pgi_ctx* ctx, uint32_t world, uint32_t rank, pgi_allgatherv_fn fn, void* user);

@@ -6,7 +6,7 @@
 //   RCCL : librccl is opened at run time (dlopen; a process that already carries torch's copy reuses it), so
 //          libpgi.so has no link-time dependency on it and single-GPU users never load it.  Equal blocks use
 //          ncclAllGather; uneven blocks (sum(N)-balanced shards, partial scheduler waves) are exchanged without
-//          padding as one group of point-to-point ncclSend/ncclRecv -- xGMI is a full mesh of point-to-point
+//          padding as one group of point-to-point ncclSend/ncclRecv (always closed, also on errors) -- xGMI is a full mesh of point-to-point
 //          links, so every rank pushes its block to its 7 peers over 7 different links.
 //   host : an all-gather-v callback over host memory (ranks that share one device -- RCCL rejects duplicate
 //          devices -- and CPU-side tests); the records make one D2H and one H2D hop.
@@ -31,6 +31,7 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     std::string error;
 };
 
@@ -64,6 +65,7 @@ static RcclApi* rccl_api() {
         api.Recv = (decltype(api.Recv))sym("ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetVersion = (decltype(api.GetVersion))dlsym(api.handle, "ncclGetVersion");  // optional
     });
     return &api;
 }
@@ -104,13 +106,26 @@ static int allgatherv_locked(pgi_ctx* ctx, const void* d_local, const uint64_t* 
             return PGI_SUCCESS;
         }
         if (mine && !in_place) HIP_TRY(hipMemcpyAsync(all + off[rank], d_local, mine, hipMemcpyDeviceToDevice, ctx->stream));
+        // A group that was opened is ALWAYS closed: an early return between GroupStart and GroupEnd would leave the group
+        // open on this thread and every later RCCL call would only be queued.  The first error is kept, the remaining
+        // calls of the group are skipped, GroupEnd runs, then the call fails.
         RCCL_TRY(api, api->GroupStart());
-        for (uint32_t k = 1; k < world; ++k) {  // peer order rotated by rank: every link is busy from the first step
+        ncclResult_t first = ncclSuccess;
+        const char* what = "";
+        for (uint32_t k = 1; k < world && first == ncclSuccess; ++k) {  // peer order rotated by rank: every link is busy from the first step
             const uint32_t to = (rank + k) % world, from = (rank + world - k) % world;
-            if (mine) RCCL_TRY(api, api->Send(d_local, (size_t)mine, ncclChar, (int)to, comm, ctx->stream));
-            if (h_bytes[from]) RCCL_TRY(api, api->Recv(all + off[from], (size_t)h_bytes[from], ncclChar, (int)from, comm, ctx->stream));
+            if (mine) {
+                first = api->Send(d_local, (size_t)mine, ncclChar, (int)to, comm, ctx->stream);
+                what = "ncclSend";
+            }
+            if (first == ncclSuccess && h_bytes[from]) {
+                first = api->Recv(all + off[from], (size_t)h_bytes[from], ncclChar, (int)from, comm, ctx->stream);
+                what = "ncclRecv";
+            }
         }
-        RCCL_TRY(api, api->GroupEnd());
+        const ncclResult_t ended = api->GroupEnd();
+        if (first != ncclSuccess) return fail(PGI_ERR_COMM, std::string(what) + ": " + api->GetErrorString(first));
+        if (ended != ncclSuccess) return fail(PGI_ERR_COMM, std::string("ncclGroupEnd: ") + api->GetErrorString(ended));
         return PGI_SUCCESS;
     }
     // host transport
@@ -138,6 +153,14 @@ int pgi_comm_unique_id(uint8_t id[PGI_COMM_ID_BYTES]) {
     ncclUniqueId u;
     RCCL_TRY(api, api->GetUniqueId(&u));
     memcpy(id, &u, sizeof u);
+    return PGI_SUCCESS;
+}
+
+int pgi_comm_rccl_probe(int* version) {
+    RcclApi* api = rccl_api();
+    if (version) *version = 0;
+    if (!api->error.empty()) return fail(PGI_ERR_COMM, api->error);
+    if (version && api->GetVersion) (void)api->GetVersion(version);
     return PGI_SUCCESS;
 }
 

@@ -57,6 +57,20 @@ Transport attach(Engine& engine, HostComm& comm, Transport want) {
         want = distinct ? Transport::Rccl : Transport::Host;
     }
     if (want == Transport::Rccl) {
+        // ncclCommInitRank is a collective: a rank that fails BEFORE it (librccl missing, a broken device) would leave the
+        // others blocked inside it for ever.  So every step that can fail on one rank only is followed by an agreement
+        // round over the host star, and the ranks either all hold a communicator or all throw.
+        auto agree = [&](bool mine, const char* what) {
+            const std::vector<uint8_t> all = comm.allgather<uint8_t>(mine ? 1 : 0);
+            std::string bad;
+            for (size_t r = 0; r < all.size(); ++r)
+                if (!all[r]) bad += (bad.empty() ? "" : ",") + std::to_string(r);
+            if (!bad.empty())
+                throw PgiError(std::string("attach: ") + what + " failed on rank(s) " + bad + (mine ? "" : std::string(": ") + pgi_last_error()));
+        };
+        int dev = 0;
+        const bool usable = pgi_comm_rccl_probe(nullptr) == PGI_SUCCESS && hipGetDevice(&dev) == hipSuccess;
+        agree(usable, "opening RCCL");
         uint8_t id[PGI_COMM_ID_BYTES] = {0};
         int rc = 0;
         if (comm.rank() == 0) rc = pgi_comm_unique_id(id);
@@ -64,7 +78,13 @@ Transport attach(Engine& engine, HostComm& comm, Transport want) {
         comm.broadcast(&ok, 4);
         if (!ok) throw PgiError(std::string("attach: ") + (comm.rank() == 0 ? pgi_last_error() : "rank 0 could not create the RCCL id"));
         comm.broadcast(id, sizeof id);
-        Engine::check(pgi_comm_init_rccl(engine.get(), comm.world(), comm.rank(), id));
+        rc = pgi_comm_init_rccl(engine.get(), comm.world(), comm.rank(), id);
+        try {
+            agree(rc == PGI_SUCCESS, "pgi_comm_init_rccl");
+        } catch (...) {
+            if (rc == PGI_SUCCESS) (void)pgi_comm_destroy(engine.get());
+            throw;
+        }
         return Transport::Rccl;
     }
     Engine::check(pgi_comm_init_host(engine.get(), comm.world(), comm.rank(), &HostComm::transportCallback, &comm));

@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -44,6 +45,8 @@ struct LaunchEnv {
 class HostComm {
    public:
     // rank 0 listens on masterPort + portOffset (the launcher's own store owns masterPort itself)
+    // timeoutSeconds: rendezvous (connect / accept); ioTimeoutSeconds: any later receive (a wave of config 5 keeps a rank
+    // busy for well under a second; an hour only guards against a peer that is gone) -- env PGI_COMM_TIMEOUT overrides it
     explicit HostComm(const LaunchEnv& env, int portOffset = 41, double timeoutSeconds = 120.0);
     ~HostComm();
     HostComm(const HostComm&) = delete;
@@ -68,6 +71,7 @@ class HostComm {
 
    protected:
     LaunchEnv env;
+    double ioTimeoutSeconds = 3600.0;
     std::vector<int> peers;  // rank 0: socket of rank r at [r]; other ranks: [0] = socket to rank 0
     int listener = -1;
 };
@@ -102,7 +106,8 @@ inline void recvAll(int fd, void* buf, size_t n) {
     char* p = (char*)buf;
     while (n) {
         const ssize_t k = ::recv(fd, p, n, 0);
-        if (k <= 0) throw PgiError("HostComm: peer closed the connection");
+        if (k <= 0) throw PgiError(k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK) ? "HostComm: timed out waiting for a peer"
+                                                                                         : "HostComm: peer closed the connection");
         p += k;
         n -= (size_t)k;
     }
@@ -110,6 +115,14 @@ inline void recvAll(int fd, void* buf, size_t n) {
 inline void noDelay(int fd) {
     int one = 1;
     (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+}
+// A peer that died must not block the others for ever: receives (and accept on the listener) give up after `seconds`
+// (recv / accept then fail with EAGAIN and the caller throws).
+inline void recvTimeout(int fd, double seconds) {
+    timeval tv{};
+    tv.tv_sec = (long)seconds;
+    tv.tv_usec = (long)((seconds - (double)tv.tv_sec) * 1e6);
+    (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
 }
 }  // namespace detail
 
@@ -126,6 +139,7 @@ inline LaunchEnv LaunchEnv::fromEnvironment() {
 
 inline HostComm::HostComm(const LaunchEnv& env_, int portOffset, double timeoutSeconds) : env(env_) {
     if (env.world <= 1) return;
+    if (const char* t = std::getenv("PGI_COMM_TIMEOUT")) ioTimeoutSeconds = std::max(1.0, std::atof(t));
     const int port = env.masterPort + portOffset;
     if (env.rank == 0) {
         listener = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -139,10 +153,12 @@ inline HostComm::HostComm(const LaunchEnv& env_, int portOffset, double timeoutS
         if (::bind(listener, (sockaddr*)&a, sizeof a) != 0 || ::listen(listener, (int)env.world) != 0)
             throw PgiError("HostComm: cannot listen on port " + std::to_string(port));
         peers.assign(env.world, -1);
+        detail::recvTimeout(listener, timeoutSeconds);  // accept() honours SO_RCVTIMEO
         for (uint32_t k = 1; k < env.world; ++k) {
             const int fd = ::accept(listener, nullptr, nullptr);
-            if (fd < 0) throw PgiError("HostComm: accept failed");
+            if (fd < 0) throw PgiError("HostComm: rank 0 timed out waiting for " + std::to_string(env.world - k) + " rank(s) to connect");
             detail::noDelay(fd);
+            detail::recvTimeout(fd, ioTimeoutSeconds);
             uint32_t r = 0;
             detail::recvAll(fd, &r, 4);
             if (r == 0 || r >= env.world || peers[r] >= 0) throw PgiError("HostComm: unexpected rank in handshake");
@@ -167,6 +183,7 @@ inline HostComm::HostComm(const LaunchEnv& env_, int portOffset, double timeoutS
         freeaddrinfo(res);
         if (fd < 0) throw PgiError("HostComm: cannot reach rank 0 at " + env.masterAddr + ":" + std::to_string(port));
         detail::noDelay(fd);
+        detail::recvTimeout(fd, ioTimeoutSeconds);
         detail::sendAll(fd, &env.rank, 4);
         peers.assign(1, fd);
     }

@@ -177,30 +177,29 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     memset(guess, 0, L * 96);
     memset(has, 0, L);
     bool any_guess = false;
-    {   // conversion in parallel over contiguous, row-balanced ranges of pairs
+    for (size_t k = 0; k < L; ++k) {  // per-pair arrays: every pair, also those without rows
+        const ViewPair& vp = pairs[lo + k];
+        thr[k] = vp.normalizedThreshold;
+        if (!vp.poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
+            const SE3d& g = vp.poseGuesses.back();
+            for (int c2 = 0; c2 < 9; ++c2) guess[12 * k + c2] = g.R[c2];
+            for (int c2 = 0; c2 < 3; ++c2) guess[12 * k + 9 + c2] = g.t[c2];
+            has[k] = 1;
+            any_guess = true;
+        }
+    }
+    {   // row conversion in parallel over contiguous, row-balanced ranges of pairs
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, kCoreNumber ? kCoreNumber : 1), std::min<size_t>(hw, rows / 65536 + 1)));
-        std::vector<uint8_t> any(nt, 0);
         auto work = [&](size_t t) {
-            const uint64_t r0 = rows * t / nt, r1 = t + 1 == nt ? rows + 1 : rows * (t + 1) / nt;  // (trailing empty pairs start at `rows`)
-            size_t k = (size_t)(std::upper_bound(off.begin(), off.end(), r0) - off.begin());
-            k = k ? k - 1 : 0;
-            while (k < L && off[k] < r0) ++k;  // pairs starting inside [r0, r1)
-            for (; k < L && off[k] < r1; ++k) {
-                const ViewPair& vp = pairs[lo + k];
-                const CorrespondenceMatrix& c = vp.correspondences;
+            const uint64_t r0 = rows * t / nt, r1 = t + 1 == nt ? rows : rows * (t + 1) / nt;
+            // pairs whose first row lies in [r0, r1): the first k with off[k] >= r0 (pairs without rows convert nothing)
+            for (size_t k = (size_t)(std::lower_bound(off.begin(), off.end(), r0) - off.begin()); k < L && off[k] < r1; ++k) {
+                const CorrespondenceMatrix& c = pairs[lo + k].correspondences;
                 for (int r = 0; r < c.rows; ++r) {
                     const double* q = c.ptr(r);
                     const size_t o = off[k] + (size_t)r;
                     x1[o] = (float)q[0]; y1[o] = (float)q[1]; x2[o] = (float)q[2]; y2[o] = (float)q[3];
-                }
-                thr[k] = vp.normalizedThreshold;
-                if (!vp.poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
-                    const SE3d& g = vp.poseGuesses.back();
-                    for (int c2 = 0; c2 < 9; ++c2) guess[12 * k + c2] = g.R[c2];
-                    for (int c2 = 0; c2 < 3; ++c2) guess[12 * k + 9 + c2] = g.t[c2];
-                    has[k] = 1;
-                    any[t] = 1;
                 }
             }
         };
@@ -208,7 +207,6 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
         work(0);
         for (std::thread& th : pool) th.join();
-        for (uint8_t a : any) any_guess |= a != 0;
     }
     mark("rows f64 AoS -> f32 SoA (host)");
     // the gathered table (P records); this rank's block is written in place at [lo, hi)
@@ -218,6 +216,8 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         own_all.reset(new DevBuf(P * sizeof(pgi_edge)));
         d_all = own_all->as<pgi_edge>();
     }
+    std::vector<uint8_t> screened;        // this block's pairs that carried a chained pose into the screening launch
+    std::vector<uint32_t> guessInliers;   // their inlier counts under the SQUARED bound (1.5 thr)^2
     if (L) {
         char* db = (char*)staging->dev;
         h2d(db, hb, any_guess ? host_total : o_guess);  // one copy out of page-locked memory
@@ -228,6 +228,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         b.d_guess_Rt = nullptr; b.d_has_guess = nullptr;
         b.n_pairs = (uint32_t)L; b.max_corr = max_corr; b.pair_id_base = lo; b.seed = seed;  // ids = positions in `pairs`
         if (any_guess && screenGuesses) {
+            screened.assign(has, has + L);
             // InTraversalPoseTester::test for every chained pose of the block in ONE launch:
             // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
             std::vector<double> Eg(9 * L, 0.0), tau2(L, 0.0);
@@ -242,10 +243,10 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             h2d(dtau.p, tau2.data(), L * 8);
             Engine::check(pgi_score_pose_batch(engine->get(), &b, dE.as<double>(), dtau.as<double>(), dcnt.as<uint32_t>(), nullptr));
             Engine::check(pgi_synchronize(engine->get()));
-            std::vector<uint32_t> cnt(L);
-            d2h(cnt.data(), dcnt.p, L * 4);
+            guessInliers.resize(L);
+            d2h(guessInliers.data(), dcnt.p, L * 4);
             for (size_t k = 0; k < L; ++k)
-                if (has[k] && cnt[k] < 5) has[k] = 0;
+                if (has[k] && guessInliers[k] < 5) has[k] = 0;
             h2d(db + o_has, has, L);  // the screened flags replace the uploaded ones
         }
         if (any_guess) {
@@ -275,6 +276,25 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         ++added;
     }
     mark("pose graph insertion");
+    // Guard for the reference-faithful guess path (guess_quirk = 1, graph_traversal.h:149,164): a chained pose passes the
+    // 5-inlier tester, then getInliers compares SQUARED residuals with the UN-squared bound and almost any pose collects
+    // kMinimumInlierNumber rows.  Count the accepted guesses that would have failed under the squared bound: those edges
+    // exist only because of the quirk (on thin graphs they are what spoils the averaged rotations).
+    if (!screened.empty()) {
+        uint64_t quirkOnly = 0;
+        for (size_t k = 0; k < L; ++k)
+            if (screened[k] && edges[lo + k].used_guess && edges[lo + k].status == PGI_EDGE_OK && guessInliers[k] < kMinimumInlierNumber)
+                ++quirkOnly;
+        lastQuirkOnlyGuesses = quirkOnly;
+    } else {
+        lastQuirkOnlyGuesses = 0;
+    }
+    if (world > 1 && screenGuesses) {  // host-side bookkeeping, 8 bytes per rank
+        uint64_t sum = 0;
+        for (uint64_t v : hostComm->allgather(lastQuirkOnlyGuesses)) sum += v;
+        lastQuirkOnlyGuesses = sum;
+    }
+    if (screenGuesses) statistics.addCount("[Pose estimation] Quirk-only guesses", lastQuirkOnlyGuesses, P);
     // observability keys of pose_graph_builder.h:636-638 (one timed event per batch, one run per pair)
     statistics.addTime("[Pose estimation]", std::chrono::duration<double>(Clock::now() - t0).count(), P);
     statistics.addCount("[Pose estimation] Runs", P, P);
@@ -395,6 +415,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
             st.posesFromGuess += edges[i].used_guess;
             if (edges[i].status == PGI_EDGE_OK) visibilityTable.addLink(wave[i].src, wave[i].dst);  // :692
         }
+        st.quirkOnlyGuesses += lastQuirkOnlyGuesses;
         statistics.addTime("[Visibility update]", std::chrono::duration<double>(Clock::now() - t1).count(), added);  // :698-699
         statistics.addCount("[Visibility update] Runs", added, added);
         st.edgesAdded += added;
@@ -691,7 +712,10 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
         }
         tick = Clock::now();
+        std::vector<uint8_t> screened;      // pairs that carried a chained pose into the screening launch
+        std::vector<uint32_t> guessInliers; // their inlier counts under the squared bound (1.5 thr)^2
         if (anyGuess) {
+            screened = has;
             std::vector<double> thr(P), Eg(9 * P, 0.0), tau2(P, 0.0);
             Engine::check(pgi_synchronize(ctx));
             d2h(thr.data(), dthr.p, P * 8);
@@ -709,10 +733,10 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             h2d(dtau.p, tau2.data(), P * 8);
             Engine::check(pgi_score_pose_batch(ctx, &b, dE.as<double>(), dtau.as<double>(), dscore.as<uint32_t>(), nullptr));
             Engine::check(pgi_synchronize(ctx));
-            std::vector<uint32_t> cnt(P);
-            d2h(cnt.data(), dscore.p, P * 4);
+            guessInliers.resize(P);
+            d2h(guessInliers.data(), dscore.p, P * 4);
             for (size_t k = 0; k < P; ++k)
-                if (has[k] && cnt[k] < 5) has[k] = 0;
+                if (has[k] && guessInliers[k] < 5) has[k] = 0;
             h2d(dguess.p, guess.data(), P * 96);
             h2d(dhas.p, has.data(), P);
             b.d_guess_Rt = dguess.as<double>();
@@ -737,6 +761,13 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 statistics.addTime("[Pose estimation]", dt, runs);
                 statistics.addCount("[Pose estimation] Runs", runs, runs);
                 statistics.addCount("[Pose estimation] Inlier number", inl, runs);
+            }
+            if (!screened.empty()) {  // accepted guesses that only the un-squared getInliers bound let through (see estimatePoses)
+                size_t quirkOnly = 0;
+                for (size_t k = 0; k < P; ++k)
+                    if (screened[k] && edges[k].used_guess && edges[k].status == PGI_EDGE_OK && guessInliers[k] < kMinimumInlierNumber)
+                        ++quirkOnly;
+                statistics.addCount("[Pose estimation] Quirk-only guesses", quirkOnly, runs);
             }
         }
         tick = Clock::now();

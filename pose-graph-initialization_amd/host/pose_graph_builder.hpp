@@ -404,6 +404,9 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     struct RunStatistics {  // the reference's RunningStatistics keys that concern this path (utils.h:15-73)
         size_t pairsProcessed = 0, edgesAdded = 0, pathsSearched = 0, pathsFound = 0, touchedNodes = 0,
                posesFromGuess = 0, hypotheses = 0, waves = 0;
+        // accepted A* guesses whose inlier count under the SQUARED bound (1.5 thr)^2 is below kMinimumInlierNumber: edges
+        // that exist only through the reference's un-squared getInliers bound (graph_traversal.h:149,164)
+        size_t quirkOnlyGuesses = 0;
     };
 
     // Wave-scheduled run over caller-provided candidate pairs (the image / feature / matching stages of
@@ -498,6 +501,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // (defined in the implementation file: HIP stays out of this header)
     struct Staging;
     std::shared_ptr<Staging> staging;
+    uint64_t lastQuirkOnlyGuesses = 0;  // of the last estimatePoses call (all ranks)
 };
 
 namespace pose {

@@ -54,7 +54,7 @@ SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_crea
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
            "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch",
            "pgi_get_params", "pgi_rotation_average_edges", "pgi_comm_unique_id", "pgi_comm_init_rccl", "pgi_comm_init_host",
-           "pgi_comm_destroy", "pgi_comm_info", "pgi_allgather_edges", "pgi_allgatherv", "pgi_host_register", "pgi_host_unregister",
+           "pgi_comm_destroy", "pgi_comm_info", "pgi_comm_rccl_probe", "pgi_allgather_edges", "pgi_allgatherv", "pgi_host_register", "pgi_host_unregister",
            "pgi_tracklets_create", "pgi_tracklets_destroy", "pgi_tracklets_add_batch", "pgi_tracklets_get_batch",
            "pgi_tracklets_info", "pgi_tracklets_track"]
 COMM_ID_BYTES = 128
@@ -176,3 +176,16 @@ def default_params(**kw):
             raise TypeError("unknown parameter %r" % k)
         setattr(p, k, v)
     return p
+
+
+def kernel_source_sha256(files=("csrc/pgi_kernels.hip", "csrc/pgi_device.hpp")):
+    """sha256 over the sources of the pose-estimation kernels (K1/K2/K3), in the given order.  Profile summaries under
+    profiles/ record it (scripts/k1_pmc_json.py); bench.py replays their counters only while it still matches the
+    sources the loaded library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_PKG)
+    for f in files:
+        with open(os.path.join(root, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

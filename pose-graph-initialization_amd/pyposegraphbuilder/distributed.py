@@ -45,6 +45,7 @@ class Communicator:
         self.engine, self.group = engine, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.transport = "none"
+        self.rccl_version = 0
         if self.world == 1:
             return
         if transport == "auto":
@@ -59,6 +60,13 @@ class Communicator:
             # Every step that can fail on one rank only is followed by an agreement round, so that the ranks either all
             # hold a communicator or all raise (a rank that raises alone would leave the others blocked in a collective).
             ident, err = [None], None
+            ver = C.c_int(0)
+            usable = lib.pgi_comm_rccl_probe(C.byref(ver)) == 0  # librccl opens and has every entry point (no collective yet)
+            probes = [None] * self.world
+            dist.all_gather_object(probes, (usable, "" if usable else L.last_error()), group=group)
+            if not all(p[0] for p in probes):
+                raise L.PgiError("RCCL is not usable on rank(s) %s" % {r: p[1] for r, p in enumerate(probes) if not p[0]})
+            self.rccl_version = int(ver.value)
             if self.rank == 0:
                 buf = (C.c_uint8 * L.COMM_ID_BYTES)()
                 rc = lib.pgi_comm_unique_id(buf)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 PMC summaries of scripts/profile_k1_r02.sh (gpurun_out/r02_k1_*_summary.txt) into
-profiles/r02_k1_pmc.json: HBM traffic (with the gfx950 FETCH_SIZE correction), the wave-lifetime split, and the
+"""Turns the rocprofv3 PMC summaries of scripts/profile_k1.sh <tag> (gpurun_out/<tag>_k1_*_summary.txt) into
+profiles/<tag>_k1_pmc.json (usage: k1_pmc_json.py r03 [git head]): HBM traffic (with the gfx950 FETCH_SIZE correction), the wave-lifetime split, and the
 EXECUTED floating-point work per launch for an honest compute roofline next to the (nominated) HBM one.
 
 flop counting: SQ_INSTS_VALU_{ADD,MUL,TRANS}_Fxx count wave-instructions (1 flop per lane), SQ_INSTS_VALU_FMA_Fxx 2 flop
@@ -16,9 +16,12 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PEAK_F32, PEAK_F64 = 157.3e12, 78.6e12
 
 
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+
+
 def read(tag, kernel="estimate_pose_kernel<2, false>"):
     vals, avg_us, calls = {}, None, None
-    for line in open(os.path.join(OUT, "r02_k1_%s_summary.txt" % tag)):
+    for line in open(os.path.join(OUT, "%s_k1_%s_summary.txt" % (TAG, tag))):
         if kernel not in line:
             continue
         m = re.search(r"(\S+)\s+n=(\d+)\s+sum=(\S+)", line)
@@ -46,8 +49,13 @@ def main():
     wc = c["SQ_WAVE_CYCLES"]
     out = {
         "kernel": "pgi::estimate_pose_kernel<2, false> (hybrid rows: 1280 in LDS, 720 from L2)", "pairs": 10000, "corrs": 2000,
-        "source": "rocprofv3 --kernel-trace --pmc ... (separate passes, scripts/profile_k1_r02.sh); sums / dispatches; "
-                  "summaries in profiles/r02_k1_rocprofv3_summary.txt",
+        "profile_tag": TAG,
+        "source": "rocprofv3 --kernel-trace --pmc ... (separate passes, scripts/profile_k1.sh %s); sums / dispatches; "
+                  "summaries in profiles/%s_k1_rocprofv3_summary.txt" % (TAG, TAG),
+        # ties these counters to the kernels that were timed: bench.py replays them only while this hash equals the hash
+        # of the sources it runs (pyposegraphbuilder._lib.kernel_source_sha256: csrc/pgi_kernels.hip + pgi_device.hpp)
+        "source_sha256": open(os.path.join(OUT, "%s_k1_source_sha256.txt" % TAG)).read().strip(),
+        "git_head": sys.argv[2] if len(sys.argv) > 2 else None,
         "kernel_us_trace_avg": avg_us, "dispatches": calls,
         "hbm_bytes_per_launch": round(fetch_b + write_b), "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]),
         "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
@@ -83,7 +91,7 @@ def main():
     out["valu_issue_busy_note"] = ("SQ_INSTS_VALU x 4 cycles / (shader cycles x 1024 SIMDs): the kernel is bound by vector-ALU issue, "
                                    "not by memory or latency -- the per-wave 'waiting' share is time spent behind the other three "
                                    "wavefronts of the SIMD")
-    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
+    dst = os.path.join(ROOT, "profiles", "%s_k1_pmc.json" % TAG)
     json.dump(out, open(dst, "w"), indent=2)
     print(json.dumps(out, indent=2))
 

@@ -9,6 +9,8 @@
 // single-process file byte for byte.  Scene format: tests/test_distributed_gpu.py (write_scene).
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 
@@ -50,6 +52,12 @@ int main(int argc, char** argv) {
         }
         if (!in) return 3;
         const bool waves = mode == "waves" || mode == "waves_guided";
+        // PGI_DRIVER_REPS > 1 (bench.py, scripts/config45_bench.py): the whole build -> run -> write cycle is repeated inside
+        // this process, one timing line per repetition; the last one is the warm figure (code objects, allocations, staging)
+        const int reps = std::max(1, std::atoi(std::getenv("PGI_DRIVER_REPS") ? std::getenv("PGI_DRIVER_REPS") : "1"));
+        const std::vector<PoseGraphBuilder::ViewPair> pairs0 = reps > 1 ? pairs : std::vector<PoseGraphBuilder::ViewPair>();
+        for (int rep = 0; rep < reps; ++rep) {
+        if (rep) pairs = pairs0;  // run() sorts and moves from its candidate list
         PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", waves, true, true);
         if (mode == "waves_guided") builder.setRotationGuidedGuesses(true);  // config 5: rotation-guided re-estimation
         const dist::Transport tr = dist::attach(builder.getEngine(), comm);
@@ -74,9 +82,9 @@ int main(int argc, char** argv) {
             const Clock::time_point t_avg = Clock::now();
             rot = builder.averageRotations(graph, V);
             sec_average = since(t_avg);
-            const uint64_t hdr[12] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
+            const uint64_t hdr[13] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
                                       st.posesFromGuess, st.hypotheses, st.waves, graph.numEdges(), rot.iterations, rot.edgesUsed,
-                                      builder.getStatistics().getCount("[A*] Touched nodes")};
+                                      builder.getStatistics().getCount("[A*] Touched nodes"), st.quirkOnlyGuesses};
             out.write((const char*)hdr, sizeof hdr);
             for (auto& id : graph.getEdgeIds()) {
                 const PoseGraphEdge e = graph.getEdgeById(id);
@@ -93,6 +101,7 @@ int main(int argc, char** argv) {
                     env.world, env.world == 1 ? "none" : tr == dist::Transport::Rccl ? "rccl" : "host", mode.c_str(), graph.numEdges(),
                     rot.iterations, mode == "shard" ? "estimate + gather + average" : "scheduler run (A*, estimate, gather, commit)", sec_graph,
                     sec_average);
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "test_distributed: %s\n", e.what());
         return 1;

@@ -18,7 +18,8 @@ def main():
     from pyposegraphbuilder import distributed as D
     prefix = sys.argv[1]
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    torch.cuda.set_device(0)  # both ranks share the one visible GPU
+    rccl = os.environ.get("PGI_TEST_RCCL") == "1"  # one device per rank: the records travel by RCCL inside libpgi.so
+    torch.cuda.set_device(rank if rccl else 0)     # default: both ranks share the one visible GPU (host transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     V = 120
     g = S.make_scene_graph(V, k=6, seed=4, median_corr=300, max_corr=1500, outlier_pair_frac=0.05)
@@ -27,7 +28,9 @@ def main():
     bounds = D.shard_bounds(sizes, world)
     lo, hi = bounds[rank]
     eng = Engine()
-    comm = D.Communicator(eng)
+    comm = D.Communicator(eng, transport="rccl" if rccl and world > 1 else "auto")
+    if rccl and world > 1:
+        assert eng.comm_info() == (world, rank, "rccl")
     r0, r1 = int(b["offsets"][lo]), int(b["offsets"][hi])
     db = eng.upload(b["x1"][r0:r1], b["y1"][r0:r1], b["x2"][r0:r1], b["y2"][r0:r1],
                     b["offsets"][lo:hi + 1] - b["offsets"][lo], 7.5e-4, seed=9, pair_id_base=lo)
