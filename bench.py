@@ -539,6 +539,41 @@ def main():
         else:
             graphs["skipped"] = "host driver %s not built" % SC.EXE
         out["graphs"] = graphs
+        # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
+        # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
+        # -> createCorrespondenceMatrix -> A* guesses -> estimatePose -> guided matching -> tracklets in HBM -- as a child
+        # process (tests/cpp/test_pipeline.cpp), warm repetition, its own wall clock and stage split
+        if os.path.exists(SC.PIPELINE_EXE):
+            t0 = time.time()
+            fviews, fposes, fcam, fsim, fpairs = S.make_feature_scene(340, 8000, band=20)
+            gen_f = time.time() - t0
+            with tempfile.TemporaryDirectory() as tmpd:
+                fin, fout = os.path.join(tmpd, "features.bin"), os.path.join(tmpd, "features.out")
+                SC.write_feature_scene(fin, fviews, fcam, fsim, fpairs, 512)
+                kp_mean = float(np.mean([len(v["xy"]) for v in fviews]))
+                del fviews
+                import subprocess
+                r = subprocess.run([SC.PIPELINE_EXE, fin, fout, "024"], capture_output=True, text=True, timeout=1200,
+                                   env=dict(os.environ, PGI_DRIVER_REPS="2"))
+                feat = {"views": 340, "keypoints_per_view": round(kp_mean), "candidate_pairs": len(fpairs), "wave": 512,
+                        "descriptor_bytes": int(340 * kp_mean * 512), "generation_s": round(gen_f, 1)}
+                if r.returncode == 0:
+                    tim = SC.pipeline_timings(r.stdout)
+                    res = SC.parse_pipeline(open(fout, "rb").read(), 3)
+                    for (mode, label), (stf, ef) in zip(((0, "plain_every_pair_descriptor_matched"), (2, "astar_hashing_reference_guesses"),
+                                                         (4, "astar_hashing_rotation_guided")), res):
+                        kf = dict(zip(SC.PIPELINE_KEYS, stf))
+                        errf = np.array([S.rot_err_deg(ef[key][1], fposes[key[1]][0] @ fposes[key[0]][0].T) for key in ef])
+                        feat[label] = {"features_to_graph_s": tim[mode]["seconds"], "stages_s": tim[mode]["stages"],
+                                       "pairs_per_s": round(len(fpairs) / tim[mode]["seconds"], 1), "edges": len(ef),
+                                       "descriptor_matching_runs": kf["matching_runs"], "tracklet_quick_matching_runs": kf["quick_matching_runs"],
+                                       "guided_matching_runs": kf["guided_matching_runs"], "tracks": kf["track_number"],
+                                       "poses_from_guess": kf["poses_from_guess"], "quirk_only_guesses": kf["quirk_only_guesses"],
+                                       "edge_rot_err_auc_at_5deg": round(S.auc_at(np.concatenate([errf, np.full(len(fpairs) - len(ef), np.inf)]), 5.0), 4),
+                                       "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
+                else:
+                    feat["error"] = r.stderr[-500:]
+            out["config3_from_features"] = feat
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),

@@ -180,6 +180,19 @@ int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr_aos, const uint64_t* d
                        uint32_t n_pairs, const double* d_E, const double* d_tau2,
                        uint32_t* d_counts, uint8_t* d_masks);
 
+/* The two scoring seams A* calls per tested path, for ONE pair with HOST pointers (re-entrant: each call leases
+ * one of the PGI_PAIR_SLOTS private slots -- stream, device scratch, pinned staging -- that pgi_estimate_pose
+ * uses, so the reference's 20 traversal threads overlap on the GPU; no allocation per call once a slot is warm):
+ *   EssentialMatrixEvaluator::getInliers (graph_traversal.h:136-168): early_exit_at = 0, h_mask = n bytes,
+ *       tau2 = kThreshold_ as passed (the reference compares the SQUARED residual with it, :164);
+ *   InTraversalPoseTester::test (graph_traversal.h:194-233): early_exit_at = kMinimumInlierNumber_, h_mask = NULL,
+ *       tau2 = the squared threshold (:184); the scan stops after the 256-row chunk holding that inlier.
+ * h_corr_aos: n x 4 doubles (cv::Mat N x 4 CV_64F); E: row-major 3 x 3; same arithmetic and operation order as
+ * pgi_score_pose_f64.  Returns 1 when early_exit_at > 0 was reached (*count = early_exit_at: the reference returns
+ * AT that inlier, :221-225), 0 otherwise (*count = rows that pass), negative on error.  h_mask may be NULL. */
+int pgi_score_pose_f64_host(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, const double E[9], double tau2,
+                            uint32_t early_exit_at, uint32_t* count, uint8_t* h_mask);
+
 /* ---- getPoseFromEssentialMatrix, batched -------------------------------- */
 /* d_E: n_pairs x 9; d_masks: rows voting (NULL, or pgi_params.vote_all_rows = 1:
  * all rows).  Writes R, t, votes, cand of d_edges (other fields untouched). */

@@ -77,62 +77,38 @@ inline bool estimatePose(const size_t kMinimumInlierNumber_, const cv::Mat& kCor
     return true;
 }
 
-/* Device-side helper shared by the two scoring seams: rows and model up, mask / count down. */
-inline uint32_t scoreF64(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kEssential_, const double tau2,
-                         std::vector<uchar>* mask);
-
 /* EssentialMatrixEvaluator::getInliers (graph_traversal.h:136-168).  The reference compares the SQUARED Sampson
- * distance with the un-squared kThreshold_ (line 164); pass kThreshold_ through unchanged to reproduce that. */
+ * distance with the un-squared kThreshold_ (line 164); pass kThreshold_ through unchanged to reproduce that.
+ * One re-entrant call (pgi_score_pose_f64_host leases a private slot: no hipMalloc, no shared stream). */
 inline void getInliers(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kDescriptor_, const double& kThreshold_,
                        std::vector<size_t>& inliers_) {
-    std::vector<uchar> mask;
-    scoreF64(kCorrespondences_, kDescriptor_, kThreshold_, &mask);
-    inliers_.reserve(mask.size());
+    CV_Assert(kCorrespondences_.type() == CV_64F && kCorrespondences_.cols == 4 && kCorrespondences_.isContinuous());
+    const RowMajor3d E = kDescriptor_;
+    std::vector<uchar> mask((size_t)kCorrespondences_.rows, 0);
+    uint32_t count = 0;
+    uchar none = 0;
+    const int rc = pgi_score_pose_f64_host(context(), kCorrespondences_.ptr<double>(), (uint32_t)kCorrespondences_.rows, E.data(),
+                                           kThreshold_, 0, &count, mask.empty() ? &none : mask.data());
+    if (rc < 0) throw std::runtime_error(pgi_last_error());
+    inliers_.reserve(count);
     for (size_t i = 0; i < mask.size(); ++i)
         if (mask[i]) inliers_.emplace_back(i);
 }
 
-/* InTraversalPoseTester::test (graph_traversal.h:194-233): true at kMinimumInlierNumber_ inliers of the squared bound. */
+/* InTraversalPoseTester::test (graph_traversal.h:194-233): true at kMinimumInlierNumber_ inliers of the squared bound;
+ * the scan stops at that inlier (:221-225), on the device too. */
 inline bool testPose(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kEssential_, const double kSquaredThreshold_,
                      const size_t kMinimumInlierNumber_, size_t& inlierNumber_) {
-    const uint32_t n = scoreF64(kCorrespondences_, kEssential_, kSquaredThreshold_, nullptr);
-    const bool ok = n >= kMinimumInlierNumber_;
-    inlierNumber_ = ok ? kMinimumInlierNumber_ : n;  /* the reference returns at that inlier (:221-225) */
-    return ok;
-}
-
-}  // namespace mi355x
-}  // namespace reconstruction
-
-/* scoreF64 needs device buffers; it is the only place this header touches the HIP runtime */
-#include <hip/hip_runtime_api.h>
-namespace reconstruction {
-namespace mi355x {
-inline uint32_t scoreF64(const cv::Mat& c, const Eigen::Matrix3d& E, const double tau2, std::vector<uchar>* mask) {
-    CV_Assert(c.type() == CV_64F && c.cols == 4 && c.isContinuous());
-    const uint32_t n = (uint32_t)c.rows;
-    const RowMajor3d Er = E;
-    const uint64_t off[2] = {0, n};
-    char* d = nullptr;
-    const size_t o_off = (size_t)n * 32, o_E = o_off + 16, o_tau = o_E + 72, o_cnt = o_tau + 8, o_mask = o_cnt + 8;
-    if (hipMalloc((void**)&d, o_mask + n + 8) != hipSuccess) throw std::runtime_error("hipMalloc failed");
-    (void)hipMemcpy(d, c.ptr<double>(), (size_t)n * 32, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d + o_off, off, 16, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d + o_E, Er.data(), 72, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d + o_tau, &tau2, 8, hipMemcpyHostToDevice);
-    int rc = pgi_score_pose_f64(context(), (const double*)d, (const uint64_t*)(d + o_off), 1, (const double*)(d + o_E),
-                                (const double*)(d + o_tau), (uint32_t*)(d + o_cnt), (uint8_t*)(d + o_mask));
-    if (rc == PGI_SUCCESS) rc = pgi_synchronize(context());
+    CV_Assert(kCorrespondences_.type() == CV_64F && kCorrespondences_.cols == 4 && kCorrespondences_.isContinuous());
+    const RowMajor3d E = kEssential_;
     uint32_t count = 0;
-    (void)hipMemcpy(&count, d + o_cnt, 4, hipMemcpyDeviceToHost);
-    if (mask) {
-        mask->assign(n, 0);
-        if (n) (void)hipMemcpy(mask->data(), d + o_mask, n, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(d);
+    const int rc = pgi_score_pose_f64_host(context(), kCorrespondences_.ptr<double>(), (uint32_t)kCorrespondences_.rows, E.data(),
+                                           kSquaredThreshold_, (uint32_t)kMinimumInlierNumber_, &count, nullptr);
     if (rc < 0) throw std::runtime_error(pgi_last_error());
-    return count;
+    inlierNumber_ = count;
+    return rc == 1;
 }
+
 }  // namespace mi355x
 }  // namespace reconstruction
 

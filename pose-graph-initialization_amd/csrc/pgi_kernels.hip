@@ -1211,6 +1211,52 @@ __global__ __launch_bounds__(256) void score_pose_f64_kernel(const double* __res
     if (lane == 0) counts[pair] = cnt;
 }
 
+// One pair for the re-entrant host seam (pgi_score_pose_f64_host): the same arithmetic, one 256-thread workgroup walking
+// the rows in chunks of 256 IN ORDER, so that InTraversalPoseTester::test's early exit (graph_traversal.h:221-225: return
+// at the kMinimumInlierNumber-th inlier) stops the scan after the chunk in which that inlier falls.  out[0] = rows that
+// pass (all rows when early == 0 or a mask is wanted, else the rows seen until the exit), out[1] = 1 iff early > 0 was
+// reached.  prm: E[9], tau2.
+__global__ __launch_bounds__(256) void score_pose_f64_one_kernel(const double* __restrict__ corr, uint32_t n,
+                                                                 const double* __restrict__ prm, uint32_t early,
+                                                                 uint32_t* __restrict__ out, uint8_t* __restrict__ mask) {
+    __shared__ uint32_t total;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const double e11 = prm[0], e12 = prm[1], e13 = prm[2], e21 = prm[3], e22 = prm[4], e23 = prm[5], e31 = prm[6], e32 = prm[7],
+                 e33 = prm[8], tau2 = prm[9];
+    const double4* rowsv = reinterpret_cast<const double4*>(corr);
+    const bool may_stop = early > 0 && mask == nullptr;
+    uint32_t seen = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        bool in = false;
+        if (i < n) {
+            const double4 s = rowsv[i];
+            const double x1 = s.x, y1 = s.y, x2 = s.z, y2 = s.w;
+            const double rxc = e11 * x2 + e21 * y2 + e31;
+            const double ryc = e12 * x2 + e22 * y2 + e32;
+            const double rwc = e13 * x2 + e23 * y2 + e33;
+            const double r = (x1 * rxc + y1 * ryc + rwc);
+            const double rx = e11 * x1 + e12 * y1 + e13;
+            const double ry = e21 * x1 + e22 * y1 + e23;
+            const double sq = r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+            in = sq < tau2;
+            if (mask) mask[i] = in;
+        }
+        const uint32_t c = (uint32_t)__popcll(__ballot(in));
+        if (lane == 0 && c) atomicAdd(&total, c);
+        __syncthreads();
+        seen = total;
+        __syncthreads();
+        if (may_stop && seen >= early) break;  // workgroup-uniform
+    }
+    if (tid == 0) {
+        out[0] = seen;
+        out[1] = (early > 0 && seen >= early) ? 1u : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: decomposition of a given E per pair (one workgroup per pair).
 // ------------------------------------------------------------------------------------------------
@@ -2014,6 +2060,47 @@ int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr, const uint64_t* d_off
                        d_tau2, n_pairs, d_counts, d_masks);
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
+}
+
+int pgi_score_pose_f64_host(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, const double E[9], double tau2,
+                            uint32_t early_exit_at, uint32_t* count, uint8_t* h_mask) {
+    if (!ctx || !E || !count || (n && !h_corr_aos)) return fail(PGI_ERR_INVALID, "null argument");
+    if (n == 0) {
+        *count = 0;
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    SlotLease lease(ctx);  // same pool as pgi_estimate_pose: A* threads and estimator threads share 32 private slots
+    pgi_ctx::PairSlot& S = *lease.S;
+    if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    // layout (pinned staging == device scratch): rows (n x 4 f64) | E[9], tau2 | out[2] | mask (n)
+    const size_t o_prm = (size_t)n * 32, o_out = o_prm + 80, o_mask = o_out + 16, bytes = o_mask + n + 64;
+    if (bytes > S.bytes) {
+        const size_t cap = bytes + bytes / 2;
+        if (S.d) (void)hipFree(S.d);
+        if (S.h) (void)hipHostFree(S.h);
+        S.d = S.h = nullptr;
+        S.bytes = 0;
+        HIP_TRY(hipMalloc(&S.d, cap));
+        HIP_TRY(hipHostMalloc(&S.h, cap, hipHostMallocDefault));
+        S.bytes = cap;
+    }
+    char* h = (char*)S.h;
+    char* d = (char*)S.d;
+    memcpy(h, h_corr_aos, (size_t)n * 32);  // the caller's cv::Mat is pageable: one pass into the pinned block, one DMA
+    memcpy(h + o_prm, E, 72);
+    memcpy(h + o_prm + 72, &tau2, 8);
+    HIP_TRY(hipMemcpyAsync(d, h, o_out, hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(score_pose_f64_one_kernel, dim3(1), dim3(256), 0, S.stream, (const double*)d, n, (const double*)(d + o_prm),
+                       early_exit_at, (uint32_t*)(d + o_out), h_mask ? (uint8_t*)(d + o_mask) : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h + o_out, d + o_out, h_mask ? 16 + (size_t)n : 16, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    const uint32_t* out = (const uint32_t*)(h + o_out);
+    const bool reached = out[1] != 0;
+    *count = reached ? early_exit_at : out[0];  // the reference returns AT that inlier (graph_traversal.h:221-225)
+    if (h_mask) memcpy(h_mask, h + o_mask, n);
+    return reached ? 1 : 0;
 }
 
 int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, const uint8_t* d_masks,

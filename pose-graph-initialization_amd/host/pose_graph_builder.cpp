@@ -714,7 +714,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         tick = Clock::now();
         std::vector<uint8_t> screened;      // pairs that carried a chained pose into the screening launch
         std::vector<uint32_t> guessInliers; // their inlier counts under the squared bound (1.5 thr)^2
-        if (anyGuess) {
+        if (anyGuess && rotationGuidedGuesses) {  // guess_mode 1 scores its own two-point hypotheses: no 5-inlier screening
+            h2d(dguess.p, guess.data(), P * 96);
+            h2d(dhas.p, has.data(), P);
+            b.d_guess_Rt = dguess.as<double>();
+            b.d_has_guess = dhas.as<uint8_t>();
+        } else if (anyGuess) {
             screened = has;
             std::vector<double> thr(P), Eg(9 * P, 0.0), tau2(P, 0.0);
             Engine::check(pgi_synchronize(ctx));

@@ -158,6 +158,21 @@ class Engine:
                                              _ptr(masks)))
         return counts.cpu().numpy().astype(np.uint32), masks[:len(corr_aos)].cpu().numpy()
 
+    def score_pose_host(self, corr_aos, E, tau2, early_exit_at=0, want_mask=True):
+        """One pair, host pointers, re-entrant (pgi_score_pose_f64_host): getInliers (early_exit_at = 0, mask) /
+        InTraversalPoseTester::test (early_exit_at = kMinimumInlierNumber, no mask) -> (reached, count, mask or None)."""
+        c = np.ascontiguousarray(corr_aos, np.float64).reshape(-1, 4)
+        Ed = np.ascontiguousarray(E, np.float64).reshape(9)
+        n = len(c)
+        mask = np.zeros(n, np.uint8) if want_mask else None
+        cnt = C.c_uint32(0)
+        rc = self._lib.pgi_score_pose_f64_host(self._ctx, c.ctypes.data_as(C.c_void_p), C.c_uint32(n), Ed.ctypes.data_as(C.c_void_p),
+                                               C.c_double(tau2), C.c_uint32(early_exit_at), C.byref(cnt),
+                                               mask.ctypes.data_as(C.c_void_p) if want_mask and n else None)
+        if rc < 0:
+            L.check(rc)
+        return rc == 1, int(cnt.value), mask
+
     def decompose_batch(self, b, E, masks=None):
         P = b["n_pairs"]
         E = torch.as_tensor(np.ascontiguousarray(E, np.float64).reshape(P, 9)).to(self.device)

@@ -121,3 +121,58 @@ def seconds_of(stdout):
     tail = stdout.strip().split("seconds:")[-1]  # the last repetition (PGI_DRIVER_REPS) is the warm one
     vals = [float(tok) for tok in tail.replace(",", " ").split() if tok.replace(".", "", 1).isdigit()]
     return vals[0], vals[1]
+
+
+# ---- feature-level scenes (tests/cpp/test_pipeline.cpp: PoseGraphBuilder::processFeatures) -------------------------------------
+PIPELINE_EXE = os.path.join(PKG, "test_pipeline")
+PIPELINE_KEYS = ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
+                 "waves", "graph_edges", "matching_runs", "quick_matching_runs", "guided_matching_runs", "guided_matches_added",
+                 "track_number", "too_few_matches", "quirk_only_guesses")
+
+
+def write_feature_scene(path, views, cam, sim, pairs, wave):
+    """u32 V, P, wave | V x V f64 similarity | per view: u32 K; f64 f, w, h; K x 2 f32 keypoints; K x 128 f32 descriptors |
+    per pair: u32 src, dst; f64 similarity"""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", len(views), len(pairs), wave))
+        f.write(np.ascontiguousarray(sim, "<f8").tobytes())
+        for v in views:
+            f.write(struct.pack("<Iddd", len(v["xy"]), *cam))
+            f.write(np.ascontiguousarray(v["xy"], "<f4").tobytes())
+            f.write(np.ascontiguousarray(v["desc"], "<f4").tobytes())
+        for i, j, s in pairs:
+            f.write(struct.pack("<IId", int(i), int(j), float(s)))
+
+
+def parse_pipeline(buf, n_modes):
+    """per mode: 16 u64 statistics (PIPELINE_KEYS) | per graph edge {u32 src, dst; f64 score; R[9]; t[3]}"""
+    pos, res = 0, []
+    for _ in range(n_modes):
+        st = struct.unpack_from("<16Q", buf, pos)
+        pos += 128
+        edges = {}
+        for _e in range(st[8]):
+            s, d, sc = struct.unpack_from("<IId", buf, pos)
+            R = np.frombuffer(buf, "<f8", 9, pos + 16).reshape(3, 3)
+            t = np.frombuffer(buf, "<f8", 3, pos + 88)
+            pos += 112
+            edges[(s, d)] = (sc, R, t)
+        res.append((st, edges))
+    assert pos == len(buf)
+    return res
+
+
+def pipeline_timings(stdout):
+    """the driver's per-mode lines -> {mode: dict(seconds=..., stages={...})} (the last repetition of a mode wins)"""
+    import re
+    out = {}
+    cur = None
+    for line in stdout.splitlines():
+        m = re.match(r"mode (\d+): (\d+) pairs -> (\d+) edges in ([0-9.]+) s", line)
+        if m:
+            cur = int(m.group(1))
+            out[cur] = {"seconds": float(m.group(4)), "pairs": int(m.group(2)), "edges": int(m.group(3)), "stages": {}}
+        elif cur is not None and "seconds:" in line:
+            for name, val in re.findall(r"([A-Za-z*+ ]+?) ([0-9.]+)(?:,|$)", line.split("seconds:")[1]):
+                out[cur]["stages"][name.strip()] = float(val)
+    return out

@@ -245,3 +245,60 @@ def make_feature_views(rng, n_views=3, n_points=1500, n_clutter=500, f=1000.0, w
                           point_id=np.concatenate([ids, -np.ones(n_clutter, np.int64)])[perm]))
         poses.append((R, t))
     return views, poses, (f, w, h)
+
+
+def make_feature_scene(n_views=340, keypoints=8000, band=20, seed=5, clutter_frac=0.25, f=1000.0, w=1600.0, h=1200.0,
+                       desc_noise=0.012, px_noise=0.3, step=0.3, detect=0.75):
+    """BASELINE config 3's surrogate AT FEATURE LEVEL (1DSfM Madrid Metropolis: ~340 images, ~8000 SIFT keypoints each; the
+    data set is on neither box): cameras walk along a street (x axis, `step` apart, small pose jitter) past a slab of 3-D
+    points (depth 4..8); every view detects `detect` of the points in its frustum (pixel keypoints with noise + a noisy copy
+    of the point's RootSIFT-like descriptor) plus unmatched clutter, about `keypoints` rows in all.  Candidate pairs = the
+    `band` next views of every view (what a retrieval network's top-k would give, k ~ 2 * band), similarity falling with the
+    distance along the walk.
+
+    Returns views[v] = dict(xy f32 [K,2], desc f32 [K,128], point_id), poses[v] = (R, t) world->camera,
+    cam = (f, w, h), sim [V,V], pairs = [(i, j, similarity)]."""
+    rng = np.random.Generator(np.random.Philox(key=SEED_BASE ^ 0xFEA7 ^ seed))
+
+    def unit(x):
+        x = np.abs(x, out=x)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x
+    n_clutter = int(keypoints * clutter_frac)
+    want_visible = (keypoints - n_clutter) / detect          # points inside a frustum
+    half = 0.5 * w / f                                         # tan of the horizontal half angle
+    area = half * (8.0 ** 2 - 4.0 ** 2)                        # frustum cross-section in the (x, z) plane, z in [4, 8]
+    x_lo, x_hi = -8.0 * half - 1.0, (n_views - 1) * step + 8.0 * half + 1.0
+    n_points = int(want_visible / area * (x_hi - x_lo) * 4.0)   # uniform over (x, z): the slab is 4 deep
+    X = np.stack([rng.uniform(x_lo, x_hi, n_points), rng.uniform(-1.4, 1.4, n_points), rng.uniform(4, 8, n_points)], 1)
+    D = unit(rng.standard_normal((n_points, 128), dtype=np.float32))
+    order = np.argsort(X[:, 0])
+    X, D = X[order], D[order]
+    views, poses = [], []
+    for v in range(n_views):
+        ax = rng.standard_normal(3)
+        R = rodrigues(ax / np.linalg.norm(ax), np.radians(rng.uniform(0.5, 6.0)))
+        C = np.array([v * step, 0.0, 0.0]) + rng.uniform(-0.1, 0.1, 3) * np.array([1.0, 0.6, 1.0])
+        t = -R @ C
+        a, z = np.searchsorted(X[:, 0], [C[0] - 8.5 * half - 1.5, C[0] + 8.5 * half + 1.5])
+        Y = X[a:z] @ R.T + t
+        px = np.stack([f * Y[:, 0] / Y[:, 2] + w / 2, f * Y[:, 1] / Y[:, 2] + h / 2], 1)
+        vis = (Y[:, 2] > 0.5) & (px[:, 0] > 0) & (px[:, 0] < w) & (px[:, 1] > 0) & (px[:, 1] < h) & (rng.random(z - a) < detect)
+        ids = a + np.nonzero(vis)[0]
+        xy = px[ids - a] + px_noise * rng.standard_normal((len(ids), 2))
+        desc = unit(D[ids] + np.float32(desc_noise) * rng.standard_normal((len(ids), 128), dtype=np.float32))
+        cxy = np.stack([rng.uniform(0, w, n_clutter), rng.uniform(0, h, n_clutter)], 1)
+        cdesc = unit(rng.standard_normal((n_clutter, 128), dtype=np.float32))
+        perm = rng.permutation(len(ids) + n_clutter)
+        views.append(dict(xy=np.concatenate([xy, cxy])[perm].astype(np.float32),
+                          desc=np.concatenate([desc, cdesc])[perm],
+                          point_id=np.concatenate([ids, -np.ones(n_clutter, np.int64)])[perm]))
+        poses.append((R, t))
+    sim = np.zeros((n_views, n_views))
+    pairs = []
+    for i in range(n_views):
+        for j in range(i + 1, min(n_views, i + band + 1)):
+            s = round(0.95 - 0.6 * (j - i) / (band + 1) + 0.001 * ((3 * i + j) % 7), 3)
+            sim[i, j] = sim[j, i] = s
+            pairs.append((i, j, s))
+    return views, poses, (f, w, h), sim, pairs

@@ -3,8 +3,11 @@
 // (plain; + path finding; + path finding + epipolar hashing/tracklets in HBM; the same with the host tracklet store) and
 // writes statistics + edges.
 #include <chrono>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <string>
 
 #include "graph_traversal.hpp"
 
@@ -41,11 +44,20 @@ int main(int argc, char** argv) {
     }
     if (!in) return 3;
     std::ofstream out(argv[2], std::ios::binary);
-    for (int mode = 0; mode < 4; ++mode) {  // mode 3 = mode 2 with the tracklets in the host store instead of HBM
+    // argv[3] (optional): the modes to run, e.g. "2" or "023" (default all four); PGI_DRIVER_REPS > 1 repeats every mode
+    // inside this process -- one timing block per repetition, the last one warm -- and writes the last repetition's result
+    const std::string modes = argc > 3 ? argv[3] : "0123";
+    const int reps = std::max(1, std::atoi(std::getenv("PGI_DRIVER_REPS") ? std::getenv("PGI_DRIVER_REPS") : "1"));
+    // mode 3 = mode 2 with the tracklets in the host store instead of HBM; mode 4 = mode 2 with rotation-guided re-estimation
+    // of the chained poses (pgi_params.guess_mode = 1) instead of the reference's guess test
+    for (int mode = 0; mode < 5; ++mode) {
+        if (modes.find((char)('0' + mode)) == std::string::npos) continue;
+        for (int rep = 0; rep < reps; ++rep) {
         const bool usePath = mode >= 1, useHashing = mode >= 2;
         // thresholds as in examples/cpp_example.cpp: 20 inliers, 50 points, 100 guided matches, 0.75 px
         PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.75, "", "", "", "", usePath, true, useHashing);
         builder.setDeviceTracklets(mode != 3);
+        if (mode == 4) builder.setRotationGuidedGuesses(true);
         PoseGraph graph;
         auto cand = pairs;
         const auto t0 = std::chrono::steady_clock::now();
@@ -57,9 +69,11 @@ int main(int argc, char** argv) {
         std::printf("        seconds: quick matching %.3f, matching %.3f, correspondences %.3f, A* %.3f, pose estimation %.3f, guided %.3f, "
                     "commit + tracklets %.3f\n", st.secQuickMatching, st.secMatching, st.secCorrespondences, st.secAStar,
                     st.secPoseEstimation, st.secGuidedMatching, st.secTrackUpdate);
+        if (rep + 1 < reps) continue;
         const uint64_t v[16] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes, st.posesFromGuess,
                                 st.hypotheses, st.waves, graph.numEdges(), st.matchingRuns, st.quickMatchingRuns, st.guidedMatchingRuns,
-                                st.guidedMatchesAdded, st.trackNumber, st.tooFewMatches, 0};
+                                st.guidedMatchesAdded, st.trackNumber, st.tooFewMatches,
+                                builder.getStatistics().getCount("[Pose estimation] Quirk-only guesses")};
         out.write((const char*)v, sizeof v);
         for (auto& id : graph.getEdgeIds()) {
             const PoseGraphEdge e = graph.getEdgeById(id);
@@ -68,6 +82,7 @@ int main(int argc, char** argv) {
             out.write((const char*)&s, 4); out.write((const char*)&d, 4); out.write((const char*)&sc, 8);
             out.write((const char*)e.getValue().getRotation().data(), 72);
             out.write((const char*)e.getValue().getTranslation().data(), 24);
+        }
         }
     }
     return 0;

@@ -28,6 +28,7 @@ def test_null_context_is_rejected_everywhere():
         lambda: lib.pgi_allgather_edges(z, z, z, z), lambda: lib.pgi_allgatherv(z, z, z, z),
         lambda: lib.pgi_rotation_average_edges(z, z, z, z, z, 0, 1, None, z, z, z),
         lambda: lib.pgi_comm_unique_id(z),
+        lambda: lib.pgi_score_pose_f64_host(z, z, 4, z, 1.0, 5, None, z),
         lambda: lib.pgi_tracklets_add_batch(z, None, 1), lambda: lib.pgi_tracklets_get_batch(z, z, z, 1, 1, 2, z, z, z),
         lambda: lib.pgi_tracklets_info(z, None, None, None), lambda: lib.pgi_tracklets_track(z, 0, z, 0, None),
     ]

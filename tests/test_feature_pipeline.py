@@ -8,6 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from pyposegraphbuilder import scenes as SC
 from pyposegraphbuilder import synthetic as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,21 +30,8 @@ def make_scene():
     return views, poses, cam, sim, pairs
 
 
-def parse(buf):
-    pos, res = 0, []
-    for _ in range(4):
-        st = struct.unpack_from("<16Q", buf, pos)
-        pos += 128
-        edges = {}
-        for _e in range(st[8]):
-            s, d, sc = struct.unpack_from("<IId", buf, pos)
-            R = np.frombuffer(buf, "<f8", 9, pos + 16).reshape(3, 3)
-            t = np.frombuffer(buf, "<f8", 3, pos + 88)
-            pos += 112
-            edges[(s, d)] = (sc, R, t)
-        res.append((st, edges))
-    assert pos == len(buf)
-    return res
+def parse(buf, n_modes=4):
+    return SC.parse_pipeline(buf, n_modes)
 
 
 @pytest.mark.gpu
@@ -51,15 +39,7 @@ def test_feature_pipeline_three_configurations(tmp_path):
     views, poses, cam, sim, pairs = make_scene()
     V = len(views)
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fin, "wb") as f:
-        f.write(struct.pack("<III", V, len(pairs), WAVE))
-        f.write(sim.astype("<f8").tobytes())
-        for v in views:
-            f.write(struct.pack("<Iddd", len(v["xy"]), *cam))
-            f.write(v["xy"].astype("<f4").tobytes())
-            f.write(v["desc"].astype("<f4").tobytes())
-        for i, j, s in pairs:
-            f.write(struct.pack("<IId", i, j, s))
+    SC.write_feature_scene(fin, views, cam, sim, pairs, WAVE)
     r = subprocess.run([EXE, fin, fout], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr
     (st0, e0), (st1, e1), (st2, e2), (st3, e3) = parse(open(fout, "rb").read())
@@ -117,3 +97,57 @@ def test_feature_pipeline_three_configurations(tmp_path):
                 assert sc == e["n_inl"][p] / cnt[p]
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_config3_from_features_at_full_size(tmp_path):
+    """BASELINE config 3 ("1DSfM Madrid Metropolis (~340 imgs) full pose-graph build on 1 GPU") FROM FEATURES at its stated
+    size: 340 views x ~8000 keypoints x 128-d descriptors (1.4 GB), the 20 next views of every view as candidates (k ~ 40,
+    6590 pairs), path finding and epipolar hashing on, tracklets in HBM -- processImages' loop body
+    (pose_graph_builder.h:391-709) with point_track.h:568-711 behind it.  Checked: (i) against the CORRESPONDENCE-level run
+    of the same scene (mode 0: every pair descriptor-matched and estimated on its own) -- same edge set up to a handful,
+    rotations of common edges agree; (ii) the device tracklet store against the host store: every counter and every edge
+    identical; (iii) against the ground truth."""
+    views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
+    assert len(views) == 340 and 7500 < np.mean([len(v["xy"]) for v in views]) < 8500 and len(pairs) == 6590
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    SC.write_feature_scene(fin, views, cam, sim, pairs, 512)
+    del views
+    r = subprocess.run([EXE, fin, fout, "0234"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    print(r.stdout)
+    (st0, e0), (st2, e2), (st3, e3), (st4, e4) = parse(open(fout, "rb").read(), 4)
+    os.remove(fin)
+    # (ii) tracklets in HBM == host store, counter for counter and edge for edge
+    assert st2 == st3 and e2.keys() == e3.keys()
+    for key in e2:
+        assert e2[key][0] == e3[key][0] and np.array_equal(e2[key][1], e3[key][1]) and np.array_equal(e2[key][2], e3[key][2])
+    k, k4 = dict(zip(SC.PIPELINE_KEYS, st2)), dict(zip(SC.PIPELINE_KEYS, st4))
+    assert st0[0] == st2[0] == st4[0] == len(pairs) and st0[9] == len(pairs)
+    # the hashing runs replace most descriptor matches by tracklet look-ups and feed guided matches back
+    for kk in (k, k4):
+        assert kk["quick_matching_runs"] > 0.5 * len(pairs) and kk["matching_runs"] + kk["quick_matching_runs"] == len(pairs)
+        assert kk["guided_matching_runs"] > 0 and kk["guided_matches_added"] > 0 and kk["track_number"] > 100000
+    # (i) against the correspondence-level run, (iii) against the ground truth
+    common = sorted(set(e0) & set(e2) & set(e4))
+    assert min(len(e0), len(e2), len(e4)) >= 0.97 * len(pairs) and len(common) >= 0.97 * len(pairs)
+    def gt(s, d):
+        return poses[d][0] @ poses[s][0].T
+    err0 = np.array([S.rot_err_deg(e0[key][1], gt(*key)) for key in common])
+    err2 = np.array([S.rot_err_deg(e2[key][1], gt(*key)) for key in common])
+    err4 = np.array([S.rot_err_deg(e4[key][1], gt(*key)) for key in common])
+    diff4 = np.array([S.rot_err_deg(e0[key][1], e4[key][1]) for key in common])
+    for name, err, kk in (("plain (correspondence level)", err0, dict(zip(SC.PIPELINE_KEYS, st0))), ("A* + hashing, reference guesses", err2, k),
+                          ("A* + hashing, rotation-guided", err4, k4)):
+        print("config 3 from features, %-32s: %d edges, %d guesses used (%d quirk-only), %d hypotheses; rot err median %.3f deg, "
+              "< 0.5 deg %.3f, < 5 deg %.3f" % (name, kk["graph_edges"], kk["poses_from_guess"], kk["quirk_only_guesses"], kk["hypotheses"],
+                                                np.median(err), np.mean(err < 0.5), np.mean(err < 5.0)))
+    assert np.median(err0) < 0.1 and np.mean(err0 < 0.5) > 0.97
+    # rotation-guided re-estimation of the chained poses: the correspondence-level answer, pair for pair
+    assert np.median(err4) < 0.1 and np.mean(err4 < 0.5) > 0.97 and np.median(diff4) < 0.1 and np.mean(diff4 < 0.5) > 0.97
+    assert k4["quirk_only_guesses"] == 0 and k4["poses_from_guess"] > 0.5 * len(pairs)
+    # The reference's guess path (pose_graph_builder.h:974-1029), reproduced by default: a chained pose that passes the
+    # 5-inlier tester is accepted on the rows inside the UN-squared bound (graph_traversal.h:164 -- a ~33 px band, i.e.
+    # nearly every row, mismatches included) and refitted on all of them.  Most such edges are fine, a good tenth is not;
+    # the run counts the guesses only the quirk let through.  Documented, measured, and the reason guess_mode = 1 exists.
+    assert np.median(err2) < 0.15 and np.mean(err2 < 5.0) > 0.8 and k["quirk_only_guesses"] > 0

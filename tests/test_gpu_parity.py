@@ -576,3 +576,59 @@ def test_rotation_guided_guess_mode_matches_oracle(eng):
         assert max(bad) > 5.0
     finally:
         eng.set_params(guess_mode=0)
+
+
+def test_host_scoring_seam_from_twenty_threads(eng):
+    """pgi_score_pose_f64_host -- the seam EssentialMatrixEvaluator::getInliers (graph_traversal.h:136-168) and
+    InTraversalPoseTester::test (:194-233) sit behind inside A* -- called like the reference calls it: 20 threads, 1000 calls
+    each, host pointers, no shared state.  Every answer equals the literal restatements pgo_ref_get_inliers /
+    pgo_ref_pose_test (index lists; (true, kMin) at the early exit, (false, count) otherwise)."""
+    import threading
+    sizes = [50, 64, 257, 600, 1000, 2000, 5, 1]
+    b = S.make_batch(range(8800, 8800 + len(sizes)), sizes)
+    thr = 7.5e-4
+    cases = []
+    rng = np.random.default_rng(12)
+    for p, n in enumerate(sizes):
+        a, z = int(b["offsets"][p]), int(b["offsets"][p + 1])
+        corr = np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1).astype(np.float64)
+        good = (b["R"][p], b["t"][p])
+        ax = rng.standard_normal(3)
+        bad = (S.rodrigues(ax / np.linalg.norm(ax), 0.4) @ b["R"][p], b["t"][p][::-1].copy())
+        for R, t in (good, bad):
+            E = O.ref_essential_from_pose(R, t)
+            for kmin in (5, 20, 100000):
+                ok, cnt = O.ref_pose_test(corr, R, t, 1.5 * thr, kmin)
+                cases.append(("test", corr, E, (1.5 * thr) ** 2, kmin, (ok, cnt)))
+            for tau in (1.5 * thr, (1.5 * thr) ** 2):          # the un-squared quirk bound (:164) and the squared one
+                cases.append(("inliers", corr, E, tau, 0, O.ref_get_inliers(corr, E, tau)))
+    errors = []
+
+    def worker(tid):
+        r = np.random.default_rng(100 + tid)
+        try:
+            for _ in range(1000):
+                kind, corr, E, tau2, kmin, exp = cases[int(r.integers(len(cases)))]
+                if kind == "test":
+                    reached, cnt, _ = eng.score_pose_host(corr, E, tau2, early_exit_at=kmin, want_mask=False)
+                    if (reached, cnt) != exp:
+                        errors.append((tid, kind, len(corr), kmin, (reached, cnt), exp))
+                else:
+                    reached, cnt, mask = eng.score_pose_host(corr, E, tau2)
+                    if reached or cnt != len(exp) or not np.array_equal(np.nonzero(mask)[0], exp):
+                        errors.append((tid, kind, len(corr), cnt, len(exp)))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(20)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    # with a mask wanted the scan is complete even when an early-exit level is given
+    kind, corr, E, tau2, _, exp = next(c for c in cases if c[0] == "inliers" and len(c[1]) == 2000)
+    reached, cnt, mask = eng.score_pose_host(corr, E, tau2, early_exit_at=5)
+    assert reached and cnt == 5 and np.array_equal(np.nonzero(mask)[0], exp)
+    # empty input
+    assert eng.score_pose_host(np.zeros((0, 4)), np.eye(3), 1.0, early_exit_at=5, want_mask=False)[:2] == (False, 0)
