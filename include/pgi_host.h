@@ -1,0 +1,53 @@
+/* pgi_host.h -- C entry points of libpgi_host.so, the C++ host layer (host/pose_graph_builder.hpp: the reference's
+ * PoseGraphBuilder with its A* edge scheduler, visibility table and pose graph over libpgi.so).
+ *
+ * The reference is a C++ class (src/pyposegraphbuilder/include/pose_graph_builder.h:25-171) whose Python package is
+ * empty; these few functions let a non-C++ caller -- pyposegraphbuilder.PoseGraphBuilder.run -- drive the SAME
+ * scheduler the C++ surface uses instead of re-implementing it: descending-similarity waves, A* pose guesses on the
+ * graph committed by the previous waves (findPath, :785-862), batched guess screening and estimatePose, edge and
+ * visibility update.  Plain pointers and sizes, caller-owned buffers, negative return = error (pgih_last_error). */
+#ifndef PGI_HOST_H
+#define PGI_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgih_builder pgih_builder;
+
+/* the 17 constructor arguments of reconstruction::PoseGraphBuilder, in the reference's order
+ * (pose_graph_builder.h:30-47; call site examples/cpp_example.cpp:86-103) */
+typedef struct {
+    uint64_t core_number, maximum_tracklet_number, maximum_search_depth, maximum_path_number, minimum_inlier_number,
+        minimum_point_number, maximum_point_number_for_epipolar_hashing;
+    double traversal_heuristics_weight, similarity_threshold, inlier_outlier_threshold;
+    const char *image_path, *workspace_path, *similarity_graph_path, *focal_length_path;
+    int32_t use_path_finding, use_gpu, use_epipolar_hashing;
+} pgih_config;
+
+typedef struct {           /* one edge of the resulting pose graph (pose_graph.h:28-60) */
+    uint32_t src, dst;
+    double score;          /* inliers / matches (pose_graph_builder.h:645-654) */
+    double R[9], t[3];     /* T_dst_src, row-major rotation */
+} pgih_graph_edge;
+
+#define PGIH_STATS 16      /* pairs processed, edges added, A* searched / found / touched, poses from guesses, hypotheses,
+                            * waves, graph edges, quirk-only guesses, rest 0 */
+
+const char* pgih_last_error(void);
+pgih_builder* pgih_create(const pgih_config* cfg);   /* NULL on failure (no HIP device: there is no CPU fallback) */
+void pgih_destroy(pgih_builder* b);
+/* pgi_params.guess_mode of the builder's engine: 1 = rotation-guided re-estimation of chained poses (BASELINE config 5) */
+int pgih_set_rotation_guided(pgih_builder* b, int on);
+/* PoseGraphBuilder::run over caller-provided candidate pairs.  Pair p: views src[p] -> dst[p], retrieval similarity,
+ * normalised threshold thr[p], correspondences rows [offsets[p], offsets[p+1]) of corr_aos (n x 4 doubles, the reference's
+ * cv::Mat N x 4 CV_64F).  The similarity table A* uses holds the candidate pairs' values (0 elsewhere).  Writes at most
+ * edge_capacity edges (in (src, dst) order), their number to *n_edges, PGIH_STATS counters to stats (may be NULL). */
+int pgih_run_pairs(pgih_builder* b, uint32_t n_pairs, const uint32_t* src, const uint32_t* dst, const double* similarity,
+                   const double* thr, const uint64_t* offsets, const double* corr_aos, uint32_t wave_size,
+                   pgih_graph_edge* edges, uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGI_HOST_H */

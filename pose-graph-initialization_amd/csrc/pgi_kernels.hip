@@ -1725,6 +1725,18 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         }
         return at.type == hipMemoryTypeHost;
     };
+    // A range must be page-locked as a whole or not at all: the runtime rejects a copy that leaves a registered range
+    // ("invalid argument"), and a kernel working in place would fault past its end.  Checked up front, on both ends.
+    {
+        const uint64_t rows_all = h_offsets[n_pairs] - h_offsets[0];
+        const void* lo[6] = {h_x1, h_y1, h_x2, h_y2, h_edges, h_masks};
+        const size_t len[6] = {(size_t)rows_all * 4, (size_t)rows_all * 4, (size_t)rows_all * 4, (size_t)rows_all * 4,
+                               (size_t)n_pairs * sizeof(pgi_edge), (size_t)rows_all};
+        for (int k = 0; k < 6; ++k)
+            if (len[k] && page_locked(lo[k]) != page_locked(static_cast<const char*>(lo[k]) + len[k] - 1))
+                return fail(PGI_ERR_INVALID, "pgi_estimate_pose_batch_host: a buffer is page-locked only in part (register the whole "
+                                             "range the batch uses, or none of it)");
+    }
     const bool pin_in = page_locked(h_x1) && page_locked(h_y1) && page_locked(h_x2) && page_locked(h_y2);
     // (results always return on the chunk's kernel stream, two launches behind the front: measured faster than an
     // immediate copy on a dedicated stream even for page-locked result buffers, 8.6 ms vs 9.0-13 ms)
@@ -1732,12 +1744,22 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     if (pinned && ctx->host_direct && page_locked(h_edges) && page_locked(h_masks)) {  // work on the caller's buffers in place
         void* hp[6] = {const_cast<float*>(h_x1), const_cast<float*>(h_y1), const_cast<float*>(h_x2), const_cast<float*>(h_y2), h_edges, h_masks};
         void* dp[6] = {};
+        // The kernel will touch the WHOLE of every range: both ends must be mapped, and contiguously (two separate
+        // registrations that happen to cover both ends do not make one device range) -- else the copy pipeline runs.
+        const uint64_t rows_total = h_offsets[n_pairs] - h_offsets[0];
+        const size_t span[6] = {(size_t)rows_total * 4, (size_t)rows_total * 4, (size_t)rows_total * 4, (size_t)rows_total * 4,
+                                (size_t)n_pairs * sizeof(pgi_edge), (size_t)rows_total};
         bool mapped = true;
-        for (int k = 0; k < 6 && mapped; ++k)
-            if (hipHostGetDevicePointer(&dp[k], hp[k], 0) != hipSuccess || !dp[k]) {
-                (void)hipGetLastError();  // page-locked but not mapped into the device's address space: copy instead
+        for (int k = 0; k < 6 && mapped; ++k) {
+            void* last = nullptr;
+            char* last_byte = static_cast<char*>(hp[k]) + (span[k] ? span[k] - 1 : 0);  // (the arrays start at the batch's first row)
+            if (hipHostGetDevicePointer(&dp[k], hp[k], 0) != hipSuccess || !dp[k] || !page_locked(last_byte) ||
+                hipHostGetDevicePointer(&last, last_byte, 0) != hipSuccess || !last ||
+                static_cast<char*>(last) - static_cast<char*>(dp[k]) != last_byte - static_cast<char*>(hp[k])) {
+                (void)hipGetLastError();  // page-locked but not (wholly, contiguously) mapped into the device's address space: copy instead
                 mapped = false;
             }
+        }
         if (mapped) {
             const float* src[4] = {static_cast<const float*>(dp[0]), static_cast<const float*>(dp[1]), static_cast<const float*>(dp[2]),
                                    static_cast<const float*>(dp[3])};

@@ -900,12 +900,24 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     if (const char* e = std::getenv("PGI_TRACKLETS_LIST_CAP")) list_cap = std::min<uint32_t>(kListCap, std::max(8, std::atoi(e)));
     bool huge = false;
     a.list_cap = list_cap;
-    const DeviceState committed = h;  // a batch that fails leaves the store as it was (the rounds may have advanced the quirk state)
-    auto give_up = [&](int code, const char* msg) {
-        (void)hipMemcpyAsync(st, &committed, sizeof committed, hipMemcpyHostToDevice, s);
-        (void)hipStreamSynchronize(s);
-        return pgi::fail(code, msg);
-    };
+    // A batch that fails leaves the store as it was: the rounds advance the device-side quirk state (phase, key, counters)
+    // and the track count moves before the merge, so EVERY non-success exit from here on -- the explicit give-ups, a
+    // failed reserve / memset / scan / sort / merge -- restores both; only a completed merge dismisses the guard.
+    struct Rollback {
+        DeviceState* st;
+        DeviceState committed;
+        hipStream_t s;
+        pgi_tracklets* t;
+        uint32_t tracks;
+        bool armed;
+        ~Rollback() {
+            if (!armed) return;
+            (void)hipMemcpyAsync(st, &committed, sizeof committed, hipMemcpyHostToDevice, s);
+            (void)hipStreamSynchronize(s);
+            t->n_tracks = tracks;
+        }
+    } rollback{st, h, s, t, t->n_tracks, true};
+    auto give_up = [&](int code, const char* msg) { return pgi::fail(code, msg); };
     for (;;) {
         a.nev_track = t->nev_track.as<uint32_t>();
         a.nev_key = t->nev_key.as<uint64_t>(); a.nev_seq = t->nev_seq.as<uint64_t>();
@@ -978,6 +990,7 @@ int pgi_tracklets_add_batch(pgi_tracklets* t, const pgi_tracklet_pair* h_pairs, 
     timer.mark("order events");
     rc = merge_batch(t, n_new, s);
     timer.mark("merge into the three orderings");
+    if (rc == PGI_SUCCESS) rollback.armed = false;
     return rc;
 }
 

@@ -1,0 +1,112 @@
+// c_api.cpp -- the C entry points of libpgi_host.so (include/pgi_host.h): PoseGraphBuilder::run for non-C++ callers.
+#include "../../include/pgi_host.h"
+
+#include <algorithm>
+#include <memory>
+#include <string>
+
+#include "graph_traversal.hpp"
+
+using namespace reconstruction;
+
+struct pgih_builder {
+    std::unique_ptr<PoseGraphBuilder> impl;
+};
+
+namespace {
+thread_local std::string g_error;
+int fail(const std::string& what) {
+    g_error = what;
+    return -1;
+}
+}  // namespace
+
+extern "C" {
+
+const char* pgih_last_error(void) { return g_error.c_str(); }
+
+pgih_builder* pgih_create(const pgih_config* c) {
+    if (!c) {
+        g_error = "pgih_create: null configuration";
+        return nullptr;
+    }
+    try {
+        auto str = [](const char* s) { return std::string(s ? s : ""); };
+        std::unique_ptr<pgih_builder> b(new pgih_builder);
+        b->impl.reset(new PoseGraphBuilder(c->core_number, c->maximum_tracklet_number, c->maximum_search_depth, c->maximum_path_number,
+                                           c->minimum_inlier_number, c->minimum_point_number, c->maximum_point_number_for_epipolar_hashing,
+                                           c->traversal_heuristics_weight, c->similarity_threshold, c->inlier_outlier_threshold,
+                                           str(c->image_path), str(c->workspace_path), str(c->similarity_graph_path),
+                                           str(c->focal_length_path), c->use_path_finding != 0, c->use_gpu != 0,
+                                           c->use_epipolar_hashing != 0));
+        return b.release();
+    } catch (const std::exception& e) {
+        g_error = std::string("pgih_create: ") + e.what();
+        return nullptr;
+    }
+}
+
+void pgih_destroy(pgih_builder* b) { delete b; }
+
+int pgih_set_rotation_guided(pgih_builder* b, int on) {
+    if (!b) return fail("pgih_set_rotation_guided: null builder");
+    try {
+        b->impl->setRotationGuidedGuesses(on != 0);
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+    return 0;
+}
+
+int pgih_run_pairs(pgih_builder* b, uint32_t n_pairs, const uint32_t* src, const uint32_t* dst, const double* similarity,
+                   const double* thr, const uint64_t* offsets, const double* corr_aos, uint32_t wave_size, pgih_graph_edge* edges,
+                   uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats) {
+    if (!b || !n_edges || (n_pairs && (!src || !dst || !similarity || !thr || !offsets || !corr_aos)) || (edge_capacity && !edges))
+        return fail("pgih_run_pairs: null argument");
+    try {
+        uint32_t views = 0;
+        for (uint32_t p = 0; p < n_pairs; ++p) views = std::max(views, std::max(src[p], dst[p]) + 1u);
+        SimilarityTable sim(std::max(views, 1u), 0.0, false);
+        for (uint32_t i = 0; i < views; ++i)
+            for (uint32_t j = i + 1; j < views; ++j) sim.setSimilarity(i, j, 0.0);
+        std::vector<PoseGraphBuilder::ViewPair> pairs(n_pairs);
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            PoseGraphBuilder::ViewPair& vp = pairs[p];
+            vp.src = src[p];
+            vp.dst = dst[p];
+            vp.similarity = similarity[p];
+            vp.normalizedThreshold = thr[p];
+            const uint64_t rows = offsets[p + 1] - offsets[p];
+            vp.correspondences = CorrespondenceMatrix((int)rows);
+            if (rows) std::copy(corr_aos + 4 * offsets[p], corr_aos + 4 * offsets[p + 1], vp.correspondences.ptr());
+            sim.setSimilarity(vp.src, vp.dst, vp.similarity);
+        }
+        PoseGraph graph;
+        const PoseGraphBuilder::RunStatistics st = b->impl->run(pairs, graph, wave_size ? wave_size : 4096, &sim);
+        uint32_t k = 0;
+        for (const EdgeId& id : graph.getEdgeIds()) {
+            if (k < edge_capacity) {
+                const PoseGraphEdge e = graph.getEdgeById(id);
+                pgih_graph_edge& o = edges[k];
+                o.src = (uint32_t)id.first;
+                o.dst = (uint32_t)id.second;
+                o.score = e.getScore();
+                for (int c = 0; c < 9; ++c) o.R[c] = e.getValue().getRotation()[c];
+                for (int c = 0; c < 3; ++c) o.t[c] = e.getValue().getTranslation()[c];
+            }
+            ++k;
+        }
+        *n_edges = k;
+        if (stats) {
+            const uint64_t v[PGIH_STATS] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
+                                            st.posesFromGuess, st.hypotheses, st.waves, graph.numEdges(), st.quirkOnlyGuesses};
+            std::copy(v, v + PGIH_STATS, stats);
+        }
+        if (k > edge_capacity) return fail("pgih_run_pairs: edge buffer too small");
+    } catch (const std::exception& e) {
+        return fail(std::string("pgih_run_pairs: ") + e.what());
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -14,6 +14,8 @@
 #pragma once
 #include <algorithm>
 #include <fstream>
+#include <cstdlib>
+#include <iterator>
 #include <functional>
 #include <sstream>
 #include <queue>
@@ -47,31 +49,53 @@ class SimilarityTable {
         if (from >= size || to >= size) return -1.0;  // NO_SUCH_VERTEX
         return similarity[from][to];
     }
-    // imagesimilarity_graph.h:108-171: whitespace-separated N x N text ("%1.3f" from get_image_similarity.py).
-    // Pairs enter the heap while the mirrored cell still holds its initial 1.0, i.e. only (i<j) for a
-    // symmetric file -- and never for a similarity of exactly 1.0 (the reference's test, reproduced).
+    // The similarity matrix file (format: imagesimilarity_graph.h:108-171): N lines of N numbers, "%1.3f" as written by
+    // get_image_similarity.py.  The whole file is tokenised in one pass with strtod and checked strictly -- exactly N x N
+    // numbers, N per line, nothing else (trailing blank lines are tolerated) -- before a single cell is touched, so a
+    // bad file leaves the table as it was.
+    // Heap-entry rule, kept because the candidate order depends on it: cells are written in row-major order, and pair
+    // (i, j) is queued when i != j, the value reaches the threshold and it DIFFERS from what the mirrored cell (j, i)
+    // holds at that moment -- the table's previous content (1.0 after construction) while j > i, the file's own value
+    // once row j has been written.  For a symmetric file that is: each pair once, as (i < j), and never a similarity of
+    // exactly 1.0.
     bool loadFromFile(const std::string& fname) {
-        std::ifstream file(fname);
+        std::ifstream file(fname, std::ios::binary);
         if (!file.is_open()) return false;
-        std::vector<std::vector<double>> temp;
-        std::string line;
-        while (std::getline(file, line)) {
-            std::stringstream ss(line);
-            temp.emplace_back();
-            double value;
-            while (ss >> value) temp.back().push_back(value);
+        const std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+        const size_t N = similarity.size();
+        std::vector<double> cell;
+        cell.reserve(N * N);
+        const char* p = text.c_str();
+        const char* const end = p + text.size();
+        size_t in_line = 0;
+        while (p < end) {
+            const char c = *p;
+            if (c == '\n') {
+                if (in_line != 0 && in_line != N) return false;   // a short or long row
+                if (in_line == 0 && cell.size() != N * N && !cell.empty()) return false;  // blank line inside the matrix
+                in_line = 0;
+                ++p;
+            } else if (c == ' ' || c == '\t' || c == '\r') {
+                ++p;
+            } else {
+                char* q = nullptr;
+                const double v = std::strtod(p, &q);
+                if (q == p || cell.size() == N * N) return false;  // not a number / more than N x N values
+                cell.push_back(v);
+                ++in_line;
+                p = q;
+            }
         }
-        if (temp.size() != similarity.size()) return false;
-        for (size_t i = 0; i < similarity.size(); ++i) {
-            if (temp[i].size() != similarity[i].size()) return false;
-            for (size_t j = 0; j < temp[i].size(); ++j) {
-                similarity[i][j] = temp[i][j];
-                if (build_priority_queue && i != j && image_similarity_threshold <= similarity[i][j] &&
-                    similarity[j][i] != similarity[i][j]) {
-                    views.insert(i);
-                    views.insert(j);
-                    view_pair_queue.emplace(similarity[i][j], i, j);
-                }
+        if ((in_line != 0 && in_line != N) || cell.size() != N * N) return false;
+        for (size_t k = 0; k < N * N; ++k) {
+            const size_t i = k / N, j = k % N;
+            const double v = cell[k];
+            const double mirrored = similarity[j][i];  // previous content for j > i, this file's value for j < i
+            similarity[i][j] = v;
+            if (build_priority_queue && i != j && image_similarity_threshold <= v && mirrored != v) {
+                views.insert(i);
+                views.insert(j);
+                view_pair_queue.emplace(v, i, j);
             }
         }
         return true;

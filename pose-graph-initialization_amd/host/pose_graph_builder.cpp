@@ -75,26 +75,6 @@ void d2h(void* h, const void* d, size_t n) {
 }
 }  // namespace
 
-namespace detail {
-int score_f64(pgi_ctx* ctx, const double* corr, uint32_t n, const double E[9], double tau2, uint32_t* count,
-              uchar* mask) {
-    DevBuf dc((size_t)n * 32), doff(16), dE(72), dt(8), dcnt(4), dm(n);
-    const uint64_t off[2] = {0, n};
-    h2d(dc.p, corr, (size_t)n * 32);
-    h2d(doff.p, off, 16);
-    h2d(dE.p, E, 72);
-    h2d(dt.p, &tau2, 8);
-    int rc = pgi_score_pose_f64(ctx, dc.as<double>(), doff.as<uint64_t>(), 1, dE.as<double>(), dt.as<double>(),
-                                dcnt.as<uint32_t>(), dm.as<uint8_t>());
-    if (rc < 0) return rc;
-    rc = pgi_synchronize(ctx);
-    if (rc < 0) return rc;
-    d2h(count, dcnt.p, 4);
-    if (mask) d2h(mask, dm.p, n);
-    return PGI_SUCCESS;
-}
-}  // namespace detail
-
 namespace {
 // f64 AoS rows of many pairs -> flattened f32 SoA batch on the device
 struct DeviceBatch {

@@ -249,11 +249,6 @@ class Engine {
     pgi_ctx* ctx;
 };
 
-// device buffer helpers live in the implementation file to keep HIP out of this header
-namespace detail {
-int score_f64(pgi_ctx* ctx, const double* corr, uint32_t n, const double E[9], double tau2, uint32_t* count,
-              uchar* mask);
-}
 
 class EssentialMatrixEvaluator {  // include/graph_traversal.h:82-170
    public:
@@ -264,8 +259,10 @@ class EssentialMatrixEvaluator {  // include/graph_traversal.h:82-170
                     const double& kThreshold_, std::vector<size_t>& inliers_) const {
         std::vector<uchar> mask((size_t)kCorrespondences_.rows);
         uint32_t cnt = 0;
-        Engine::check(detail::score_f64(eng->get(), kCorrespondences_.ptr(), (uint32_t)kCorrespondences_.rows,
-                                        kDescriptor_.data(), kThreshold_, &cnt, mask.data()));
+        uchar none = 0;
+        // one re-entrant call on host pointers (private slot of the context: no allocation, no shared stream)
+        Engine::check(pgi_score_pose_f64_host(eng->get(), kCorrespondences_.ptr(), (uint32_t)kCorrespondences_.rows,
+                                              kDescriptor_.data(), kThreshold_, 0, &cnt, mask.empty() ? &none : mask.data()));
         inliers_.reserve((size_t)kCorrespondences_.rows);
         for (size_t i = 0; i < mask.size(); ++i)
             if (mask[i]) inliers_.emplace_back(i);
@@ -287,13 +284,17 @@ class InTraversalPoseTester {  // include/graph_traversal.h:174-242
     // graph_traversal.h:194-233: true as soon as kMinimumInlierNumber inliers exist; inlierNumber_ is then
     // exactly kMinimumInlierNumber (the reference returns at that inlier), otherwise the full count.
     bool test(const SE3d& kPose_, size_t& inlierNumber_) const {
+        if (!kMinimumInlierNumber) {  // nothing to reach
+            inlierNumber_ = 0;
+            return true;
+        }
         const Matrix3d E = pose::getEssentialMatrixFromRelativePose(kPose_);
         uint32_t cnt = 0;
-        Engine::check(detail::score_f64(eng->get(), correspondences->ptr(), (uint32_t)correspondences->rows, E.data(),
-                                        kSquaredInlierOutlierThreshold, &cnt, nullptr));
-        const bool ok = cnt >= kMinimumInlierNumber;
-        inlierNumber_ = ok ? kMinimumInlierNumber : cnt;
-        return ok;
+        const int rc = pgi_score_pose_f64_host(eng->get(), correspondences->ptr(), (uint32_t)correspondences->rows, E.data(),
+                                               kSquaredInlierOutlierThreshold, (uint32_t)kMinimumInlierNumber, &cnt, nullptr);
+        Engine::check(rc);  // the device scan stops at that inlier too (graph_traversal.h:221-225)
+        inlierNumber_ = cnt;
+        return rc == 1;
     }
 
    protected:

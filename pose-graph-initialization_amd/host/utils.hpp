@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -83,34 +84,48 @@ class RunningStatistics {
     CountTable countValues;
 };
 
-// utils.h:122-182.  results_: (image name without the "images/" prefix, focal length, width, height).
-// Lines without a third token keep focal length 0 (the reference leaves it uninitialised there);
-// image sizes are not probed here (the reference reads them with cv::imread) and stay 0.
+// The 1DSfM image list, "list_with_focals.txt" (format: utils.h:122-182): one image per line,
+//     images/<name> [<flag> <focal length>]
+// results_ gets (name without the "images/" directory, focal length, width, height) per image; totalImageNumber_ the
+// number of images listed.  Parsed strictly, which the reference does not do: a line without
+// a focal length yields focal 0 -- the reference leaves the value uninitialised there; a focal length that is not a
+// number, or a line with more than three fields, makes the whole load fail instead of slipping through atof; empty
+// lines are skipped.  A name without the "images/" prefix is kept whole (the reference cuts seven characters blindly).
+// Image sizes are not probed here (the reference reads them with cv::imread) and stay 0.
 inline bool load1DSfMImageList(const std::string& kListPath_, size_t& totalImageNumber_,
                                std::vector<std::tuple<std::string, double, double, double>>& results_) {
     totalImageNumber_ = 0;
-    std::ifstream file(kListPath_);
+    std::ifstream file(kListPath_, std::ios::binary);
     if (!file.is_open()) return false;
-    std::string line;
-    while (std::getline(file, line)) {
-        ++totalImageNumber_;
-        size_t counter = 0;
-        std::istringstream iss(line);
-        std::string imageName, s;
-        double focalLength = 0.0;
-        while (iss >> s) {
-            switch (counter++) {
-                case 0:
-                    imageName = s.size() >= 7 ? s.substr(7, s.size() - 7) : std::string();
-                    break;
-                case 1:
-                    break;
-                case 2:
-                    focalLength = std::atof(s.c_str());
-                    break;
-            }
+    const std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+    static const char kDir[] = "images/";
+    const auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\r'; };
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string field[3];  // name, flag, focal length
+        size_t nfields = 0, p = pos;
+        while (p < eol) {
+            while (p < eol && blank(text[p])) ++p;
+            if (p == eol) break;
+            size_t q = p;
+            while (q < eol && !blank(text[q])) ++q;
+            if (nfields == 3) return false;  // a fourth field: not this format
+            field[nfields++] = text.substr(p, q - p);
+            p = q;
         }
-        results_.emplace_back(imageName, focalLength, 0.0, 0.0);
+        pos = eol + 1;
+        if (nfields == 0) continue;
+        double focal = 0.0;
+        if (nfields == 3) {
+            char* end = nullptr;
+            focal = std::strtod(field[2].c_str(), &end);
+            if (end == field[2].c_str() || *end != '\0' || !(focal >= 0.0)) return false;
+        }
+        const bool prefixed = field[0].compare(0, sizeof kDir - 1, kDir) == 0;
+        results_.emplace_back(prefixed ? field[0].substr(sizeof kDir - 1) : field[0], focal, 0.0, 0.0);
+        ++totalImageNumber_;
     }
     return true;
 }

@@ -120,3 +120,45 @@ def test_text_formats_similarity_matrix_and_image_list(tmp_path):
     assert rest[0] == "sim01 %.3f sim10 %.3f" % (sim[0, 1], sim[1, 0])
     assert rest[1:6] == ["list 1", "total 3", "a_001.jpg 1234.5000", "b.jpg 0.0000", "c.png 800.0000"]
     assert rest[6] == "stat 6.0 2 3.0"
+
+
+def test_text_loaders_parse_strictly(tmp_path):
+    """The rewritten loaders (host/graph_traversal.hpp SimilarityTable::loadFromFile, host/utils.hpp load1DSfMImageList)
+    refuse what the reference lets through and leave the table untouched on failure; an
+    asymmetric matrix shows the heap-entry rule in full: (i, j) is queued when its value differs from what cell (j, i)
+    holds at that moment -- 1.0 before row j is written, the file's value after."""
+    N, thr = 3, 0.2
+    good_list = "images/a.jpg 0 500\n"
+
+    def run(sim_text, list_text):
+        fs, fl, fo = tmp_path / "s.txt", tmp_path / "l.txt", tmp_path / "o.txt"
+        fs.write_text(sim_text)
+        fl.write_text(list_text)
+        subprocess.check_call([EXE, "formats", str(fs), str(N), str(thr), str(fl), str(fo)])
+        return fo.read_text().split("\n")
+
+    sym = "1.000 0.500 0.100\n0.500 1.000 0.700\n0.100 0.700 1.000\n"
+    out = run(sym + "\n\n", good_list)                       # trailing blank lines are tolerated
+    assert out[0] == "load 1" and out[1] == "pairs 2 views 3" and out[2:4] == ["0.700 1 2", "0.500 0 1"]
+    for bad in ("1.000 0.500\n0.500 1.000 0.700\n0.100 0.700 1.000\n",            # a short row
+                "1.000 0.500 0.100 9\n0.500 1.000 0.700\n0.100 0.700 1.000\n",     # a long row
+                "1.000 0.500 0.100\n0.500 1.000 0.700\n",                            # a row missing
+                "1.000 0.5x0 0.100\n0.500 1.000 0.700\n0.100 0.700 1.000\n",       # not a number
+                "1.000 0.500 0.100\n\n0.500 1.000 0.700\n0.100 0.700 1.000\n",     # blank line inside the matrix
+                sym + "0.1 0.2 0.3\n"):                                               # a fourth row
+        out = run(bad, good_list)
+        assert out[0] == "load 0" and out[1] == "pairs 0 views 0", bad
+        assert out[2] == "sim01 1.000 sim10 1.000"          # untouched: still the constructor's 1.0
+    # asymmetric: (0,1)=0.5 vs (1,0)=0.6 -> both directions differ from their mirror and are queued; (0,2)=(2,0)=0.3 once;
+    # (1,2)=0.9 against a mirror of (2,1)=0.9: queued when written first (mirror still 1.0), not again from row 2
+    asym = "1.000 0.500 0.300\n0.600 1.000 0.900\n0.300 0.900 1.000\n"
+    out = run(asym, good_list)
+    assert out[0] == "load 1" and out[1] == "pairs 4 views 3"
+    assert out[2:6] == ["0.900 1 2", "0.600 1 0", "0.500 0 1", "0.300 0 2"]
+    # image list: names without the directory prefix are kept whole, blank lines skipped, bad focal / extra fields refused
+    out = run(sym, "images/a.jpg 0 500\n\nplain.png 1 640.5\r\nimages/nofocal.jpg\n")
+    i = out.index("list 1")
+    assert out[i + 1] == "total 3" and out[i + 2:i + 5] == ["a.jpg 500.0000", "plain.png 640.5000", "nofocal.jpg 0.0000"]
+    for bad in ("images/a.jpg 0 12abc\n", "images/a.jpg 0 500 extra\n", "images/a.jpg 0 -3\n"):
+        out = run(sym, bad)
+        assert "list 0" in out, bad

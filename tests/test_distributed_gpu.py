@@ -156,3 +156,36 @@ def test_rccl_two_ranks_match_single_process(tmp_path):
     assert all("transport=rccl" in x for x in o)
     single = open(out1 + ".0", "rb").read()
     assert open(out2 + ".0", "rb").read() == single and open(out2 + ".1", "rb").read() == single
+
+
+@pytest.mark.gpu
+def test_python_builder_run_is_the_cpp_scheduler(tmp_path):
+    """pyposegraphbuilder.PoseGraphBuilder.run goes through libpgi_host.so (pgih_run_pairs, include/pgi_host.h): on the
+    V = 340 scene it returns the graph the C++ driver's A*-scheduled run writes -- same edges, scores, rotations,
+    translations, bit for bit -- and the same scheduler counters; with rotationGuided the guided driver's."""
+    from pyposegraphbuilder import PoseGraphBuilder
+    g, wave = SC.make_scene("v340")
+    path = str(tmp_path / "scene.bin")
+    write_scene(path, g, wave, sim_kind=2)
+    b, sim = g["batch"], SC.pair_similarity(g)
+    pairs = []
+    for e, (i, j) in enumerate(g["pairs"]):
+        a, z = int(b["offsets"][e]), int(b["offsets"][e + 1])
+        pairs.append(dict(src=int(i), dst=int(j), similarity=float(sim[e]), threshold=7.5e-4,
+                          correspondences=np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1)))
+    builder = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", True, True, True)
+    try:
+        for mode, guided in (("waves", False), ("waves_guided", True)):
+            run_ranks([EXE, path, str(tmp_path / mode), mode], 1)
+            stats, edges = SC.read_waves(open(str(tmp_path / mode) + ".0", "rb").read())
+            graph = builder.run(pairs, waveSize=wave, rotationGuided=guided)
+            assert len(graph) == len(edges) == stats["graph_edges"]
+            for r in edges:
+                ge = graph[(int(r["src"]), int(r["dst"]))]
+                assert ge["score"] == r["score"] and np.array_equal(ge["R"].ravel(), r["R"]) and np.array_equal(ge["t"], r["t"])
+            for key in ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess",
+                        "hypotheses", "waves", "quirk_only_guesses"):
+                assert builder.statistics[key] == stats[key], key
+            assert builder.statistics["paths_found"] > 0 and builder.statistics["poses_from_guess"] > 0
+    finally:
+        builder.close()

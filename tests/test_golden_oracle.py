@@ -44,3 +44,24 @@ def test_estimate_pose_guess_golden():
     # even pairs carry the true pose; pair 7's GARBAGE guess is accepted too: the reference's
     # un-squared threshold (graph_traversal.h:164) admits 33 px residuals, 20 of 257 rows qualify
     assert list(out["used_guess"]) == [1, 0, 1, 0, 1, 0, 1, 1]
+
+
+GN = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1_nister_lo.npz"))
+
+
+@pytest.mark.parametrize("tag,kw", [("", {}), ("_fixed", {"fixed_budget": 96}), ("_guess", {"guess": True})])
+def test_nister_only_local_optimisation_is_still_the_pre_change_behaviour(tag, kw):
+    """golden_v1_nister_lo.npz = the outputs golden_v1.npz held BEFORE the hybrid linear / n-point refit became the default
+    (taken from the repository history, commit b743299^, same inputs): lo_linear_pct = 0 must reproduce them byte for
+    byte, so that what the change did to the results is visible as the difference between the two fixtures."""
+    kw = dict(kw)
+    guess = kw.pop("guess", False)
+    out, masks = O.estimate_pose_batch(G["ep_x1"], G["ep_y1"], G["ep_x2"], G["ep_y2"], G["ep_offsets"], G["ep_thr"],
+                                       O.default_params(lo_linear_pct=0, **kw), int(G["ep_seed"]), pair_id_base=9000,
+                                       guesses=G["ep_guesses"] if guess else None, has_guess=np.ones(8, np.uint8) if guess else None)
+    old = GN["ep_out" + tag]
+    for k in old.dtype.names:
+        assert np.array_equal(out[k], old[k]), k
+    assert np.array_equal(masks, GN["ep_masks" + tag])
+    if not guess:  # and the change is a real one: the default's outputs differ on this fixture
+        assert not np.array_equal(G["ep_out" + tag]["E"], old["E"])

@@ -166,6 +166,23 @@ def test_estimate_pose_golden(eng, tag, kw):
     assert_edges_match(got, G["ep_out" + tag])
 
 
+@pytest.mark.parametrize("tag,fixed", [("", 0), ("_fixed", 96)])
+def test_estimate_pose_golden_nister_only_lo(eng, tag, fixed):
+    """lo_linear_pct = 0 on the device == the fixture's PRE-CHANGE outputs (tests/golden/golden_v1_nister_lo.npz, taken from
+    the repository history): the behaviour before the hybrid refit stays pinned."""
+    GN = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1_nister_lo.npz"))
+    eng.set_params(fixed_budget=fixed, lo_linear_pct=0)
+    try:
+        db = eng.upload(G["ep_x1"], G["ep_y1"], G["ep_x2"], G["ep_y2"], G["ep_offsets"], G["ep_thr"],
+                        seed=int(G["ep_seed"]), pair_id_base=9000)
+        edges, masks = eng.estimate_pose_batch(db)
+        got = eng.edges_to_numpy(edges)
+    finally:
+        eng.set_params(fixed_budget=0, lo_linear_pct=35)
+    assert np.array_equal(masks.cpu().numpy(), GN["ep_masks" + tag])
+    assert_edges_match(got, GN["ep_out" + tag])
+
+
 def test_estimate_pose_guess_golden(eng):
     db = eng.upload(G["ep_x1"], G["ep_y1"], G["ep_x2"], G["ep_y2"], G["ep_offsets"], G["ep_thr"],
                     guesses=G["ep_guesses"], seed=int(G["ep_seed"]), pair_id_base=9000)
@@ -301,6 +318,7 @@ def test_python_builder_surface():
                           correspondences=np.stack([batch[k][a:z] for k in ("x1", "y1", "x2", "y2")], 1)))
     g = b.run(pairs)
     assert set(g) == {(0, 1), (1, 2)}  # pair 2 has < kMinimumPointNumber matches, pair 3 is below the similarity threshold
+    assert b.statistics["pairs_processed"] == 2 and b.statistics["edges_added"] == 2 and b.statistics["waves"] == 1
     for (s_, d_), e in g.items():
         assert S.rot_err_deg(e["R"], batch["R"][s_]) < 1.0 and 0.3 < e["score"] < 0.7
     ok, R, t, mask, n_inl = b.estimatePose(pairs[0]["correspondences"], 7.5e-4)
@@ -534,6 +552,29 @@ def test_page_locked_host_batch_equals_device_batch(direct, monkeypatch):
         eng.close()
 
 
+def test_partially_page_locked_buffers_are_refused(eng):
+    """A caller may have page-locked a shorter range than the batch needs (a pinned slice of a larger array).  The HIP
+    runtime rejects copies that leave a registered range and a kernel working in place would fault past its end, so the
+    call checks both ends of every range up front and fails loudly; fully registered and fully pageable buffers work."""
+    from pyposegraphbuilder import _lib as L
+    P = 700
+    b = S.make_batch(np.arange(9100, 9100 + P), 600)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=5, pair_id_base=9)
+    e, m = eng.estimate_pose_batch(db)
+    ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+    xs = [np.array(b[k], np.float32) for k in ("x1", "y1", "x2", "y2")]
+    out = (np.zeros(P, ref.dtype), np.zeros(len(ref_m), np.uint8))
+    for part in ([xs[0][:len(xs[0]) // 2]], [out[1][:len(out[1]) // 3]], [xs[2][len(xs[2]) // 2:]]):   # a head, a head, a tail
+        eng.pin(*part)
+        try:
+            with pytest.raises(L.PgiError, match="only in part"):
+                eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=5, pair_id_base=9, out=out)
+        finally:
+            eng.unpin(*part)
+    got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=5, pair_id_base=9, out=out)
+    assert np.array_equal(got_m, ref_m) and np.array_equal(got["E"], ref["E"])
+
+
 def test_rotation_guided_guess_mode_matches_oracle(eng):
     """guess_mode = 1 (BASELINE config 5): keep the guess's rotation, re-estimate the translation direction
     from 32 two-point hypotheses, local optimisation, accept at min_inliers, else the robust fit -- bit-identical to the
@@ -632,3 +673,48 @@ def test_host_scoring_seam_from_twenty_threads(eng):
     assert reached and cnt == 5 and np.array_equal(np.nonzero(mask)[0], exp)
     # empty input
     assert eng.score_pose_host(np.zeros((0, 4)), np.eye(3), 1.0, early_exit_at=5, want_mask=False)[:2] == (False, 0)
+
+
+def test_config2_at_full_size_equals_the_oracle(eng):
+    """BASELINE config 2 in the suite at its stated size -- all 10 000 pairs x 2 000 correspondences, bench.py's own ids and
+    seed -- against the CPU oracle on every pair (OpenMP over the box's cores: about a second): identical masks, models,
+    counts, iteration and refit numbers; R within 1e-4 rad, t-direction cosine within 1e-3 (north_star's bars)."""
+    P, N, seed, thr = 10000, 2000, 0xB0BA, 7.5e-4
+    b = S.make_batch(np.arange(P), N)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=0)
+    edges, masks = eng.estimate_pose_batch(db)
+    got = eng.edges_to_numpy(edges)
+    exp, emasks = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, O.default_params(), seed,
+                                        pair_id_base=0)
+    assert np.array_equal(masks.cpu().numpy(), emasks)                     # identical inlier masks, 20 M rows
+    assert np.array_equal(got["E"], exp["E"])
+    for k in ("status", "n_inl", "score", "iters", "lo_runs", "votes", "cand", "used_guess"):
+        assert np.array_equal(got[k], exp[k]), k
+    ok = exp["status"] == 1
+    assert ok.sum() >= 0.999 * P
+    Rg, Re = got["R"][ok].reshape(-1, 3, 3), exp["R"][ok].reshape(-1, 3, 3)
+    ang = np.arccos(np.clip((np.einsum("kij,kij->k", Rg, Re) - 1) / 2, -1, 1))
+    assert ang.max() < R_TOL_RAD
+    assert np.einsum("ki,ki->k", got["t"][ok], exp["t"][ok]).min() > 1 - T_COS_TOL
+    errs = np.array([S.rot_err_deg(got["R"][i].reshape(3, 3), b["R"][i]) if ok[i] else np.inf for i in range(P)])
+    assert S.auc_at(errs) > 0.985
+
+
+def test_config1_single_pair_of_2000_correspondences(eng):
+    """BASELINE config 1 ("single pair, 2k synthetic corrs", the examples/cpp_example.cpp path): exactly N = 2000 through the
+    literal seam pgi_estimate_pose (host pointers, cv::Mat N x 4 CV_64F layout), with and without a pose guess, against
+    the oracle's pgo_estimate_pose."""
+    d = S.make_pair(424242, 2000)
+    corr = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1).astype(np.float64)
+    assert corr.shape == (2000, 4)
+    thr, seed, pid = 7.5e-4, 31, 424242
+    guess = np.concatenate([d["R"].ravel(), d["t"]])
+    for g in (None, guess):
+        ok, e, mask = eng.estimate_pose(corr, thr, guesses=None if g is None else g[None], seed=seed, pair_id=pid)
+        oe, omask = O.estimate_pose(d["x1"], d["y1"], d["x2"], d["y2"], thr, g, O.default_params(), seed, pid)
+        assert ok and e.status == oe.status == 1
+        assert np.array_equal(mask, omask) and np.array_equal(np.array(e.E), np.array(oe.E))
+        assert (e.n_inl, e.iters, e.lo_runs, e.used_guess) == (oe.n_inl, oe.iters, oe.lo_runs, oe.used_guess)
+        assert e.used_guess == (0 if g is None else 1)
+        assert rot_angle(np.array(e.R), np.array(oe.R)) < R_TOL_RAD and np.array(e.t) @ np.array(oe.t) > 1 - T_COS_TOL
+        assert S.rot_err_deg(np.array(e.R).reshape(3, 3), d["R"]) < (0.1 if g is None else 2.0)
