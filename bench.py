@@ -266,6 +266,37 @@ def main():
         ms = a.elapsed_time(z)
         out["fixed_budget_256"] = {"edges_per_s": round(P / (ms * 1e-3), 1), "kernel_ms": round(ms, 3)}
         eng.set_params(fixed_budget=args.fixed_budget)
+        # Two batches in flight (never `value`): a launch of 10 000 pairs ends with a drain -- the last workgroups, a few of
+        # them on pairs that need 300-1000 hypotheses, keep the kernel alive while most CUs are already idle
+        # (scripts/k1_tail_probe.py: T(P) = 0.89 ms + P / 1.79 M edges/s, i.e. 14 % of this launch).  Independent batches on
+        # two contexts / streams fill each other's drain; this is what a caller with more than one batch at hand gets.
+        eng2 = Engine(fixed_budget=args.fixed_budget)
+        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+        edges_b, masks_b = torch.empty_like(edges), torch.empty_like(masks)
+        with torch.cuda.stream(s_b):
+            db_b = eng2.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=pair_base)
+        torch.cuda.synchronize()
+
+        def two_in_flight(k):
+            for i in range(k):
+                if i % 2 == 0:
+                    with torch.cuda.stream(s_a):
+                        eng.estimate_pose_batch(db, edges, masks)
+                else:
+                    with torch.cuda.stream(s_b):
+                        eng2.estimate_pose_batch(db_b, edges_b, masks_b)
+        two_in_flight(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        two_in_flight(args.steps)
+        torch.cuda.synchronize()
+        t_pipe2 = time.perf_counter() - t0
+        same_b = bool(torch.equal(edges_b, edges) and torch.equal(masks_b, masks))
+        eng2.close()
+        eng._bind_stream()
+        out["two_batches_in_flight"] = {"edges_per_s": round(P * args.steps / t_pipe2, 1), "ms_per_batch": round(1e3 * t_pipe2 / args.steps, 3),
+                                        "identical_results": same_b,
+                                        "note": "the same %d steps alternating between two contexts on two streams; not `value` (one batch at a time)" % args.steps}
         # PCIe-inclusive rate (never `value`), headline variant first: page-locked caller buffers (hipHostMalloc, here through
         # torch's pinned allocator) -- K1 works on them in place over PCIe: it reads every row once and writes every result once
         px = [torch.from_numpy(np.ascontiguousarray(b[k], np.float32)).pin_memory().numpy() for k in ("x1", "y1", "x2", "y2")]

@@ -78,4 +78,9 @@ struct pgi_ctx {
     int match_waves = 4;  // wavefronts per matching workgroup (4 or 8; env PGI_MATCH_WAVES)
     int lds_min_wgs = 2;  // stage rows in LDS only if this many workgroups still fit per CU
     int hybrid_rows = 1;  // pairs just above the 4-workgroup LDS capacity keep their tail rows in HBM/L2 (env PGI_HYBRID_ROWS)
+    // ragged batches: the occupancy classes of one batch are independent launches; they run CONCURRENTLY on side streams
+    // (fork / join by events around the caller's stream), so one class's workgroups fill the tail of another's
+    hipStream_t class_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t class_fork = nullptr, class_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int class_overlap = 1;  // env PGI_CLASS_OVERLAP=0: one class after the other on the caller's stream
 };

@@ -1435,6 +1435,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
+    if (const char* e = getenv("PGI_CLASS_OVERLAP")) c->class_overlap = atoi(e);
     if (const char* e = getenv("PGI_HOST_DIRECT")) c->host_direct = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
@@ -1483,6 +1484,11 @@ void pgi_destroy(pgi_ctx* ctx) {
         if (ctx->h_match_stage[k]) (void)hipHostFree(ctx->h_match_stage[k]);
         if (ctx->match_stage_ev[k]) (void)hipEventDestroy(ctx->match_stage_ev[k]);
     }
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->class_stream[k]) (void)hipStreamDestroy(ctx->class_stream[k]);
+        if (ctx->class_join[k]) (void)hipEventDestroy(ctx->class_join[k]);
+    }
+    if (ctx->class_fork) (void)hipEventDestroy(ctx->class_fork);
     if (ctx->d_direct) (void)hipFree(ctx->d_direct);
     if (ctx->d_mirror) (void)hipFree(ctx->d_mirror);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
@@ -1568,21 +1574,22 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
     const uint32_t cap4 = rows_cap(4), cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
     bool hybrid = false;
+    hipStream_t ls = stream;  // the stream the next launch goes to (a class's side stream when classes overlap)
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + (hybrid ? fixed_stash : fixed);
         if (hybrid) {  // first cap_rows rows in LDS, the tail from HBM/L2
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
         } else {
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), dim3(b->n_pairs), dim3(NT), lds, stream, a);
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
         }
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed_stash, stream, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed_stash, stream, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed_stash, ls, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed_stash, ls, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
@@ -1610,17 +1617,38 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
         hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, stream, b->d_offsets,
                            b->n_pairs, cap4, cap3, cap2, cap1, lists, counts);
         const uint32_t caps[4] = {cap4, cap3, cap2, cap1};
-        for (int k = 0; k < 5; ++k) {
-            if (k > 0 && cap <= caps[k - 1]) break;  // no pair can be this large
+        int n_classes = 1;
+        while (n_classes < 5 && cap > caps[n_classes - 1]) ++n_classes;  // classes a pair of this batch can fall into
+        // The classes are independent launches (disjoint pairs, disjoint outputs).  With more than one, all but the last
+        // go to side streams that wait for the bucket lists (fork event) and are joined back into the caller's stream:
+        // the workgroups of one class fill the CUs another class's tail leaves idle, and an empty class costs nothing.
+        bool overlap = ctx->class_overlap && n_classes > 1;
+        if (overlap) {
+            if (!ctx->class_fork && hipEventCreateWithFlags(&ctx->class_fork, hipEventDisableTiming) != hipSuccess) overlap = false;
+            for (int k = 0; k < n_classes - 1 && overlap; ++k) {
+                if (!ctx->class_stream[k] && hipStreamCreateWithFlags(&ctx->class_stream[k], hipStreamNonBlocking) != hipSuccess) overlap = false;
+                if (overlap && !ctx->class_join[k] && hipEventCreateWithFlags(&ctx->class_join[k], hipEventDisableTiming) != hipSuccess) overlap = false;
+            }
+            if (!overlap) (void)hipGetLastError();
+        }
+        if (overlap) HIP_TRY(hipEventRecord(ctx->class_fork, stream));
+        for (int k = 0; k < n_classes; ++k) {
             a.pair_list = lists + (size_t)k * b->n_pairs;
             a.pair_count = counts + k;
+            const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
+            ls = side ? ctx->class_stream[k] : stream;
+            if (side) HIP_TRY(hipStreamWaitEvent(ls, ctx->class_fork, 0));
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
             hybrid = k == 1 && ctx->hybrid_rows;
             if (hybrid) launch_lds(rows_cap_of(4, fixed_stash));  // 1280 rows in LDS next to the sample stash
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;
+            if (side) HIP_TRY(hipEventRecord(ctx->class_join[k], ls));
         }
+        ls = stream;
+        if (overlap)
+            for (int k = 0; k < n_classes - 1; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->class_join[k], 0));
     }
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
