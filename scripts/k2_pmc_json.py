@@ -21,9 +21,9 @@ def read(tag, kernel="score_pose_kernel"):
         m = re.search(r"(\S+)\s+n=(\d+)\s+sum=(\S+)", line)
         if m:
             vals[m.group(1)] = float(m.group(3)) / int(m.group(2))
-        else:
-            f = line.split(")")[-1].split()
-            calls, avg_us = int(f[0]), float(f[2])
+        else:  # "<name (cut at 60 chars)>  calls  total_us  avg_us  %  vgpr agpr sgpr lds"
+            f = line.split()
+            calls, avg_us = int(f[-8]), float(f[-6])
     return vals, avg_us, calls
 
 
