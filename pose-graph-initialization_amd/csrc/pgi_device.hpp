@@ -182,6 +182,34 @@ PGI_DEV void sample5(uint64_t base, uint32_t hyp, uint32_t n, uint32_t idx[5]) {
     }
 }
 
+// The same five indices, drawn cooperatively by a 16-lane group (K1's passes; round 3).  sample5 makes every lane hash
+// all eight candidate draws and run the whole acceptance cascade (~320 instructions, 24 of them quarter-rate integer
+// multiplies); here sub-lane k < 8 hashes draw k only, "repeats an accepted index" becomes "equals an earlier draw" (a draw
+// rejected earlier equals an accepted one, so the two tests coincide; seven DPP row shifts), the accepted draws are ranked
+// by a ballot and the first five travel through `slot` (five words of group-private LDS that are dead at this point).
+// Wave-uniform slow path -- some group has fewer than five distinct values among its first eight draws (tiny pairs) --
+// is sample5 itself, so the result is sample5's in every case.
+PGI_DEV void sample5_group(uint64_t base, uint32_t hyp, uint32_t n, int s, int gbase, int lane, uint32_t* slot, uint32_t idx[5]) {
+    const uint32_t cand = draw_index(base, hyp, (uint32_t)(s & 7), n);
+    bool dup = false;
+#define PGI_SHR_CMP(K) dup |= (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)cand, 0x110 + K, 0xF, 0xF, false) == cand;
+    PGI_SHR_CMP(1) PGI_SHR_CMP(2) PGI_SHR_CMP(3) PGI_SHR_CMP(4) PGI_SHR_CMP(5) PGI_SHR_CMP(6) PGI_SHR_CMP(7)
+#undef PGI_SHR_CMP
+    const bool acc = s < 8 && !dup;  // (row_shr leaves the sentinel in sub-lanes below K: never equal to an index < n)
+    const uint32_t gm = (uint32_t)(__ballot(acc) >> gbase) & 0xFFu;
+    const bool enough = __popc(gm) >= 5;
+    if (__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(enough))) == 64) {
+        const uint32_t rank = (uint32_t)__popc(gm & ((1u << s) - 1u));
+        if (acc && rank < 5u) slot[rank] = cand;
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) idx[k] = slot[k];
+        wave_sync();
+    } else {
+        sample5(base, hyp, n, idx);
+    }
+}
+
 // ---- Sampson terms (f32; the scoring primitive) ---------------------------------
 // r = p2^T E p1 and the gradient norm of graph_traversal.h:107-115, evaluated with
 // one fused multiply-add per term.

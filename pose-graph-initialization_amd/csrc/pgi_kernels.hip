@@ -349,14 +349,14 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
     wave_sync();
     const int m = lane / 9, l = lane - 9 * m;
     const bool act = lane < 36;
+    // pair m of round r is ((r + m + 1) mod 9, (r + 8 - m) mod 9): both members advance by one per round, so they are
+    // carried and wrapped instead of recomputed (the two modulo-9 reductions per round were integer multiply sequences)
+    int pr = act ? m + 1 : 1, qr = act ? 8 - m : 8;
     for (int sw = 0; sw < kJacobiSweeps; ++sw)
         for (int r = 0; r < 9; ++r) {
-            int p = (r + m + 1) % 9, q = (r + 9 - (m + 1)) % 9;
-            if (p > q) {
-                const int tq = p;
-                p = q;
-                q = tq;
-            }
+            const int p = min(pr, qr), q = max(pr, qr);
+            pr = pr == 8 ? 0 : pr + 1;
+            qr = qr == 8 ? 0 : qr + 1;
             double c = 1.0, s = 0.0;
             if (act) {
                 const double apq = A[9 * p + q];
@@ -790,15 +790,17 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
             const uint32_t local = pass * 4 + g;
             const bool active = local < rs;
             const uint32_t hyp = base_hyp + (active ? local : 0u);
+            const GroupScratch gs = group_scratch(wscr, g);
             uint32_t idx[5];
-            sample5(rng_base, hyp, prm.sampler ? progressive_rows(hyp, n, prm.max_iters) : n, idx);
+            // (region A of the group is dead between passes: the five accepted draws travel through its first words)
+            sample5_group(rng_base, hyp, prm.sampler ? progressive_rows(hyp, n, prm.max_iters) : n, s, g * 16, ln,
+                          reinterpret_cast<uint32_t*>(gs.rega), idx);
             uint32_t my = idx[0];
 #pragma unroll
             for (int k = 1; k < 5; ++k)
                 if (s == k) my = idx[k];
             const float4 mine = rows.get(my);
             prof.mark<1>();
-            const GroupScratch gs = group_scratch(wscr, g);
             nullspace5_group(mine, s, g * 16, gs);
             prof.mark<2>();
             float E32[9];
