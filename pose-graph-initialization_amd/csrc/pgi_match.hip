@@ -1068,6 +1068,439 @@ __global__ __launch_bounds__(256) void guided_scan_binned_kernel(const GuidedPai
     }
 }
 
+// ---- the same candidates found through a fine angular index (round 3) -----------------------------------------------------
+// The 45 bins of the reference save little when the epipole lies far outside the image -- the usual case: nearly all
+// keypoints then share two or three bins, and where a source's bin coincides with a populated destination bin the source
+// still meets hundreds to thousands of destinations (config 3 from features: 51 % of the GPU time).  But the gate itself
+// confines the candidates far more tightly: dist = r^2 (a1 + b1) / (a1 b1) >= r^2 / a1 = (distance of x1 from the
+// destination's epipolar line l_j = F^T x2 in the SOURCE image)^2, every l_j passes through the source epipole e, so a
+// destination can pass the gate of a source at distance d from e only if the angle between (x1 - e) and l_j is below
+// asin(0.75 / d) -- a window of a few 1e-4 rad in the normal angle of l_j, the very angle the reference bins by.
+// Destinations are counting-sorted by that angle at kGaBuckets times the resolution of... the pair's own range
+// [min_angle, min_angle + range] (guided_angle_bucket_kernel); a bin is a contiguous run of fine buckets, and a source
+// visits only the fine buckets that lie BOTH in its bin and in its window (+- one for rounding), applies the same bin
+// equality and exact gate as before and evaluates the survivors in ascending destination index -- the order the reference
+// meets them in, which `second` depends on.  Degenerate records (zero / non-finite normal or angle) live in an extra bucket
+// every source visits; a source with an odd window visits its whole bin.
+constexpr int kGaBuckets = 8192;
+constexpr int kGaList = 16;    // candidates a thread collects per round
+struct GaEntry {      // 48 B per destination keypoint, in bucket order
+    double rxc, ryc, rwc, a1;
+    uint32_t j;
+    int32_t bin;
+    uint32_t pad[2];
+};
+// the reference's angle of a line normal in degrees, folded to (0, 180] (matcher.h:292-296), and its place in the pair's range
+__device__ __forceinline__ double ga_angle(double ny, double nx) {
+    double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
+    if (angle > 180) angle -= 180;
+    return angle;
+}
+// fine bucket of an angle inside [amin, amax], the span the pair's destination angles really cover (far narrower than
+// the corner-derived [min_angle, min_angle + range] the bins divide); clamped at both ends; -1: not a number
+__device__ __forceinline__ int ga_fine(double angle, double amin, double amax) {
+    if (!(angle == angle)) return -1;
+    const double f = (angle - amin) * ((double)kGaBuckets / fmax(amax - amin, 1.0e-9));
+    return !(f > 0.0) ? 0 : (f >= (double)(kGaBuckets - 1) ? kGaBuckets - 1 : (int)f);
+}
+// centre of a source keypoint's window in the folded degrees: the normal of the line through the epipole and the keypoint
+__device__ __forceinline__ double ga_source_centre(double vx, double vy) {
+    double c = kRadianToDegree * atan2(vy, vx) + 90.0;
+    c -= floor(c / 180.0) * 180.0;  // [0, 180)
+    return c;
+}
+// grid (pairs), 1024 threads: records, bins and fine buckets of the destination keypoints; then the source keypoints in the
+// order of their windows, so that the threads of a scanning workgroup visit the same few buckets and descriptor rows
+__global__ __launch_bounds__(1024) void guided_angle_bucket_kernel(const GuidedPair* __restrict__ pairs, GaEntry* __restrict__ entries,
+                                                                   uint32_t* __restrict__ keys /* per destination: its bucket */,
+                                                                   uint32_t* __restrict__ starts /* pairs x (kGaBuckets + 2) */,
+                                                                   double* __restrict__ spans /* pairs x {smallest, largest angle} */,
+                                                                   uint32_t* __restrict__ order /* per pair: sources by window */) {
+    __shared__ uint32_t cnt[kGaBuckets + 1];
+    __shared__ uint32_t part[1024];
+    const GuidedPair P = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    __shared__ unsigned long long span[2];  // bit patterns of the smallest / largest angle (positive doubles order like integers)
+    for (uint32_t i = tid; i <= (uint32_t)kGaBuckets; i += 1024u) cnt[i] = 0;
+    if (tid == 0) { span[0] = ~0ull; span[1] = 0ull; }
+    __syncthreads();
+    for (uint32_t j = tid; j < P.n2; j += 1024u) {
+        const double x2 = (double)P.kp2[2 * (size_t)j], y2 = (double)P.kp2[2 * (size_t)j + 1];
+        const double rxc = (P.F[0] * x2 + P.F[3] * y2) + P.F[6];
+        const double ryc = (P.F[1] * x2 + P.F[4] * y2) + P.F[7];
+        const double a1 = rxc * rxc + ryc * ryc;
+        if (a1 > 0.0 && a1 < 1.0e300) {
+            const double ang = ga_angle(ryc, rxc);
+            if (ang > 0.0) {  // (0, 180]; NaN fails
+                atomicMin(&span[0], (unsigned long long)__double_as_longlong(ang));
+                atomicMax(&span[1], (unsigned long long)__double_as_longlong(ang));
+            }
+        }
+    }
+    __syncthreads();
+    const double amin = span[0] == ~0ull ? 0.0 : __longlong_as_double((long long)span[0]);
+    const double amax = span[1] == 0ull ? 180.0 : __longlong_as_double((long long)span[1]);
+    if (tid == 0) {  // the scan maps its intervals through the same span
+        double* sp = reinterpret_cast<double*>(spans) + 2 * (size_t)blockIdx.x;
+        sp[0] = amin;
+        sp[1] = amax;
+    }
+    for (uint32_t j = tid; j < P.n2; j += 1024u) {
+        const double x2 = (double)P.kp2[2 * (size_t)j], y2 = (double)P.kp2[2 * (size_t)j + 1];
+        const double rxc = (P.F[0] * x2 + P.F[3] * y2) + P.F[6];
+        const double ryc = (P.F[1] * x2 + P.F[4] * y2) + P.F[7];
+        const double a1 = rxc * rxc + ryc * ryc;
+        int kb = -1;
+        if (a1 > 0.0 && a1 < 1.0e300) kb = ga_fine(ga_angle(ryc, rxc), amin, amax);
+        const uint32_t k = kb < 0 ? (uint32_t)kGaBuckets : (uint32_t)kb;  // degenerate: the bucket every source visits
+        keys[P.off2 + j] = k;
+        atomicAdd(&cnt[k], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the kGaBuckets regular counters: 1024 threads x 8
+    uint32_t local[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { local[k] = cnt[tid * 8u + k]; sum += local[k]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    uint32_t* st = starts + (size_t)blockIdx.x * (kGaBuckets + 2);
+    const uint32_t n_deg = cnt[kGaBuckets];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { st[tid * 8u + k] = run; cnt[tid * 8u + k] = run; run += local[k]; }
+    if (tid == 1023u) {
+        st[kGaBuckets] = run;                         // the degenerate bucket follows the regular ones
+        st[kGaBuckets + 1] = run + n_deg;
+        cnt[kGaBuckets] = run;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < P.n2; j += 1024u) {
+        const double x2 = (double)P.kp2[2 * (size_t)j], y2 = (double)P.kp2[2 * (size_t)j + 1];
+        const double rxc = (P.F[0] * x2 + P.F[3] * y2) + P.F[6];
+        const double ryc = (P.F[1] * x2 + P.F[4] * y2) + P.F[7];
+        const double rwc = (P.F[2] * x2 + P.F[5] * y2) + P.F[8];
+        const uint32_t pos = atomicAdd(&cnt[keys[P.off2 + j]], 1u);  // (order inside a bucket is arbitrary: candidates are sorted later)
+        GaEntry e;
+        e.rxc = rxc; e.ryc = ryc; e.rwc = rwc; e.a1 = rxc * rxc + ryc * ryc;
+        e.j = j;
+        e.bin = epipolar_bin(ryc, rxc, P.min_angle, P.range, P.bins);
+        e.pad[0] = e.pad[1] = 0;
+        entries[P.off2 + pos] = e;
+    }
+    // the sources, counting-sorted by the bucket of their window centre (any order is correct; this one is cache friendly)
+    __syncthreads();
+    for (uint32_t i = tid; i <= (uint32_t)kGaBuckets; i += 1024u) cnt[i] = 0;
+    __syncthreads();
+    auto source_key = [&](uint32_t i) -> uint32_t {
+        const double vx = (double)P.kp1[2 * (size_t)i] - P.ep0, vy = (double)P.kp1[2 * (size_t)i + 1] - P.ep1;
+        const int kb = ga_fine(ga_source_centre(vx, vy), amin, amax);
+        return kb < 0 ? 0u : (uint32_t)kb;
+    };
+    for (uint32_t i = tid; i < P.n1; i += 1024u) atomicAdd(&cnt[source_key(i)], 1u);
+    __syncthreads();
+    sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { local[k] = cnt[tid * 8u + k]; sum += local[k]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    run = part[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cnt[tid * 8u + k] = run; run += local[k]; }
+    __syncthreads();
+    for (uint32_t i = tid; i < P.n1; i += 1024u) order[P.off + atomicAdd(&cnt[source_key(i)], 1u)] = i;
+}
+
+constexpr int kGtRows = 16;        // destination descriptor rows a wavefront stages in LDS at a time
+constexpr int kGtStride = kD + 4;  // floats per staged row: 16-byte aligned rows, rows 16 apart share banks
+constexpr int kGtRecs = 176;       // destination records staged at a time, in the same memory (48 B each)
+// grid (ceil(n1 / (64 / G)), pairs), ONE wavefront per workgroup: 64 / G sources that are neighbours in window order, G lanes
+// each (lane g of a source takes the records at positions = g mod G, so the lanes of a source share its work evenly).
+//   (1) every lane keeps its source's descriptor in 128 registers;
+//   (2) the records of the few fine buckets the gate window and the bin leave are staged in LDS from the smallest position any
+//       lane still needs; a lane lists the gate-passing destinations of its share (destination index, record position), the
+//       kGaList smallest destination indices in sorted registers;
+//   (3) the wavefront stages the records' descriptor rows kGtRows at a time -- neighbours in window order want the same rows,
+//       so a row is fetched once per wavefront instead of once per (source, candidate) -- and each lane sums the squared
+//       differences of its listed candidates that lie in the staged rows, sequentially in double (fma(v, v, dd) is
+//       dd + v * v exactly: the product of two f32-valued doubles is exact), every bit of matcher.h:352-371;
+//   (4) matcher.h:352-371 meets the candidates in ascending destination index and keeps `best` and `second` = the best BEFORE
+//       the last improvement.  The last improvement is the first candidate that attains the overall minimum, so
+//       second = min{distance of c : index of c < index of that candidate} -- which needs no particular evaluation order.
+//       A source with more than its lists hold is handled in rounds of ascending index ranges.
+template <int G>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_scan_tile_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
+    const double* __restrict__ spans, const uint32_t* __restrict__ order, int32_t* __restrict__ best_out, double* __restrict__ ratio_out) {
+    static_assert(G == 1 || G == 2 || G == 4, "lanes per source");
+    constexpr uint32_t kSources = 64u / G;
+    __shared__ uint32_t list[kGaList][64];  // (destination index << 16 | record position), ascending
+    __shared__ double dist[kGaList][64];
+    __shared__ __attribute__((aligned(16))) float tile[kGtRows][kGtStride];
+    const GuidedPair P = pairs[blockIdx.y];
+    const uint32_t lane = threadIdx.x, slot = lane / G, g = lane % G;
+    if (blockIdx.x * kSources >= P.n1) return;      // (wavefront-uniform; in a live wavefront every lane stays for the shared steps)
+    const bool active = blockIdx.x * kSources + slot < P.n1;
+    const uint32_t i = active ? order[P.off + blockIdx.x * kSources + slot] : 0u;
+    const double x1 = (double)P.kp1[2 * (size_t)i], y1 = (double)P.kp1[2 * (size_t)i + 1];
+    const double rx = (P.F[0] * x1 + P.F[1] * y1) + P.F[2];
+    const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
+    const double b1 = rx * rx + ry * ry;
+    const double vx = x1 - P.ep0, vy = y1 - P.ep1;
+    const int32_t my_bin = epipolar_bin(vx, -vy, P.min_angle, P.range, P.bins);  // as guided_bucket_kernel's side 0
+    const uint32_t* st = starts + (size_t)blockIdx.y * (kGaBuckets + 2);
+    const double amin = spans[2 * (size_t)blockIdx.y], amax = spans[2 * (size_t)blockIdx.y + 1];
+    // the fine buckets of this source's bin: bin = round((bins - 1) u), u = (angle - min_angle) / range  <=>  the angle lies
+    // between min_angle + (bin -+ 0.5) range / (bins - 1) (either order: range is negative for an in-image epipole)
+    int f0 = 0, f1 = kGaBuckets - 1;
+    if (P.bins > 1 && P.range == P.range && P.range != 0.0) {
+        const double step = P.range / (double)(P.bins - 1);
+        const double ea = P.min_angle + ((double)my_bin - 0.5) * step, eb = P.min_angle + ((double)my_bin + 0.5) * step;
+        const bool open_lo = my_bin == 0, open_hi = my_bin == P.bins - 1;  // the end bins also take everything beyond the range
+        double lo_ang = fmin(ea, eb), hi_ang = fmax(ea, eb);
+        if ((open_lo && step > 0.0) || (open_hi && step < 0.0)) lo_ang = -1.0e300;
+        if ((open_hi && step > 0.0) || (open_lo && step < 0.0)) hi_ang = 1.0e300;
+        f0 = max(0, ga_fine(lo_ang, amin, amax) - 1);
+        f1 = min(kGaBuckets - 1, ga_fine(hi_ang, amin, amax) + 1);
+    }
+    // the window the gate leaves: the line through e and x1 has direction atan2(vy, vx); a gate-passing l_j deviates from it by
+    // less than asin(0.75 / d), and its NORMAL is a quarter turn away.  In the reference's folded degrees:
+    int g0[2] = {0, 0}, g1[2] = {kGaBuckets - 1, -1};  // up to two pieces (the window may straddle the fold at 0 / 180)
+    const double d2 = vx * vx + vy * vy;
+    if (d2 > 4.0 && d2 < 1.0e300 && b1 > 0.0 && b1 < 1.0e300) {
+        const double c = ga_source_centre(vx, vy);
+        const double half = kRadianToDegree * asin(0.75 / sqrt(d2)) * 1.0001 + 1.0e-5;  // margin for rounding
+        if (2.0 * half < 179.0) {
+            double lo[2] = {c - half, 0.0}, hi[2] = {c + half, -1.0};  // pieces of [c - half, c + half] folded into (0, 180]
+            if (lo[0] <= 0.0) { lo[1] = lo[0] + 180.0; hi[1] = 180.0; lo[0] = 0.0; }
+            else if (hi[0] > 180.0) { lo[1] = 0.0; hi[1] = hi[0] - 180.0; hi[0] = 180.0; }
+            for (int k = 0; k < 2; ++k) {
+                if (hi[k] < lo[k]) { g0[k] = 0; g1[k] = -1; continue; }
+                const int fa = ga_fine(lo[k], amin, amax), fb = ga_fine(hi[k], amin, amax);
+                if (fa < 0 || fb < 0) { g0[k] = 0; g1[k] = kGaBuckets - 1; continue; }
+                g0[k] = max(0, fa - 1);
+                g1[k] = min(kGaBuckets - 1, fb + 1);
+            }
+        }
+    }
+    // the fine-bucket intervals to visit: window pieces cut to the bin's interval; merged when the margins made them meet
+    int v0[2], v1[2];
+    for (int k = 0; k < 2; ++k) { v0[k] = max(g0[k], f0); v1[k] = min(g1[k], f1); }
+    if (v1[0] >= v0[0] && v1[1] >= v0[1] && v0[1] <= v1[0] + 1 && v0[0] <= v1[1] + 1) {
+        v0[0] = min(v0[0], v0[1]);
+        v1[0] = max(v1[0], v1[1]);
+        v1[1] = v0[1] - 1;  // empty
+    }
+    auto wave_sync = [] {  // LDS written by some lanes is read by others of the same wavefront
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // (1) through the tile, so that the 512-byte rows are read whole: kGtRows sources at a time, their lanes keep the row
+    float a[kD];
+    static_assert(kGtRows == 16, "sixteen rows in flight per pass");
+    for (uint32_t part = 0; part < kSources / kGtRows; ++part) {
+        {
+            float2 bv[16];
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)i, (int)((kGtRows * part + u) * G));
+                bv[u] = reinterpret_cast<const float2*>(P.d1 + (size_t)ir * kD)[lane];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+        }
+        wave_sync();
+        if (slot / (uint32_t)kGtRows == part) {
+            const float4* row = reinterpret_cast<const float4*>(&tile[slot % (uint32_t)kGtRows][0]);
+#pragma unroll
+            for (int q = 0; q < kD / 4; ++q) {
+                const float4 t = row[q];
+                a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            }
+        }
+        wave_sync();
+    }
+    // this source's record ranges: the (at most two) window pieces and the degenerate records every source visits
+    uint32_t re0[3] = {0u, 0u, st[kGaBuckets]}, re1[3] = {0u, 0u, st[kGaBuckets + 1]};
+    for (int k = 0; k < 2; ++k)
+        if (v1[k] >= v0[k]) { re0[k] = st[v0[k]]; re1[k] = st[v1[k] + 1]; }
+    if (!active) re1[0] = re0[0] = re1[1] = re0[1] = re1[2] = re0[2] = 0u;
+    static_assert(sizeof(GaEntry) == 48 && kGtRecs * sizeof(GaEntry) <= sizeof(float) * kGtRows * kGtStride, "records are staged in the tile");
+    GaEntry* recs = reinterpret_cast<GaEntry*>(&tile[0][0]);
+    // (2) this lane's gate-passing destinations with index > after: the kGaList smallest go to `list`; returns how many in all
+    auto collect = [&](int64_t after) -> uint32_t {
+        uint32_t total = 0;
+        uint32_t L[kGaList];  // ascending; unused places hold the largest number
+#pragma unroll
+        for (int p2 = 0; p2 < kGaList; ++p2) L[p2] = 0xFFFFFFFFu;
+        uint32_t c0[3] = {re0[0], re0[1], re0[2]};  // cursors
+        while (true) {
+            uint32_t need = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (c0[k] < re1[k]) need = min(need, c0[k]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) need = min(need, (uint32_t)__shfl_xor((int)need, d));
+            if (need == 0xFFFFFFFFu) break;
+            const uint32_t E = need, nrec = min((uint32_t)kGtRecs, P.n2 - E);
+            wave_sync();
+            {   // 48-byte records as 16-byte pieces, coalesced
+                const uint4* src = reinterpret_cast<const uint4*>(entries + P.off2 + E);
+                uint4* dst = reinterpret_cast<uint4*>(recs);
+                for (uint32_t q = lane; q < nrec * 3u; q += 64u) dst[q] = src[q];
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t lo = max(c0[k], E), hi = min(re1[k], E + nrec);
+                for (uint32_t e = lo + (g + G - lo % G) % G; e < hi; e += G) {  // this lane's share: positions = g mod G
+                    const GaEntry en = recs[e - E];
+                    if (en.bin != my_bin || (int64_t)en.j <= after) continue;
+                    const double r = (x1 * en.rxc + y1 * en.ryc) + en.rwc;
+                    const double num = (r * r) * (en.a1 + b1), den = en.a1 * b1;
+                    if (den > 0.0 && num >= 0.57 * den) continue;  // surely far (the pre-test of the binned scan)
+                    if (!(den > 0.0 && num <= 0.56 * den)) {        // not surely near either: the reference's quotient decides
+                        const double dd = num / den;
+                        if (dd >= 0.75 * 0.75) continue;
+                    }
+                    ++total;
+                    // sorted insertion, the largest dropping out when full: L'[p] = median(L[p - 1], L[p], key)
+                    const uint32_t key = (en.j << 16) | e;
+#pragma unroll
+                    for (int p2 = kGaList - 1; p2 >= 1; --p2) L[p2] = max(L[p2 - 1], min(L[p2], key));
+                    L[0] = min(L[0], key);
+                }
+                if (hi > c0[k]) c0[k] = hi;
+            }
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < kGaList; ++p2) list[p2][lane] = L[p2];
+        return total;
+    };
+    auto group_min_u32 = [](uint32_t v) {
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+        return v;
+    };
+    double best = DBL_MAX, second = DBL_MAX;
+    int32_t best_index = -1;
+    uint32_t count = 0;
+    int64_t after = -1;
+    bool more = true;  // (the same for the lanes of a source)
+    while (__any(more)) {
+        const uint32_t total = collect(more ? after : (int64_t)0x7FFFFFFF);  // (every lane takes part in the staging; a finished source lists nothing)
+        // a lane that found more than it lists holds all of its share up to its largest listed index: the round covers the
+        // indices up to the smallest such bound among the source's lanes; the rest waits for the next round
+        const uint32_t jcap = group_min_u32(total > (uint32_t)kGaList ? (list[kGaList - 1][lane] >> 16) : 0xFFFFFFFFu);
+        uint32_t nlist = 0;
+        for (uint32_t c = 0; c < min(total, (uint32_t)kGaList); ++c) nlist += (list[c][lane] >> 16) <= jcap ? 1u : 0u;  // (a prefix: ascending)
+        // (3) until no lane has an unevaluated candidate: stage the rows from the smallest pending record position on
+        uint32_t pend = nlist ? (0xFFFFFFFFu >> (32u - nlist)) : 0u;
+        while (true) {
+            uint32_t emin = 0xFFFFFFFFu;
+            for (uint32_t m = pend; m; m &= m - 1u) emin = min(emin, list[__builtin_ctz(m)][lane] & 0xFFFFu);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) emin = min(emin, (uint32_t)__shfl_xor((int)emin, d));
+            if (emin == 0xFFFFFFFFu) break;
+            const uint32_t E = emin, nrow = min((uint32_t)kGtRows, P.n2 - E);
+            const uint32_t rj = lane < nrow ? entries[P.off2 + E + lane].j : 0u;
+            wave_sync();
+            {
+                float2 bv[16];
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; ++u) {
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rj, (int)u);
+                    if (u < nrow) bv[u] = reinterpret_cast<const float2*>(P.d2 + (size_t)j * kD)[lane];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; ++u)
+                    if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+            }
+            wave_sync();
+            uint32_t mine = 0;  // this lane's pending candidates inside the staged rows
+            for (uint32_t m = pend; m; m &= m - 1u) {
+                const uint32_t c = (uint32_t)__builtin_ctz(m);
+                if ((list[c][lane] & 0xFFFFu) - E < nrow) mine |= 1u << c;
+            }
+            pend &= ~mine;
+            while (__any(mine != 0u)) {  // two candidates at a time: two independent chains of dependent additions
+                if (mine) {
+                    const uint32_t ca = (uint32_t)__builtin_ctz(mine);
+                    mine &= mine - 1u;
+                    const uint32_t cb = mine ? (uint32_t)__builtin_ctz(mine) : ca;
+                    mine &= mine - 1u;  // (0 & anything = 0)
+                    const float4* ta = reinterpret_cast<const float4*>(&tile[(list[ca][lane] & 0xFFFFu) - E][0]);
+                    const float4* tb = reinterpret_cast<const float4*>(&tile[(list[cb][lane] & 0xFFFFu) - E][0]);
+                    double da = 0.0, db = 0.0;
+#pragma unroll
+                    for (int q = 0; q < kD / 4; ++q) {
+                        const float4 u = ta[q], v = tb[q];
+                        const double u0 = (double)(a[4 * q] - u.x), u1 = (double)(a[4 * q + 1] - u.y), u2 = (double)(a[4 * q + 2] - u.z),
+                                     u3 = (double)(a[4 * q + 3] - u.w);
+                        const double w0 = (double)(a[4 * q] - v.x), w1 = (double)(a[4 * q + 1] - v.y), w2 = (double)(a[4 * q + 2] - v.z),
+                                     w3 = (double)(a[4 * q + 3] - v.w);
+                        da = fma(u0, u0, da); db = fma(w0, w0, db);
+                        da = fma(u1, u1, da); db = fma(w1, w1, db);
+                        da = fma(u2, u2, da); db = fma(w2, w2, db);
+                        da = fma(u3, u3, da); db = fma(w3, w3, db);
+                    }
+                    dist[ca][lane] = da;
+                    dist[cb][lane] = db;
+                }
+            }
+        }
+        // (4) the round's smallest distance (ties: the smallest index), then the smallest distance among smaller indices
+        double m_d = DBL_MAX;
+        uint32_t m_j = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < nlist; ++c) {  // ascending index: the first minimum wins
+            const double dc = dist[c][lane];
+            if (dc < m_d) { m_d = dc; m_j = list[c][lane] >> 16; }
+        }
+        uint32_t cnt = nlist;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const double od = __shfl_xor(m_d, d);
+            const uint32_t oj = (uint32_t)__shfl_xor((int)m_j, d);
+            if (od < m_d || (od == m_d && oj < m_j)) { m_d = od; m_j = oj; }
+            cnt += (uint32_t)__shfl_xor((int)cnt, d);
+        }
+        double s_d = DBL_MAX;
+        for (uint32_t c = 0; c < nlist; ++c)
+            if ((list[c][lane] >> 16) < m_j) s_d = fmin(s_d, dist[c][lane]);
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) s_d = fmin(s_d, __shfl_xor(s_d, d));
+        count += cnt;
+        if (m_d < best) {  // the earlier rounds held smaller indices: their best is a predecessor of this round's first minimum
+            second = fmin(best, s_d);
+            best = m_d;
+            best_index = (int32_t)m_j;
+        }
+        more = more && jcap != 0xFFFFFFFFu;
+        if (more) after = (int64_t)jcap;
+    }
+    if (!active || g != 0u) return;
+    double corr = 1.0;
+    if (count < 20u) corr = 0.65 * 0.65;
+    if (count < 10u) corr = 0.6 * 0.6;
+    if (count < 5u) corr = 0.5 * 0.5;
+    if (count < 3u) corr = 0.25 * 0.25;
+    const double ratio = (best / second) / corr;
+    const bool keep = !(ratio < 0.00001) && best_index > -1 && (ratio < 0.8 * 0.8 || count == 1u);
+    best_out[P.off + i] = keep ? best_index : -1;
+    ratio_out[P.off + i] = ratio;
+}
+
 __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* __restrict__ pairs, const int32_t* __restrict__ best_in,
                                                              const double* __restrict__ ratio_in, uint32_t* __restrict__ ci,
                                                              uint32_t* __restrict__ cj, double* __restrict__ cr, uint32_t max_n,
@@ -1615,13 +2048,22 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     }
     // bucketed scan (the hashing saves the work) where the bins fit its counters; otherwise the tiled scan over everything
     const bool bucketed = n_bins > 0 && n_bins <= (uint32_t)kGmMaxBuckets && max_kp <= (uint32_t)PGI_DESC_MAX;
+    // default for the binned mode: the fine angular index + tile scan (guided_scan_tile_kernel); PGI_GUIDED_ANGLE=0 keeps the
+    // bin-bucketed scan, PGI_GUIDED_LANES = 1 | 2 | 4 sets the lanes per source keypoint (read per call: tests switch them)
+    const char* angle_txt = getenv("PGI_GUIDED_ANGLE");
+    const bool angle_env = !angle_txt || atoi(angle_txt) != 0;
+    const bool angular = n_bins > 0 && angle_env && max_kp <= 65535u;  // (record positions are packed in 16 bits)
     const size_t pair_bytes = ((size_t)n_pairs * sizeof(GuidedPair) + 255) / 256 * 256;
     const size_t slot = ((size_t)total * 8 + 255) / 256 * 256;  // one 8-byte array of `total` entries
     const size_t so_bytes = bucketed ? ((size_t)total * 4 + 255) / 256 * 256 : 0, do_bytes = bucketed ? ((size_t)total2 * 4 + 255) / 256 * 256 : 0,
                  rec_bytes = bucketed ? ((size_t)total2 * 32 + 255) / 256 * 256 : 0,
                  st_bytes = bucketed ? ((size_t)n_pairs * 3 * (kGmMaxBuckets + 1) * 4 + 255) / 256 * 256 : 0;
     const size_t kept_bytes = ((size_t)n_pairs * 4 + 255) / 256 * 256;
-    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + 256;
+    const size_t ga_entry_bytes = angular ? ((size_t)total2 * sizeof(GaEntry) + 255) / 256 * 256 : 0,
+                 ga_key_bytes = angular ? ((size_t)total2 * 4 + 255) / 256 * 256 : 0,
+                 ga_start_bytes = angular ? ((size_t)n_pairs * (kGaBuckets + 2) * 4 + (size_t)n_pairs * 16 + 255) / 256 * 256 : 0;
+    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + ga_entry_bytes + ga_key_bytes +
+                         ga_start_bytes + 256;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -1643,7 +2085,27 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     uint32_t* d_cj = (uint32_t*)(ws + pair_bytes + 4 * slot);
     HIP_TRY(hipMemcpyAsync(d_pairs, hp.data(), (size_t)n_pairs * sizeof(GuidedPair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // hp is a local buffer
-    if (max_n1 > 0 && bucketed) {
+    if (max_n1 > 0 && angular) {
+        char* q = ws + pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes;
+        GaEntry* d_ent = (GaEntry*)q; q += ga_entry_bytes;
+        uint32_t* d_key = (uint32_t*)q; q += ga_key_bytes;
+        double* d_span = (double*)q;  // (8-byte aligned: first in the block)
+        uint32_t* d_gst = (uint32_t*)(q + (size_t)n_pairs * 16);
+        hipLaunchKernelGGL(guided_angle_bucket_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_ent, d_key, d_gst, d_span,
+                           d_cj /* the source order: guided_select_kernel overwrites it only after the scan */);
+        const char* lanes_txt = getenv("PGI_GUIDED_LANES");
+        const int lanes_env = lanes_txt ? atoi(lanes_txt) : 2;
+        if (lanes_env == 1)
+            hipLaunchKernelGGL(guided_scan_tile_kernel<1>, dim3((max_n1 + 63) / 64, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
+                               d_cj, d_best, d_rat);
+        else if (lanes_env == 4)
+            hipLaunchKernelGGL(guided_scan_tile_kernel<4>, dim3((max_n1 + 15) / 16, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
+                               d_cj, d_best, d_rat);
+        else
+            hipLaunchKernelGGL(guided_scan_tile_kernel<2>, dim3((max_n1 + 31) / 32, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
+                               d_cj, d_best, d_rat);
+        HIP_TRY(hipGetLastError());
+    } else if (max_n1 > 0 && bucketed) {
         char* q = ws + pair_bytes + 5 * slot;
         uint32_t* d_so = (uint32_t*)q; q += so_bytes;
         uint32_t* d_do = (uint32_t*)q; q += do_bytes;

@@ -200,3 +200,49 @@ def test_gpu_guided_match_binned_unusual_geometry(eng):
             assert np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o]), (cm, s, d)
             checked += len(oi)
     assert checked > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["lanes1", "lanes2", "lanes4", "bin_scan"])
+def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
+    """Source keypoints with far more gate-passing candidates than one pass of the tile scan lists (16 per lane): 120
+    destination keypoints are moved onto the epipolar line of each of four source keypoints, so those sources are handled
+    in several rounds of ascending destination index -- and `second` (the best BEFORE the last improvement, matcher.h:352-371)
+    must still come out as the reference's loop over j leaves it.  Every variant of the scan against the literal restatement."""
+    if variant == "bin_scan":
+        monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
+    else:
+        monkeypatch.setenv("PGI_GUIDED_LANES", variant[-1])
+    views, poses, cam = scene(36, 1500, 1500)
+    s, d = 0, 1
+    R, t = rel_pose(poses, s, d)
+    E = np.zeros(9)
+    O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+    k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+    F = np.asarray(O.fundamental_from_essential(E, k, k)).reshape(3, 3)
+    rng = np.random.default_rng(8)
+    xy2 = views[d]["xy"].astype(np.float64).copy()
+    crowded = rng.choice(len(views[s]["xy"]), 4, replace=False)
+    moved = rng.permutation(len(xy2))[:480].reshape(4, 120)
+    for src, rows in zip(crowded, moved):
+        l = F @ np.r_[views[s]["xy"][src].astype(np.float64), 1.0]   # x2^T F x1 = 0: the line of x1 in image 2
+        nrm = np.hypot(l[0], l[1])
+        x = rng.uniform(0.05 * cam[1], 0.95 * cam[1], 120)
+        y = -(l[0] * x + l[2]) / l[1]
+        off = rng.uniform(-0.3, 0.3, 120)
+        xy2[rows, 0] = x + off * l[0] / nrm
+        xy2[rows, 1] = y + off * l[1] / nrm
+    vs = list(views)
+    vs[d] = dict(views[d], xy=xy2.astype(np.float32))
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in vs]
+    rt = np.array([np.r_[R.ravel(), t]])
+    (gi, gj, gr), = eng.guided_match_batch(feats, [(s, d)], rt, max_n=0, n_bins=45)
+    size = (int(cam[1]), int(cam[2]))
+    oi, oj, orr, frag = O.ref_guided_match_binned(F.ravel(), vs[s]["xy"], vs[d]["xy"], vs[s]["desc"], vs[d]["desc"], size, size)
+    keep_o, keep_g = ~frag[oi].astype(bool), ~frag[gi].astype(bool)
+    assert np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o])
+    # the crowded sources really had crowds (the exhaustive gate, in numpy)
+    for src in crowded:
+        l = F @ np.r_[vs[s]["xy"][src].astype(np.float64), 1.0]
+        dist = np.abs(vs[d]["xy"].astype(np.float64) @ l[:2] + l[2]) / np.hypot(l[0], l[1])
+        assert (dist < 0.5).sum() >= 100
