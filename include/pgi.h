@@ -342,7 +342,12 @@ int pgi_build_correspondences(pgi_ctx* ctx, const pgi_keypoint_view* h_src, cons
  * a superset of the binned candidates, so ~1 % of the matches differ from the reference's.
  * If more than max_n matches survive, the max_n with the smallest adapted ratio are returned in
  * that order (pose_graph_builder.h:759-772); otherwise all, in source order.  max_n = 0 keeps
- * everything. */
+ * everything.
+ * Two implementations of the binned mode give the same bytes (tests/test_guided.py, scripts/soak_guided.py): the
+ * default sorts the destination records by a fine angle bucket and evaluates descriptor rows staged once per
+ * wavefront (guided_scan_tile_kernel; images of up to 65535 keypoints), PGI_GUIDED_ANGLE=0 in the environment
+ * selects the scan over whole bins; PGI_GUIDED_LANES = 1 | 2 | 4 (default 2) sets the lanes per source keypoint
+ * of the former.  Both variables are read per call and exist for A/B measurements only. */
 typedef struct {
     const float* d_xy;   /* n x 2 pixel coordinates        */
     const float* d_desc; /* n x 128 row-major descriptors  */
