@@ -176,11 +176,14 @@ class AStarTraversal {
     // with a pose test the pose is returned only if the test accepts it (:787-797).
     void getPath(const ViewId kFrom_, const ViewId kTo_, std::vector<ViewId>& path_, std::vector<SE3d>& poses_,
                  size_t& touchedNodes_, size_t& foundPaths_, bool& pathExists_, const PoseTest& test = PoseTest()) const {
+        // (the reference copies the parent list into every open node; here an open node points at a link of a shared chain,
+        //  and the expanded set is a flat list -- the same search, without an allocation per pushed node)
+        struct Link { ViewId vertex; int prev; };
         struct Node {
             double edgeCost, nextCost, combined;
             size_t seq;
             ViewId vertex;
-            std::vector<ViewId> parents;
+            int chain;  // link of the parent vertex, -1 at the start vertex
             size_t depth;
         };
         auto worse = [](const Node& a, const Node& b) {  // max-heap on combined, earlier insertion first
@@ -188,21 +191,23 @@ class AStarTraversal {
             return a.seq > b.seq;
         };
         std::priority_queue<Node, std::vector<Node>, decltype(worse)> openNodes(worse);
-        std::unordered_set<ViewId> nodeStates;  // vertices that have been expanded (Open/Closed)
+        std::vector<Link> chain;
+        std::vector<ViewId> nodeStates;  // vertices that have been expanded (Open/Closed)
         size_t seq = 0;
-        openNodes.push(Node{1.0, 0.0, 0.0, seq, kFrom_, {}, 0});  // (1, 0, 0) at :721
+        openNodes.push(Node{1.0, 0.0, 0.0, seq, kFrom_, -1, 0});  // (1, 0, 0) at :721
         pathExists_ = false;
         foundPaths_ = 0;
         const double oneMinusWeight = 1.0 - weight;
-        std::vector<EdgeId> edges;
         while (!openNodes.empty()) {
-            Node node = openNodes.top();
+            const Node node = openNodes.top();
             openNodes.pop();
             ++touchedNodes_;
             if (node.depth > kMaximumDepth) continue;  // :755
             if (node.vertex == kTo_) {                 // :766
-                path_ = node.parents;
+                path_.clear();
                 path_.push_back(node.vertex);
+                for (int l = node.chain; l >= 0; l = chain[(size_t)l].prev) path_.push_back(chain[(size_t)l].vertex);
+                std::reverse(path_.begin(), path_.end());
                 SE3d pose;
                 if (recoverPath(*kPoseGraph, path_, pose)) {
                     ++foundPaths_;
@@ -210,21 +215,19 @@ class AStarTraversal {
                 }
                 break;  // kMaximumPathNumber = 1 (:799-800): the first recovered path ends the search
             }
-            std::vector<ViewId> parents = node.parents;
-            parents.push_back(node.vertex);
-            nodeStates.insert(node.vertex);
-            if (node.depth < kMaximumDepth && kPoseGraph->getEdgesByVertex(node.vertex, edges)) {  // :817-820
-                for (const EdgeId& id : edges) {
-                    const PoseGraphEdge e = kPoseGraph->getEdgeById(id);
-                    if (e.getScore() < kMinimumInlierRatio) continue;  // :830
+            chain.push_back(Link{node.vertex, node.chain});
+            const int here = (int)chain.size() - 1;
+            if (std::find(nodeStates.begin(), nodeStates.end(), node.vertex) == nodeStates.end()) nodeStates.push_back(node.vertex);
+            if (node.depth < kMaximumDepth)  // :817-820
+                kPoseGraph->forEachEdgeOf(node.vertex, [&](const PoseGraphEdge& e) {
+                    if (e.getScore() < kMinimumInlierRatio) return;  // :830
                     const ViewId next = node.vertex == e.getDestinationId() ? e.getSourceId() : e.getDestinationId();
                     const double edgeCost = std::min(node.edgeCost, e.getScore());                             // :843
                     const double nextCost = std::max(node.nextCost, kHeuristicsObject.getCost(next, kTo_));    // :847
                     const double combined = weight * edgeCost + oneMinusWeight * nextCost;                     // :851
-                    if (!nodeStates.count(next))                                                               // :855
-                        openNodes.push(Node{edgeCost, nextCost, combined, ++seq, next, parents, node.depth + 1});
-                }
-            }
+                    if (std::find(nodeStates.begin(), nodeStates.end(), next) == nodeStates.end())             // :855
+                        openNodes.push(Node{edgeCost, nextCost, combined, ++seq, next, here, node.depth + 1});
+                });
         }
         pathExists_ = !poses_.empty();
     }

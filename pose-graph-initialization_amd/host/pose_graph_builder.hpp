@@ -212,6 +212,20 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         out = it->second;
         return true;
     }
+    // the edges of a vertex in insertion order, by reference and under ONE shared lock (the traversal's inner loop:
+    // getEdgesByVertex + getEdgeById per edge copy an id list and a Pose per visit)
+    template <class Fn>
+    bool forEachEdgeOf(const ViewId& id, Fn fn) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        auto it = edges_of_vertices.find(id);
+        if (it == edges_of_vertices.end()) return false;
+        for (const EdgeId& e : it->second) {
+            auto ed = edges.find(e);
+            if (ed != edges.end()) fn(ed->second);
+            else fn(PoseGraphEdge());  // (value semantics for missing ids, as getEdgeById)
+        }
+        return true;
+    }
     size_t getEdgeNumberByVertex(const ViewId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
         auto it = edges_of_vertices.find(id);
