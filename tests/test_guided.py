@@ -246,3 +246,34 @@ def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
         l = F @ np.r_[vs[s]["xy"][src].astype(np.float64), 1.0]
         dist = np.abs(vs[d]["xy"].astype(np.float64) @ l[:2] + l[2]) / np.hypot(l[0], l[1])
         assert (dist < 0.5).sum() >= 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["lanes1", "lanes2", "lanes4", "bin_scan"])
+def test_gpu_guided_match_binned_degenerate_inputs(eng, variant, monkeypatch):
+    """The binned mode on empty images, a zero pose (F = 0: every record is degenerate, every angle NaN, every destination
+    keypoint a candidate of every source: the multi-round path on the records every source visits) and a pure-rotation pose
+    (E = 0), against the literal restatement."""
+    if variant == "bin_scan":
+        monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
+    else:
+        monkeypatch.setenv("PGI_GUIDED_LANES", variant[-1])
+    views, poses, cam = scene(33, 300, 300)
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in views]
+    feats.append(eng.upload_features(np.zeros((0, 2), np.float32), np.zeros((0, 128), np.float32), *cam))
+    pairs = [(0, 3), (3, 0), (0, 1), (1, 2)]
+    rt = np.zeros((4, 12))
+    rt[3, :9] = np.eye(3).ravel()
+    got = eng.guided_match_batch(feats, pairs, rt, max_n=0, n_bins=45)
+    assert len(got[0][0]) == 0 and len(got[1][0]) == 0
+    size = (int(cam[1]), int(cam[2]))
+    for p in (2, 3):
+        s, d = pairs[p]
+        E = np.zeros(9)
+        O.lib().pgo_ref_essential_from_pose(O._p(O.f64(rt[p, :9])), O._p(O.f64(rt[p, 9:])), O._p(E))
+        k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+        oi, oj, orr, frag = O.ref_guided_match_binned(O.fundamental_from_essential(E, k, k), views[s]["xy"], views[d]["xy"],
+                                                      views[s]["desc"], views[d]["desc"], size, size)
+        keep_o, keep_g = ~frag[oi].astype(bool), ~frag[got[p][0]].astype(bool)
+        assert np.array_equal(got[p][0][keep_g], oi[keep_o]) and np.array_equal(got[p][1][keep_g], oj[keep_o])
+        assert np.array_equal(got[p][2][keep_g], orr[keep_o], equal_nan=True)
