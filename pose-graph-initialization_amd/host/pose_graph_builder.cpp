@@ -467,6 +467,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         lay[v].rm = take((size_t)n_pad * PGI_DESC_DIM * 4);
         lay[v].f16 = take((size_t)n_pad * PGI_DESC_DIM * 2);
     }
+    const std::chrono::steady_clock::time_point uploadStart = std::chrono::steady_clock::now();
     DevBuf arena(std::max<size_t>(arenaBytes, 256));
     char* const ab = arena.as<char>();
     for (size_t v = 0; v < V; ++v) {
@@ -486,6 +487,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         kpView[v] = pgi_keypoint_view{xy, n, 0, f, f, cx, cy};
         featView[v] = pgi_feature_view{xy, desc, n, 0, f, f, cx, cy, views[v].width, views[v].height};
     }
+    Engine::check(pgi_synchronize(ctx));
+    st.secUpload = std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count();
     std::stable_sort(cand.begin(), cand.end(), [](const CandidatePair& a, const CandidatePair& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
         return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);

@@ -464,7 +464,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
         // wall-clock seconds per stage (RunningStatistics' "[Matching]", "[Quick matching]", "[A*]", "[Pose estimation]",
         // "[Epipolar Hashing]" timers of the reference)
         double secQuickMatching = 0, secMatching = 0, secCorrespondences = 0, secAStar = 0, secPoseEstimation = 0,
-               secGuidedMatching = 0, secTrackUpdate = 0;
+               secGuidedMatching = 0, secTrackUpdate = 0, secUpload = 0;  // secUpload: features -> HBM + descriptor preparation
     };
     // Per wave of candidate pairs (descending similarity): tracklet correspondences for pairs the graph already
     // connects (:493-518), descriptor matching for the rest (:521-546), createCorrespondenceMatrix (:553-565), A*

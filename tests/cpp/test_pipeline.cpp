@@ -66,8 +66,8 @@ int main(int argc, char** argv) {
         std::printf("mode %d: %zu pairs -> %zu edges in %.3f s (%.1f pairs/s; %zu matched, %zu quick, %zu guided runs)\n", mode,
                     (size_t)st.pairsProcessed, (size_t)st.edgesAdded, sec, st.pairsProcessed / sec, (size_t)st.matchingRuns,
                     (size_t)st.quickMatchingRuns, (size_t)st.guidedMatchingRuns);
-        std::printf("        seconds: quick matching %.3f, matching %.3f, correspondences %.3f, A* %.3f, pose estimation %.3f, guided %.3f, "
-                    "commit + tracklets %.3f\n", st.secQuickMatching, st.secMatching, st.secCorrespondences, st.secAStar,
+        std::printf("        seconds: upload + prepare %.3f, quick matching %.3f, matching %.3f, correspondences %.3f, A* %.3f, pose estimation %.3f, guided %.3f, "
+                    "commit + tracklets %.3f\n", st.secUpload, st.secQuickMatching, st.secMatching, st.secCorrespondences, st.secAStar,
                     st.secPoseEstimation, st.secGuidedMatching, st.secTrackUpdate);
         if (rep + 1 < reps) continue;
         const uint64_t v[16] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes, st.posesFromGuess,
