@@ -470,6 +470,9 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     const std::chrono::steady_clock::time_point uploadStart = std::chrono::steady_clock::now();
     DevBuf arena(std::max<size_t>(arenaBytes, 256));
     char* const ab = arena.as<char>();
+    if (std::getenv("PGI_PIPELINE_TIMING"))
+        std::fprintf(stderr, "[processFeatures] arena of %.2f GB allocated in %.3f s\n", arenaBytes / 1e9,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count());
     for (size_t v = 0; v < V; ++v) {
         const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
         float* xy = reinterpret_cast<float*>(ab + lay[v].xy);

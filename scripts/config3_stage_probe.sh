@@ -8,5 +8,5 @@ from pyposegraphbuilder import scenes as SC, synthetic as S
 views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
 SC.write_feature_scene("/tmp/config3_features.bin", views, cam, sim, pairs, 512)
 PY
-PGI_DRIVER_REPS=2 timeout 120 pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out $M
+PGI_DRIVER_REPS=${REPS:-2} timeout 120 pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out $M
 rm -f /tmp/config3_features.bin /tmp/config3_features.out
