@@ -1547,9 +1547,87 @@ __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* _
     }
 }
 
-// More kept matches than the cut allows: rank by counting (ratio ascending, ties by position) and keep ranks below the cut.
-// grid (kRankSplit, pairs): a pair's matches are ranked 1024 at a time, each slice by its own workgroup -- one workgroup per
-// pair left three quarters of the chip idle while it walked through the slices (0.5 ms per wave of 64 pairs).
+// More kept matches than the cut allows: the `lim` smallest adapted ratios (ties by position), in that order
+// (pose_graph_builder.h:759-772).  One workgroup per image pair: a radix select over the ratios' bit patterns (they are
+// positive doubles or +0 / +inf / NaN-free by construction of `keep`, so integer order is value order) finds the lim-th
+// smallest key T in eight histogram passes; the keys below T and the first ties at T (in position order) are the answer,
+// gathered into LDS and ranked among themselves.  O(m) instead of the O(m^2) rank-by-counting over all kept matches.
+constexpr uint32_t kTopMax = 1024;  // the largest cut handled here (the reference cuts at 100)
+__global__ __launch_bounds__(1024) void guided_topn_kernel(const GuidedPair* __restrict__ pairs, const uint32_t* __restrict__ kept,
+                                                           const uint32_t* __restrict__ ci, const uint32_t* __restrict__ cj,
+                                                           const double* __restrict__ cr, uint32_t max_n, uint32_t out_stride,
+                                                           uint32_t* __restrict__ out_src, uint32_t* __restrict__ out_dst,
+                                                           double* __restrict__ out_ratio) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long sel_key[kTopMax];
+    __shared__ uint32_t sel_pos[kTopMax];
+    __shared__ uint32_t wtot[16];
+    __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t s_need, s_count, s_carry;
+    const GuidedPair P = pairs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, m = kept[blockIdx.x];
+    if (max_n == 0u || m <= max_n) return;
+    const size_t o = (size_t)blockIdx.x * out_stride;
+    const uint32_t lim = max_n < out_stride ? max_n : out_stride;  // (<= kTopMax: checked by the host)
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(cr + P.off);
+    // the lim-th smallest key, a byte at a time from the top
+    if (tid == 0) { s_prefix = 0ull; s_need = lim; }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (tid < 256u) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix, high = shift == 56 ? 0ull : ~0ull << (shift + 8);
+        for (uint32_t k = tid; k < m; k += 1024u) {
+            const unsigned long long key = keys[k];
+            if ((key & high) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t need = s_need, d = 0;
+            for (; d < 255u && hist[d] < need; ++d) need -= hist[d];  // the digit in which the count crosses `need`
+            s_need = need;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long T = s_prefix;
+    const uint32_t ties_taken = s_need;  // of the keys equal to T, the first `ties_taken` in position order belong to the answer
+    if (tid == 0) { s_count = 0u; s_carry = 0u; }
+    __syncthreads();
+    for (uint32_t base = 0; base < m; base += 1024u) {  // ordered count of the ties (ballots), unordered gather of the answer
+        const uint32_t k = base + tid;
+        const unsigned long long key = k < m ? keys[k] : ~0ull;
+        const bool tie = k < m && key == T;
+        const uint64_t mk = __ballot(tie);
+        if (lane == 0) wtot[wv] = (uint32_t)__popcll(mk);
+        __syncthreads();
+        uint32_t before = s_carry, all = 0;
+        for (uint32_t q = 0; q < 16u; ++q) {
+            if (q < wv) before += wtot[q];
+            all += wtot[q];
+        }
+        const uint32_t tie_rank = before + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        if (k < m && (key < T || (tie && tie_rank < ties_taken))) {
+            const uint32_t at = atomicAdd(&s_count, 1u);
+            sel_key[at] = key;
+            sel_pos[at] = k;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += all;
+        __syncthreads();
+    }
+    // exactly lim entries; rank them among themselves (ratio ascending, ties by position)
+    for (uint32_t e = tid; e < lim; e += 1024u) {
+        const unsigned long long key = sel_key[e];
+        const uint32_t pos = sel_pos[e];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < lim; ++q) rank += (sel_key[q] < key || (sel_key[q] == key && sel_pos[q] < pos)) ? 1u : 0u;
+        out_src[o + rank] = ci[P.off + pos];
+        out_dst[o + rank] = cj[P.off + pos];
+        out_ratio[o + rank] = cr[P.off + pos];
+    }
+}
+
+// the same by counting over all kept matches (cuts above kTopMax)
 constexpr uint32_t kRankSplit = 4;
 __global__ __launch_bounds__(1024) void guided_rank_kernel(const GuidedPair* __restrict__ pairs, const uint32_t* __restrict__ kept,
                                                            const uint32_t* __restrict__ ci, const uint32_t* __restrict__ cj,
@@ -2124,8 +2202,14 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     hipLaunchKernelGGL(guided_select_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_best, d_rat, d_ci, d_cj, d_cr, max_n,
                        out_stride, d_match_src, d_match_dst, d_ratio, d_counts, d_kept);
     if (max_n != 0u)  // pairs with more kept matches than the cut: rank them
-        hipLaunchKernelGGL(guided_rank_kernel, dim3(kRankSplit, n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_kept, d_ci, d_cj, d_cr, max_n,
-                           out_stride, d_match_src, d_match_dst, d_ratio);
+    {
+        if (std::min(max_n, out_stride) <= kTopMax)
+            hipLaunchKernelGGL(guided_topn_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_kept, d_ci, d_cj, d_cr, max_n, out_stride,
+                               d_match_src, d_match_dst, d_ratio);
+        else
+            hipLaunchKernelGGL(guided_rank_kernel, dim3(kRankSplit, n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_kept, d_ci, d_cj, d_cr, max_n,
+                               out_stride, d_match_src, d_match_dst, d_ratio);
+    }
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
 }

@@ -277,3 +277,23 @@ def test_gpu_guided_match_binned_degenerate_inputs(eng, variant, monkeypatch):
         keep_o, keep_g = ~frag[oi].astype(bool), ~frag[got[p][0]].astype(bool)
         assert np.array_equal(got[p][0][keep_g], oi[keep_o]) and np.array_equal(got[p][1][keep_g], oj[keep_o])
         assert np.array_equal(got[p][2][keep_g], orr[keep_o], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_n", [1, 7, 100, 333, 1024, 1500])
+def test_gpu_guided_match_cut_with_tied_ratios(eng, max_n):
+    """The top-N cut (pose_graph_builder.h:759-772: smallest adapted ratio first, ties by position) where the cut falls INSIDE
+    groups of equal ratios: every source keypoint exists eight times (same position, same descriptor), so the kept matches
+    come in groups of eight identical ratios.  Cuts below and above the radix-select kernel's limit of 1024."""
+    views, poses, cam = scene(37, 2500, 500)
+    v0 = dict(views[0])
+    v0["xy"] = np.repeat(views[0]["xy"], 8, axis=0)
+    v0["desc"] = np.repeat(views[0]["desc"], 8, axis=0)
+    vs = [v0, views[1]]
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in vs]
+    R, t = rel_pose(poses, 0, 1)
+    (gi, gj, gr), = eng.guided_match_batch(feats, [(0, 1)], np.r_[R.ravel(), t][None], max_n=max_n, n_bins=0)
+    oi, oj, orr, _ = oracle_matches(vs, poses, cam, 0, 1, 0)
+    assert len(oi) > 1600 and len(np.unique(orr)) <= len(orr) // 8 + 1
+    order = np.lexsort((np.arange(len(oi)), orr))[:max_n]
+    assert np.array_equal(gi, oi[order]) and np.array_equal(gj, oj[order]) and np.array_equal(gr, orr[order])
