@@ -297,3 +297,30 @@ def test_gpu_guided_match_cut_with_tied_ratios(eng, max_n):
     assert len(oi) > 1600 and len(np.unique(orr)) <= len(orr) // 8 + 1
     order = np.lexsort((np.arange(len(oi)), orr))[:max_n]
     assert np.array_equal(gi, oi[order]) and np.array_equal(gj, oj[order]) and np.array_equal(gr, orr[order])
+
+
+@pytest.mark.gpu
+def test_gpu_guided_match_binned_images_beyond_the_bin_scan_limit(eng):
+    """20 000 keypoints on either side: more than the bin scan's counters hold (PGI_DESC_MAX = 16 384), inside the tile scan's
+    16-bit record positions.  Against the literal restatement."""
+    views, poses, cam = scene(38, 2000, 1000)
+    rng = np.random.default_rng(5)
+    big = []
+    for v in views[:2]:   # pad with clutter keypoints up to 20 000
+        extra = 20000 - len(v["xy"])
+        xy = np.vstack([v["xy"], np.c_[rng.uniform(0, cam[1], extra), rng.uniform(0, cam[2], extra)].astype(np.float32)])
+        d = rng.random((extra, 128)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        big.append(dict(xy=xy, desc=np.vstack([v["desc"], d.astype(np.float32)])))
+    feats = [eng.upload_features(v["xy"], v["desc"], *cam) for v in big]
+    R, t = rel_pose(poses, 0, 1)
+    (gi, gj, gr), = eng.guided_match_batch(feats, [(0, 1)], np.r_[R.ravel(), t][None], max_n=0, n_bins=45)
+    E = np.zeros(9)
+    O.lib().pgo_ref_essential_from_pose(O._p(O.f64(R).ravel()), O._p(O.f64(t)), O._p(E))
+    k = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
+    size = (int(cam[1]), int(cam[2]))
+    oi, oj, orr, frag = O.ref_guided_match_binned(O.fundamental_from_essential(E, k, k), big[0]["xy"], big[1]["xy"], big[0]["desc"],
+                                                  big[1]["desc"], size, size)
+    keep_o, keep_g = ~frag[oi].astype(bool), ~frag[gi].astype(bool)
+    assert len(oi) > 500
+    assert np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o])
