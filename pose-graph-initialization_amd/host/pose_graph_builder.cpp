@@ -515,7 +515,56 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     typedef std::chrono::steady_clock Clock;
     auto since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
     DevPool pool;
-    auto processWave = [&](const std::vector<CandidatePair>& wave) {
+    // The path searches of the NEXT wave run on the host while this wave's guided matching occupies the GPU: they read the
+    // pose graph and the visibility as this wave's commit leaves them -- exactly what they would see at the start of the
+    // next wave -- so the guesses, the counters and the graph are the same as without the overlap.
+    struct SearchedWave {
+        std::vector<CandidatePair> wave;
+        bool searched = false;            // the vectors below are filled (path finding on)
+        std::vector<uint8_t> found_pose;  // per pair of `wave`
+        std::vector<double> pose;         // 12 per pair
+        std::vector<size_t> touched, found;
+        double seconds = 0;
+    };
+    size_t cursor = 0;  // next candidate
+    auto formWave = [&](std::vector<CandidatePair>& w) {
+        w.clear();
+        while (cursor < cand.size() && w.size() < waveSize) {
+            const CandidatePair& cp = cand[cursor];
+            if (cp.similarity < kSimilarityThreshold) { cursor = cand.size(); break; }
+            if (cp.src >= V || cp.dst >= V) throw PgiError("processFeatures: view index out of range");
+            ++cursor;
+            if (poseGraph_.hasEdge(cp.src, cp.dst) || poseGraph_.hasEdge(cp.dst, cp.src)) continue;  // :426-431
+            w.push_back(cp);
+        }
+    };
+    auto searchWave = [&](SearchedWave& sw) {  // findPath (:785-862) for every pair of the wave the graph already connects
+        sw.searched = false;
+        if (!pathFinding || sw.wave.empty()) return;
+        const Clock::time_point t0 = Clock::now();
+        const size_t n = sw.wave.size();
+        sw.found_pose.assign(n, 0);
+        sw.pose.assign(12 * n, 0.0);
+        sw.touched.assign(n, 0);
+        sw.found.assign(n, 0);
+        ImageSimilarityHeuristics heuristics(*similarityTable);
+        AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0, kMaximumSearchDepth);
+        for (size_t i = 0; i < n; ++i) {
+            if (!visibilityTable.hasLink(sw.wave[i].src, sw.wave[i].dst)) continue;
+            std::vector<ViewId> path;
+            std::vector<SE3d> poses;
+            bool exists = false;
+            traversal.getPath(sw.wave[i].src, sw.wave[i].dst, path, poses, sw.touched[i], sw.found[i], exists);
+            if (poses.empty()) continue;
+            for (int c = 0; c < 9; ++c) sw.pose[12 * i + c] = poses.back().R[c];
+            for (int c = 0; c < 3; ++c) sw.pose[12 * i + 9 + c] = poses.back().t[c];
+            sw.found_pose[i] = 1;
+        }
+        sw.searched = true;
+        sw.seconds = since(t0);
+    };
+    auto processWave = [&](const SearchedWave& current, SearchedWave& next) {
+        const std::vector<CandidatePair>& wave = current.wave;
         const size_t P = wave.size();
         if (!P) return;
         Engine::check(pgi_synchronize(ctx));  // the previous wave's kernels are done with the pool
@@ -674,33 +723,33 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         std::vector<uint8_t> has(P, 0);
         bool anyGuess = false;
         size_t waveSearched = 0, waveTouched = 0, waveFound = 0;
+        double searchSeconds = 0;  // (spent during the previous wave's guided matching when the searches ran ahead)
         if (pathFinding) {
-            ImageSimilarityHeuristics heuristics(*similarityTable);
-            AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
-                                                                kMaximumSearchDepth);
+            SearchedWave inlineSearch;
+            const SearchedWave* sw = &current;
+            if (!current.searched) {  // the first wave, or a caller without the overlap
+                inlineSearch.wave = wave;
+                searchWave(inlineSearch);
+                sw = &inlineSearch;
+            }
+            searchSeconds = sw->seconds;
             for (size_t k = 0; k < P; ++k) {
                 const size_t i = order[k];
-                if (!visible[i] || skipped[k]) continue;
-                std::vector<ViewId> path;
-                std::vector<SE3d> poses;
-                size_t touched = 0, found = 0;
-                bool exists = false;
-                traversal.getPath(wave[i].src, wave[i].dst, path, poses, touched, found, exists);
+                if (!visible[i] || skipped[k]) continue;  // (a pair without enough matches never asked for a path, :550-551)
                 ++st.pathsSearched;
-                st.touchedNodes += touched;
-                st.pathsFound += found;
+                st.touchedNodes += sw->touched[i];
+                st.pathsFound += sw->found[i];
                 ++waveSearched;
-                waveTouched += touched;
-                waveFound += found;
-                if (poses.empty()) continue;
-                for (int c = 0; c < 9; ++c) guess[12 * k + c] = poses.back().R[c];
-                for (int c = 0; c < 3; ++c) guess[12 * k + 9 + c] = poses.back().t[c];
+                waveTouched += sw->touched[i];
+                waveFound += sw->found[i];
+                if (!sw->found_pose[i]) continue;
+                for (int c = 0; c < 12; ++c) guess[12 * k + c] = sw->pose[12 * i + c];
                 has[k] = 1;
                 anyGuess = true;
             }
         }
         {
-            const double dt = since(tick);
+            const double dt = (current.searched ? 0.0 : since(tick)) + (current.searched ? searchSeconds : 0.0);
             st.secAStar += dt;
             if (waveSearched) {  // :599-602
                 statistics.addTime("[A*]", dt, waveSearched);
@@ -774,7 +823,33 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
         }
         tick = Clock::now();
-        // (6) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
+        // (6a) commit the edges in wave order (:645-654) and the visibility (:692): nothing of it depends on the guided matches,
+        //      and the next wave's path searches need it
+        std::vector<size_t> slotOf(P);
+        for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
+        double commitSeconds = 0;
+        {
+            const Clock::time_point t0 = Clock::now();
+            for (size_t i = 0; i < P; ++i) {
+                const size_t k = slotOf[i];
+                ++st.pairsProcessed;
+                if (skipped[k]) continue;
+                st.hypotheses += edges[k].iters;
+                st.posesFromGuess += edges[k].used_guess;
+                if (edges[k].status != PGI_EDGE_OK) continue;  // :641-642
+                SE3d T;
+                for (int c = 0; c < 9; ++c) T.R[c] = edges[k].R[c];
+                for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
+                poseGraph_.addVertex(wave[i].src);
+                poseGraph_.addVertex(wave[i].dst);
+                poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matchCount[i]);
+                ++st.edgesAdded;
+                visibilityTable.addLink(wave[i].src, wave[i].dst);
+            }
+            commitSeconds = since(t0);
+        }
+        tick = Clock::now();
+        // (6b) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
         std::vector<size_t> guidedOf;
         std::vector<pgi_feature_view> ga, gb;
         std::vector<double> gpose;
@@ -796,6 +871,12 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             dr.reset(new WaveBuf(pool, G * (size_t)gstride * 8)); dc.reset(new WaveBuf(pool, G * 4));
             Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds->as<uint32_t>(),
                                                  dd->as<uint32_t>(), dr->as<double>(), dc->as<uint32_t>()));
+        }
+        // while the GPU works on that: the next wave and its path searches
+        formWave(next.wave);
+        searchWave(next);
+        if (!guidedOf.empty()) {
+            const size_t G = guidedOf.size();
             Engine::check(pgi_synchronize(ctx));
             gcnt.resize(G);
             d2h(gcnt.data(), dc->p, G * 4);
@@ -806,8 +887,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
             st.guidedMatchingRuns += G;
         }
-        {   // :684-686
-            const double dt = since(tick);
+        {   // :684-686 (the searches that ran meanwhile are booked under A*, not here)
+            const double dt = std::max(0.0, since(tick) - next.seconds);
             st.secGuidedMatching += dt;
             if (!guidedOf.empty()) {
                 size_t extra = 0;
@@ -818,28 +899,13 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
         }
         tick = Clock::now();
-        // (7) commit in wave order: edge (:645-654), visibility (:692), tracklets (:677-681, :702-709)
-        std::vector<size_t> slotOf(P);
-        for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
+        // (7) the tracklets of the committed edges, in wave order (:677-681, :702-709)
         std::vector<size_t> guidedSlot(P, (size_t)-1);
         for (size_t q = 0; q < guidedOf.size(); ++q) guidedSlot[guidedOf[q]] = q;
         std::vector<pgi_tracklet_pair> adds;
-        for (size_t i = 0; i < P; ++i) {
+        for (size_t i = 0; i < P && kUseEpipolarHashing; ++i) {
             const size_t k = slotOf[i];
-            ++st.pairsProcessed;
-            if (skipped[k]) continue;
-            st.hypotheses += edges[k].iters;
-            st.posesFromGuess += edges[k].used_guess;
-            if (edges[k].status != PGI_EDGE_OK) continue;  // :641-642
-            SE3d T;
-            for (int c = 0; c < 9; ++c) T.R[c] = edges[k].R[c];
-            for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
-            poseGraph_.addVertex(wave[i].src);
-            poseGraph_.addVertex(wave[i].dst);
-            poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matchCount[i]);
-            ++st.edgesAdded;
-            visibilityTable.addLink(wave[i].src, wave[i].dst);
-            if (!kUseEpipolarHashing) continue;
+            if (skipped[k] || edges[k].status != PGI_EDGE_OK) continue;
             if (deviceTracks) {  // the add() calls of the wave, in commit order, straight from the device rows
                 pgi_tracklet_pair a{};
                 a.view_src = (uint32_t)wave[i].src;
@@ -869,8 +935,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
         }
         if (!adds.empty()) Engine::check(pgi_tracklets_add_batch(store.t, adds.data(), (uint32_t)adds.size()));
-        {   // :698-699 (the commit loop holds the visibility update)
-            const double dt = since(tick);
+        {   // :698-699 (the edge / visibility commit above is part of it)
+            const double dt = since(tick) + commitSeconds;
             st.secTrackUpdate += dt;
             statistics.addTime("[Visibility update]", dt, P);
             statistics.addCount("[Visibility update] Runs", P, P);
@@ -878,15 +944,13 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         ++st.waves;
     };
 
-    std::vector<CandidatePair> wave;
-    for (const CandidatePair& cp : cand) {
-        if (cp.similarity < kSimilarityThreshold) break;
-        if (cp.src >= V || cp.dst >= V) throw PgiError("processFeatures: view index out of range");
-        if (poseGraph_.hasEdge(cp.src, cp.dst) || poseGraph_.hasEdge(cp.dst, cp.src)) continue;  // :426-431
-        wave.push_back(cp);
-        if (wave.size() == waveSize) { processWave(wave); wave.clear(); }
+    SearchedWave current, next;
+    formWave(current.wave);  // (the first wave's searches, if any, run inside processWave)
+    while (!current.wave.empty()) {
+        next = SearchedWave();
+        processWave(current, next);
+        current = std::move(next);
     }
-    processWave(wave);
     st.trackNumber = tracks.trackNumber();
     if (deviceTracks) {
         uint64_t n = 0;
