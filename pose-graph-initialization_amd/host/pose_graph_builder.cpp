@@ -823,31 +823,6 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
         }
         tick = Clock::now();
-        // (6a) commit the edges in wave order (:645-654) and the visibility (:692): nothing of it depends on the guided matches,
-        //      and the next wave's path searches need it
-        std::vector<size_t> slotOf(P);
-        for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
-        double commitSeconds = 0;
-        {
-            const Clock::time_point t0 = Clock::now();
-            for (size_t i = 0; i < P; ++i) {
-                const size_t k = slotOf[i];
-                ++st.pairsProcessed;
-                if (skipped[k]) continue;
-                st.hypotheses += edges[k].iters;
-                st.posesFromGuess += edges[k].used_guess;
-                if (edges[k].status != PGI_EDGE_OK) continue;  // :641-642
-                SE3d T;
-                for (int c = 0; c < 9; ++c) T.R[c] = edges[k].R[c];
-                for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
-                poseGraph_.addVertex(wave[i].src);
-                poseGraph_.addVertex(wave[i].dst);
-                poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matchCount[i]);
-                ++st.edgesAdded;
-                visibilityTable.addLink(wave[i].src, wave[i].dst);
-            }
-            commitSeconds = since(t0);
-        }
         tick = Clock::now();
         // (6b) guided matching for the successful tracklet pairs, one launch sequence (:657-686)
         std::vector<size_t> guidedOf;
@@ -872,7 +847,32 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             Engine::check(pgi_guided_match_batch(ctx, ga.data(), gb.data(), (uint32_t)G, gpose.data(), kEpipolarBins, gstride, gstride, ds->as<uint32_t>(),
                                                  dd->as<uint32_t>(), dr->as<double>(), dc->as<uint32_t>()));
         }
-        // while the GPU works on that: the next wave and its path searches
+        // while the GPU works on that: (6a) the edges in wave order (:645-654) and the visibility (:692) -- nothing of it depends
+        // on the guided matches, and the next wave's path searches need it --
+        std::vector<size_t> slotOf(P);
+        for (size_t k = 0; k < P; ++k) slotOf[order[k]] = k;
+        double commitSeconds = 0;
+        {
+            const Clock::time_point t0 = Clock::now();
+            for (size_t i = 0; i < P; ++i) {
+                const size_t k = slotOf[i];
+                ++st.pairsProcessed;
+                if (skipped[k]) continue;
+                st.hypotheses += edges[k].iters;
+                st.posesFromGuess += edges[k].used_guess;
+                if (edges[k].status != PGI_EDGE_OK) continue;  // :641-642
+                SE3d T;
+                for (int c = 0; c < 9; ++c) T.R[c] = edges[k].R[c];
+                for (int c = 0; c < 3; ++c) T.t[c] = edges[k].t[c];
+                poseGraph_.addVertex(wave[i].src);
+                poseGraph_.addVertex(wave[i].dst);
+                poseGraph_.addEdge(wave[i].src, wave[i].dst, Pose(T), (double)edges[k].n_inl / (double)matchCount[i]);
+                ++st.edgesAdded;
+                visibilityTable.addLink(wave[i].src, wave[i].dst);
+            }
+            commitSeconds = since(t0);
+        }
+        // ... then the next wave and its path searches
         formWave(next.wave);
         searchWave(next);
         if (!guidedOf.empty()) {
@@ -887,8 +887,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
             st.guidedMatchingRuns += G;
         }
-        {   // :684-686 (the searches that ran meanwhile are booked under A*, not here)
-            const double dt = std::max(0.0, since(tick) - next.seconds);
+        {   // :684-686 (the commit and the searches that ran meanwhile are booked under their own stages, not here)
+            const double dt = std::max(0.0, since(tick) - next.seconds - commitSeconds);
             st.secGuidedMatching += dt;
             if (!guidedOf.empty()) {
                 size_t extra = 0;
