@@ -47,6 +47,28 @@ int pgih_run_pairs(pgih_builder* b, uint32_t n_pairs, const uint32_t* src, const
                    const double* thr, const uint64_t* offsets, const double* corr_aos, uint32_t wave_size,
                    pgih_graph_edge* edges, uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats);
 
+
+typedef struct {           /* one view of pgih_run_features (feature_utils.h:53-95: what keypoints.h5 / image_data.h5 hold) */
+    const float* keypoints;    /* n x 2 pixel coordinates */
+    const float* descriptors;  /* n x 128, row-major */
+    uint32_t n, pad;
+    double focal_length, width, height;
+} pgih_view;
+
+#define PGIH_FEATURE_STATS 24  /* the PGIH_STATS counters, then [16] descriptor-matching runs, [17] tracklet quick-matching runs,
+                                * [18] guided-matching runs, [19] guided matches added, [20] tracks, [21] pairs with too few matches */
+#define PGIH_STAGES 8          /* seconds: upload + prepare, quick matching, matching, correspondences, A*, pose estimation,
+                                * guided matching, commit + tracklets */
+
+/* PoseGraphBuilder::processFeatures -- the loop body of processImages (pose_graph_builder.h:391-709) on in-memory features:
+ * per wave of candidate pairs (descending similarity) tracklet quick matching, descriptor matching, createCorrespondenceMatrix,
+ * A* pose guesses, estimatePose, guided matching, tracklet / visibility / graph update, with the builder's 17 arguments.
+ * device_tracklets != 0 keeps the tracklet store in HBM (the default of the C++ class).  Outputs as pgih_run_pairs;
+ * stats (PGIH_FEATURE_STATS) and stage_seconds (PGIH_STAGES) may be NULL. */
+int pgih_run_features(pgih_builder* b, uint32_t n_views, const pgih_view* views, uint32_t n_pairs, const uint32_t* src,
+                      const uint32_t* dst, const double* similarity, uint32_t wave_size, int device_tracklets, pgih_graph_edge* edges,
+                      uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats, double* stage_seconds);
+
 #ifdef __cplusplus
 }
 #endif

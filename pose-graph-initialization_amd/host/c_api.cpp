@@ -109,4 +109,63 @@ int pgih_run_pairs(pgih_builder* b, uint32_t n_pairs, const uint32_t* src, const
     return 0;
 }
 
+int pgih_run_features(pgih_builder* b, uint32_t n_views, const pgih_view* views, uint32_t n_pairs, const uint32_t* src,
+                      const uint32_t* dst, const double* similarity, uint32_t wave_size, int device_tracklets, pgih_graph_edge* edges,
+                      uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats, double* stage_seconds) {
+    if (!b || !n_edges || (n_views && !views) || (n_pairs && (!src || !dst || !similarity)) || (edge_capacity && !edges))
+        return fail("pgih_run_features: null argument");
+    try {
+        std::vector<PoseGraphBuilder::ViewFeaturesRef> vf(n_views);
+        for (uint32_t v = 0; v < n_views; ++v) {
+            vf[v].keypoints = views[v].keypoints;
+            vf[v].descriptors = views[v].descriptors;
+            vf[v].n = views[v].n;
+            vf[v].focalLength = views[v].focal_length; vf[v].width = views[v].width; vf[v].height = views[v].height;
+        }
+        SimilarityTable sim(std::max(n_views, 1u), 0.0, false);
+        for (uint32_t i = 0; i < n_views; ++i)
+            for (uint32_t j = i + 1; j < n_views; ++j) sim.setSimilarity(i, j, 0.0);
+        std::vector<PoseGraphBuilder::CandidatePair> cand(n_pairs);
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            if (src[p] >= n_views || dst[p] >= n_views) return fail("pgih_run_features: view index out of range");
+            cand[p] = PoseGraphBuilder::CandidatePair{src[p], dst[p], similarity[p]};
+            sim.setSimilarity(src[p], dst[p], similarity[p]);
+        }
+        b->impl->setDeviceTracklets(device_tracklets != 0);
+        PoseGraph graph;
+        const PoseGraphBuilder::FeatureRunStatistics st = b->impl->processFeatures(vf, cand, graph, wave_size ? wave_size : 512, &sim);
+        uint32_t k = 0;
+        for (const EdgeId& id : graph.getEdgeIds()) {
+            if (k < edge_capacity) {
+                const PoseGraphEdge e = graph.getEdgeById(id);
+                pgih_graph_edge& o = edges[k];
+                o.src = (uint32_t)id.first;
+                o.dst = (uint32_t)id.second;
+                o.score = e.getScore();
+                for (int c = 0; c < 9; ++c) o.R[c] = e.getValue().getRotation()[c];
+                for (int c = 0; c < 3; ++c) o.t[c] = e.getValue().getTranslation()[c];
+            }
+            ++k;
+        }
+        *n_edges = k;
+        if (stats) {
+            const uint64_t v[PGIH_FEATURE_STATS] = {st.pairsProcessed, st.edgesAdded, st.pathsSearched, st.pathsFound, st.touchedNodes,
+                                                    st.posesFromGuess, st.hypotheses, st.waves, graph.numEdges(),
+                                                    b->impl->getStatistics().getCount("[Pose estimation] Quirk-only guesses"), 0, 0, 0, 0, 0, 0,
+                                                    st.matchingRuns, st.quickMatchingRuns, st.guidedMatchingRuns, st.guidedMatchesAdded,
+                                                    st.trackNumber, st.tooFewMatches};
+            std::copy(v, v + PGIH_FEATURE_STATS, stats);
+        }
+        if (stage_seconds) {
+            const double sec[PGIH_STAGES] = {st.secUpload, st.secQuickMatching, st.secMatching, st.secCorrespondences, st.secAStar,
+                                             st.secPoseEstimation, st.secGuidedMatching, st.secTrackUpdate};
+            std::copy(sec, sec + PGIH_STAGES, stage_seconds);
+        }
+        if (k > edge_capacity) return fail("pgih_run_features: edge buffer too small");
+    } catch (const std::exception& e) {
+        return fail(std::string("pgih_run_features: ") + e.what());
+    }
+    return 0;
+}
+
 }  // extern "C"

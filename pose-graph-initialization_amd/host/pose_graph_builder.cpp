@@ -439,7 +439,23 @@ void PoseGraphBuilder::initializeReconstruction(const size_t& kImageNumber_,
     }
 }
 
-PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeatures>& views,
+PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeatures>& owned,
+                                                                          std::vector<CandidatePair>& cand,
+                                                                          PoseGraph& poseGraph_, size_t waveSize,
+                                                                          const SimilarityTable* similarityTable,
+                                                                          const MatchLookup* cachedMatches) {
+    std::vector<ViewFeaturesRef> views(owned.size());
+    for (size_t v = 0; v < owned.size(); ++v) {
+        if (owned[v].descriptors.size() != owned[v].size() * (size_t)PGI_DESC_DIM) throw PgiError("processFeatures: descriptors must be n x 128");
+        views[v].keypoints = owned[v].keypoints.data();
+        views[v].descriptors = owned[v].descriptors.data();
+        views[v].n = owned[v].size();
+        views[v].focalLength = owned[v].focalLength; views[v].width = owned[v].width; views[v].height = owned[v].height;
+    }
+    return processFeatures(views, cand, poseGraph_, waveSize, similarityTable, cachedMatches);
+}
+
+PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const std::vector<ViewFeaturesRef>& views,
                                                                           std::vector<CandidatePair>& cand,
                                                                           PoseGraph& poseGraph_, size_t waveSize,
                                                                           const SimilarityTable* similarityTable,
@@ -459,7 +475,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     auto take = [&](size_t bytes) { const size_t o = arenaBytes; arenaBytes += (bytes + 255) & ~(size_t)255; return o; };
     for (size_t v = 0; v < V; ++v) {
         const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
-        if (views[v].descriptors.size() != (size_t)n * PGI_DESC_DIM) throw PgiError("processFeatures: descriptors must be n x 128");
+        if (n && (!views[v].keypoints || !views[v].descriptors)) throw PgiError("processFeatures: null feature arrays");
         lay[v].xy = take((size_t)n * 8);
         lay[v].desc = take((size_t)n * PGI_DESC_DIM * 4);
         lay[v].dt = take((size_t)n_pad * PGI_DESC_DIM * 4);
@@ -481,8 +497,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         float* norm = reinterpret_cast<float*>(ab + lay[v].norm);
         float* rm = reinterpret_cast<float*>(ab + lay[v].rm);
         uint16_t* f16 = reinterpret_cast<uint16_t*>(ab + lay[v].f16);
-        h2d(xy, views[v].keypoints.data(), (size_t)n * 8);
-        h2d(desc, views[v].descriptors.data(), (size_t)n * PGI_DESC_DIM * 4);
+        h2d(xy, views[v].keypoints, (size_t)n * 8);
+        h2d(desc, views[v].descriptors, (size_t)n * PGI_DESC_DIM * 4);
         Engine::check(pgi_desc_prepare(ctx, desc, n, dt, norm));
         Engine::check(pgi_desc_prepare_screen(ctx, desc, n, rm, f16));
         const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;

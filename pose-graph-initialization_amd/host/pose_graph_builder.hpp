@@ -454,6 +454,13 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
         double focalLength = 1.0, width = 0.0, height = 0.0;
         size_t size() const { return keypoints.size() / 2; }
     };
+    struct ViewFeaturesRef {  // the same, not owning (arrays of a caller in another language: pgih_run_features)
+        const float* keypoints = nullptr;
+        const float* descriptors = nullptr;
+        size_t n = 0;
+        double focalLength = 1.0, width = 0.0, height = 0.0;
+        size_t size() const { return n; }
+    };
     struct CandidatePair {
         ViewId src, dst;
         double similarity;
@@ -475,6 +482,10 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // true and fills the (src index, dst index, ratio) list when the pair's matches are already known.
     typedef std::function<bool(ViewId, ViewId, std::vector<std::tuple<size_t, size_t, double>>&)> MatchLookup;
     FeatureRunStatistics processFeatures(const std::vector<ViewFeatures>& views, std::vector<CandidatePair>& candidatePairs,
+                                         PoseGraph& poseGraph_, size_t waveSize = 1024,
+                                         const class SimilarityTable* similarityTable = nullptr,
+                                         const MatchLookup* cachedMatches = nullptr);
+    FeatureRunStatistics processFeatures(const std::vector<ViewFeaturesRef>& views, std::vector<CandidatePair>& candidatePairs,
                                          PoseGraph& poseGraph_, size_t waveSize = 1024,
                                          const class SimilarityTable* similarityTable = nullptr,
                                          const MatchLookup* cachedMatches = nullptr);

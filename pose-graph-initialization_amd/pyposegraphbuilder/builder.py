@@ -22,6 +22,11 @@ class _HostConfig(_C.Structure):
                [(n, _C.c_int32) for n in ("use_path_finding", "use_gpu", "use_epipolar_hashing")]
 
 
+class _HostView(_C.Structure):  # pgih_view
+    _fields_ = [("keypoints", _C.c_void_p), ("descriptors", _C.c_void_p), ("n", _C.c_uint32), ("pad", _C.c_uint32),
+                ("focal_length", _C.c_double), ("width", _C.c_double), ("height", _C.c_double)]
+
+
 _GRAPH_EDGE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("score", "<f8"), ("R", "<f8", 9), ("t", "<f8", 3)])  # pgih_graph_edge
 
 
@@ -88,6 +93,51 @@ class PoseGraphBuilder:
         return {(int(e["src"]), int(e["dst"])): dict(R=e["R"].reshape(3, 3).copy(), t=e["t"].copy(), score=float(e["score"]))
                 for e in edges[:n_edges.value]}
 
+    def runFeatures(self, views, pairs, waveSize=512, rotationGuided=False, deviceTracklets=True):
+        """The loop body of processImages (pose_graph_builder.h:391-709) on in-memory features -- the C++
+        PoseGraphBuilder::processFeatures behind pgih_run_features (include/pgi_host.h), marshalled only.
+
+        views: sequence of dict(xy[n,2] float32 pixels, desc[n,128] float32, focal, width, height);
+        pairs: iterable of (src, dst, similarity).  Returns the pose graph {(src, dst): dict(R, t, score)};
+        `statistics` holds the counters, `stage_seconds` the wall-clock split of the run."""
+        import ctypes as C
+        keep = []   # the arrays the view records point into
+        vrec = (_HostView * max(len(views), 1))()
+        for k, v in enumerate(views):
+            xy = np.ascontiguousarray(v["xy"], np.float32).reshape(-1, 2)
+            desc = np.ascontiguousarray(v["desc"], np.float32).reshape(-1, 128)
+            if len(xy) != len(desc):
+                raise ValueError("view %d: %d keypoints but %d descriptors" % (k, len(xy), len(desc)))
+            keep += [xy, desc]
+            vrec[k] = _HostView(xy.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), len(xy), 0, float(v["focal"]),
+                                float(v["width"]), float(v["height"]))
+        pairs = list(pairs)
+        P = len(pairs)
+        src = np.array([p[0] for p in pairs], np.uint32)
+        dst = np.array([p[1] for p in pairs], np.uint32)
+        sim = np.array([p[2] for p in pairs], np.float64)
+        lib, h = self._host()
+        if lib.pgih_set_rotation_guided(h, int(bool(rotationGuided))) < 0:
+            raise RuntimeError(lib.pgih_last_error().decode())
+        edges = np.zeros(max(P, 1), _GRAPH_EDGE)
+        n_edges = C.c_uint32(0)
+        stats = np.zeros(24, np.uint64)
+        stages = np.zeros(8, np.float64)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib.pgih_run_features(h, len(views), vrec, P, ptr(src), ptr(dst), ptr(sim), int(waveSize), int(bool(deviceTracklets)), ptr(edges),
+                                   len(edges), C.byref(n_edges), ptr(stats), ptr(stages))
+        if rc < 0:
+            raise RuntimeError(lib.pgih_last_error().decode())
+        names = ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
+                 "waves", "graph_edges", "quirk_only_guesses")
+        self.statistics = dict(zip(names, (int(v) for v in stats)))
+        self.statistics.update(zip(("matching_runs", "quick_matching_runs", "guided_matching_runs", "guided_matches_added", "track_number",
+                                    "too_few_matches"), (int(v) for v in stats[16:22])))
+        self.stage_seconds = dict(zip(("upload + prepare", "quick matching", "matching", "correspondences", "A*", "pose estimation",
+                                       "guided", "commit + tracklets"), (float(v) for v in stages)))
+        return {(int(e["src"]), int(e["dst"])): dict(R=e["R"].reshape(3, 3).copy(), t=e["t"].copy(), score=float(e["score"]))
+                for e in edges[:n_edges.value]}
+
     def _host(self):
         """libpgi_host.so's builder with this object's 17 constructor arguments (created on first use)."""
         import ctypes as C
@@ -105,6 +155,8 @@ class PoseGraphBuilder:
         lib.pgih_set_rotation_guided.argtypes = [C.c_void_p, C.c_int]
         lib.pgih_run_pairs.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p, C.c_uint32,
                                                                                      C.POINTER(C.c_uint32), C.c_void_p]
+        lib.pgih_run_features.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         enc = lambda s_: str(s_).encode()
         cfg = _HostConfig(self.kCoreNumber, self.kMaximumTrackletNumber, self.kMaximumSearchDepth, self.kMaximumPathNumber,
                           self.kMinimumInlierNumber, self.kMinimumPointNumber, self.kMaximumPointNumberForEpipolarHashing,

@@ -151,3 +151,33 @@ def test_config3_from_features_at_full_size(tmp_path):
     # nearly every row, mismatches included) and refitted on all of them.  Most such edges are fine, a good tenth is not;
     # the run counts the guesses only the quirk let through.  Documented, measured, and the reason guess_mode = 1 exists.
     assert np.median(err2) < 0.15 and np.mean(err2 < 5.0) > 0.8 and k["quirk_only_guesses"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rotationGuided", [False, True])
+def test_python_run_features_is_the_cpp_pipeline(tmp_path, rotationGuided):
+    """pyposegraphbuilder.PoseGraphBuilder.runFeatures (pgih_run_features of libpgi_host.so) against the C++ driver on the same
+    scene, path finding + epipolar hashing with the tracklets in HBM: same counters, same edges, every bit."""
+    from pyposegraphbuilder.builder import PoseGraphBuilder
+    views, poses, cam, sim, pairs = make_scene()
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    SC.write_feature_scene(fin, views, cam, sim, pairs, WAVE)
+    mode = "4" if rotationGuided else "2"
+    r = subprocess.run([EXE, fin, fout, mode], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    (st, edges), = parse(open(fout, "rb").read(), 1)
+    b = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.75, "", "", "", "", True, True, True)
+    try:
+        vs = [dict(xy=v["xy"], desc=v["desc"], focal=cam[0], width=cam[1], height=cam[2]) for v in views]
+        graph = b.runFeatures(vs, pairs, waveSize=WAVE, rotationGuided=rotationGuided)
+        k = dict(zip(SC.PIPELINE_KEYS, st))
+        for name in ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
+                     "waves", "graph_edges", "matching_runs", "quick_matching_runs", "guided_matching_runs", "guided_matches_added",
+                     "track_number", "quirk_only_guesses"):
+            assert b.statistics[name] == k[name], name
+        assert graph.keys() == edges.keys() and len(graph) > 0.9 * len(pairs)
+        for key, (sc, R, t) in edges.items():
+            assert graph[key]["score"] == sc and np.array_equal(graph[key]["R"], R.reshape(3, 3)) and np.array_equal(graph[key]["t"], t)
+        assert sum(b.stage_seconds.values()) > 0
+    finally:
+        b.close()

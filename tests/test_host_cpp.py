@@ -28,12 +28,13 @@ def test_host_library_exports_and_header_symbols():
     host = C.CDLL(os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi_host.so"))
     hdr_h = open(os.path.join(ROOT, "include", "pgi_host.h")).read()
     declared_h = set(re.findall(r"\b(pgih_[a-z0-9_]+)\s*\(", hdr_h))
-    assert declared_h == {"pgih_last_error", "pgih_create", "pgih_destroy", "pgih_set_rotation_guided", "pgih_run_pairs"}
+    assert declared_h == {"pgih_last_error", "pgih_create", "pgih_destroy", "pgih_set_rotation_guided", "pgih_run_pairs", "pgih_run_features"}
     for s in declared_h:
         assert hasattr(host, s), s
     host.pgih_create.restype = C.c_void_p
     assert not host.pgih_create(None)                       # refused, not crashed
     assert host.pgih_run_pairs(None, 0, None, None, None, None, None, None, 0, None, 0, None, None) < 0
+    assert host.pgih_run_features(None, 0, None, 0, None, None, None, 0, 1, None, 0, None, None, None) < 0
     # no device here => creation fails loudly instead of falling back to the CPU
     if lib.pgi_device_count() == 0:
         assert not lib.pgi_create(-1, None)
