@@ -1446,10 +1446,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                     for (int q = 0; q < kD / 4; ++q) {
                         const float4 u = ta[q], v = tb[q];
-                        const double u0 = (double)(a[4 * q] - u.x), u1 = (double)(a[4 * q + 1] - u.y), u2 = (double)(a[4 * q + 2] - u.z),
-                                     u3 = (double)(a[4 * q + 3] - u.w);
-                        const double w0 = (double)(a[4 * q] - v.x), w1 = (double)(a[4 * q + 1] - v.y), w2 = (double)(a[4 * q + 2] - v.z),
-                                     w3 = (double)(a[4 * q + 3] - v.w);
+                        // (two f32 differences per instruction: v_pk_add_f32; each is the same IEEE subtraction)
+                        typedef float pk2 __attribute__((ext_vector_type(2)));
+                        const pk2 a01 = {a[4 * q], a[4 * q + 1]}, a23 = {a[4 * q + 2], a[4 * q + 3]};
+                        const pk2 du01 = a01 - pk2{u.x, u.y}, du23 = a23 - pk2{u.z, u.w}, dv01 = a01 - pk2{v.x, v.y}, dv23 = a23 - pk2{v.z, v.w};
+                        const double u0 = (double)du01.x, u1 = (double)du01.y, u2 = (double)du23.x, u3 = (double)du23.y;
+                        const double w0 = (double)dv01.x, w1 = (double)dv01.y, w2 = (double)dv23.x, w3 = (double)dv23.y;
                         da = fma(u0, u0, da); db = fma(w0, w0, db);
                         da = fma(u1, u1, da); db = fma(w1, w1, db);
                         da = fma(u2, u2, da); db = fma(w2, w2, db);
