@@ -180,6 +180,11 @@ int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr_aos, const uint64_t* d
                        uint32_t n_pairs, const double* d_E, const double* d_tau2,
                        uint32_t* d_counts, uint8_t* d_masks);
 
+/* The tester's decision for a whole batch without a host round trip: d_has_guess[p] is cleared where d_counts[p] (from
+ * pgi_score_pose_batch with tau2 = (1.5 thr)^2) is below min_count -- InTraversalPoseTester::test accepts a chained pose at
+ * kMinimumInlierNumber = 5 inliers (pose_graph_builder.h:809, graph_traversal.h:221-225).  Asynchronous on the stream. */
+int pgi_screen_guesses(pgi_ctx* ctx, const uint32_t* d_counts, uint32_t min_count, uint8_t* d_has_guess, uint32_t n_pairs);
+
 /* The two scoring seams A* calls per tested path, for ONE pair with HOST pointers (re-entrant: each call leases
  * one of the PGI_PAIR_SLOTS private slots -- stream, device scratch, pinned staging -- that pgi_estimate_pose
  * uses, so the reference's 20 traversal threads overlap on the GPU; no allocation per call once a slot is warm):
@@ -198,6 +203,16 @@ int pgi_score_pose_f64_host(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, 
  * all rows).  Writes R, t, votes, cand of d_edges (other fields untouched). */
 int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* batch, const double* d_E,
                         const uint8_t* d_masks, pgi_edge* d_edges);
+
+/* pose::getPoseFromEssentialMatrix (pose_utils.h:172-252) as the reference calls it -- ONE pair, HOST pointers: E (row-major
+ * 3 x 3) and the N x 4 CV_64F correspondence matrix in, rotation (row-major), unit translation and the winning candidate's
+ * vote count out (the reference's return value, :251).  Re-entrant through the PGI_PAIR_SLOTS pool like pgi_estimate_pose.
+ * h_mask (n bytes, may be NULL): the rows that vote; NULL, or pgi_params.vote_all_rows = 1: every row, the reference's
+ * population (:203).  Candidate order, first-maximum rule and the sign rule t_out = (cand odd ? -t : +t) are the
+ * reference's (:182, :201, :243-250); the per-row test is the depth-sign rule of the product (same
+ * rotation as the reference's 4 x 4 DLT + raw-z test in 100 % of 102 000 measured pairs).  cand (optional): 0..3. */
+int pgi_pose_from_essential_host(pgi_ctx* ctx, const double E[9], const double* h_corr_aos, uint32_t n, const uint8_t* h_mask,
+                                 double R[9], double t[3], uint32_t* votes, uint32_t* cand);
 
 /* ---- minimal solver, batched (5-point; debugging / parity) -------------- */
 /* d_pts: n_samples x 5 x 4 floats.  d_models: n_samples x 10 x 9 floats,

@@ -41,12 +41,16 @@ void pgih_destroy(pgih_builder* b);
 int pgih_set_rotation_guided(pgih_builder* b, int on);
 /* PoseGraphBuilder::run over caller-provided candidate pairs.  Pair p: views src[p] -> dst[p], retrieval similarity,
  * normalised threshold thr[p], correspondences rows [offsets[p], offsets[p+1]) of corr_aos (n x 4 doubles, the reference's
- * cv::Mat N x 4 CV_64F).  The similarity table A* uses holds the candidate pairs' values (0 elsewhere).  Writes at most
- * edge_capacity edges (in (src, dst) order), their number to *n_edges, PGIH_STATS counters to stats (may be NULL). */
-int pgih_run_pairs(pgih_builder* b, uint32_t n_pairs, const uint32_t* src, const uint32_t* dst, const double* similarity,
-                   const double* thr, const uint64_t* offsets, const double* corr_aos, uint32_t wave_size,
-                   pgih_graph_edge* edges, uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats);
-
+ * cv::Mat N x 4 CV_64F; read in place, never copied on the host).  n_views: every id must be below it (0 = derive it from
+ * the ids, which must then stay below PGIH_MAX_VIEWS); offsets must not decrease and no pair may exceed INT_MAX rows --
+ * violations are errors, nothing is allocated from unchecked caller data.  The similarity table A* uses holds the candidate
+ * pairs' values (0 elsewhere; a sparse table).  seed: wave w of the run draws with seed + w (0 = what the C++ drivers use).
+ * Writes at most edge_capacity edges (in insertion order), their number to *n_edges, PGIH_STATS counters to stats (may be NULL). */
+#define PGIH_MAX_VIEWS (1u << 24)
+int pgih_run_pairs(pgih_builder* b, uint32_t n_views, uint32_t n_pairs, const uint32_t* src, const uint32_t* dst,
+                   const double* similarity, const double* thr, const uint64_t* offsets, const double* corr_aos,
+                   uint32_t wave_size, uint64_t seed, pgih_graph_edge* edges, uint32_t edge_capacity, uint32_t* n_edges,
+                   uint64_t* stats);
 
 typedef struct {           /* one view of pgih_run_features (feature_utils.h:53-95: what keypoints.h5 / image_data.h5 hold) */
     const float* keypoints;    /* n x 2 pixel coordinates */

@@ -109,6 +109,26 @@ inline bool testPose(const cv::Mat& kCorrespondences_, const Eigen::Matrix3d& kE
     return rc == 1;
 }
 
+/* pose::getPoseFromEssentialMatrix (pose_utils.h:172-252): E and the N x 4 CV_64F correspondence matrix in; rotation, unit
+ * translation out; returns the winning candidate's vote count (:251).  Every row votes, as in the reference (:203).  One
+ * re-entrant call on host pointers (pgi_pose_from_essential_host).  Candidate order, first maximum and the translation
+ * sign rule are the reference's; the per-row test is the product's depth-sign rule. */
+inline int getPoseFromEssentialMatrix(const Eigen::Matrix3d& essential_matrix_, const cv::Mat& normalized_correspondences_,
+                                      Eigen::Matrix3d& rotation_, Eigen::Vector3d& translation_) {
+    CV_Assert(normalized_correspondences_.type() == CV_64F && normalized_correspondences_.cols == 4 &&
+              normalized_correspondences_.isContinuous());
+    const RowMajor3d E = essential_matrix_;
+    double R[9], t[3];
+    uint32_t votes = 0;
+    const int rc = pgi_pose_from_essential_host(context(), E.data(),
+                                                normalized_correspondences_.rows ? normalized_correspondences_.ptr<double>() : nullptr,
+                                                (uint32_t)normalized_correspondences_.rows, /*all rows vote*/ nullptr, R, t, &votes, nullptr);
+    if (rc < 0) throw std::runtime_error(pgi_last_error());
+    rotation_ = Eigen::Map<const RowMajor3d>(R);
+    translation_ = Eigen::Map<const Eigen::Vector3d>(t);
+    return (int)votes;
+}
+
 }  // namespace mi355x
 }  // namespace reconstruction
 

@@ -1213,6 +1213,14 @@ __global__ __launch_bounds__(256) void score_pose_f64_kernel(const double* __res
     if (lane == 0) counts[pair] = cnt;
 }
 
+// The accept / reject decision of InTraversalPoseTester::test for a whole wave, on the device: a chained pose stays a guess
+// only if the screening launch counted at least `min_count` rows for it (pose_graph_builder.h:809: 5).
+__global__ __launch_bounds__(256) void screen_guesses_kernel(const uint32_t* __restrict__ counts, uint32_t min_count,
+                                                             uint8_t* __restrict__ has, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && has[i] && counts[i] < min_count) has[i] = 0;
+}
+
 // One pair for the re-entrant host seam (pgi_score_pose_f64_host): the same arithmetic, one 256-thread workgroup walking
 // the rows in chunks of 256 IN ORDER, so that InTraversalPoseTester::test's early exit (graph_traversal.h:221-225: return
 // at the kMinimumInlierNumber-th inlier) stops the scan after the chunk in which that inlier falls.  out[0] = rows that
@@ -1315,6 +1323,63 @@ __global__ __launch_bounds__(256) void decompose_kernel(const float* __restrict_
         for (int c = 0; c < 3; ++c) e->t[c] = (best & 1u) ? -tt[c] : tt[c];
         e->votes = votes[best];
         e->cand = best;
+    }
+}
+
+// One pair for the re-entrant host seam (pgi_pose_from_essential_host): rows in the reference's layout (n x 4 f64, the
+// cv::Mat of pose_utils.h:172), rounded to f32 like every row the engine estimates on, so the result equals
+// decompose_kernel's on the converted batch bit for bit.  prm: E[9]; out: R[9], t[3] (doubles), then votes, cand (u32).
+__global__ __launch_bounds__(256) void decompose_one_kernel(const double* __restrict__ corr, uint32_t n,
+                                                            const double* __restrict__ prm, const uint8_t* __restrict__ mask,
+                                                            double* __restrict__ out) {
+    __shared__ double Rt[21];
+    __shared__ uint32_t votes[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) decompose_wave(prm, Rt, tid);
+    if (tid == 0) votes[0] = votes[1] = votes[2] = votes[3] = 0;
+    __syncthreads();
+    double R1[9], R2[9], tt[3];
+    for (int c = 0; c < 9; ++c) {
+        R1[c] = Rt[c];
+        R2[c] = Rt[9 + c];
+    }
+    tt[0] = Rt[18]; tt[1] = Rt[19]; tt[2] = Rt[20];
+    const double4* rowsv = reinterpret_cast<const double4*>(corr);
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + tid;
+        const bool voter = (i < n) && (!mask || mask[i]);
+        uint32_t b1 = 0, b2 = 0;
+        if (voter) {
+            const double4 s = rowsv[i];
+            const double X1[3] = {(double)(float)s.x, (double)(float)s.y, 1.0}, X2[3] = {(double)(float)s.z, (double)(float)s.w, 1.0};
+            double x2t[3];
+            cross3(X2, tt, x2t);
+            b1 = cheirality_bits(R1, tt, X1, X2, x2t);
+            b2 = cheirality_bits(R2, tt, X1, X2, x2t);
+        }
+        v0 += __popcll(__ballot(b1 & 1u));
+        v1 += __popcll(__ballot(b1 & 2u));
+        v2 += __popcll(__ballot(b2 & 1u));
+        v3 += __popcll(__ballot(b2 & 2u));
+    }
+    if (lane == 0) {
+        atomicAdd(&votes[0], v0);
+        atomicAdd(&votes[1], v1);
+        atomicAdd(&votes[2], v2);
+        atomicAdd(&votes[3], v3);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t best = 0;
+        for (uint32_t c = 1; c < 4; ++c)
+            if (votes[c] > votes[best]) best = c;  // first maximum wins (pose_utils.h:243-250)
+        const double* Rb = (best >> 1) ? R2 : R1;
+        for (int c = 0; c < 9; ++c) out[c] = Rb[c];
+        for (int c = 0; c < 3; ++c) out[9 + c] = (best & 1u) ? -tt[c] : tt[c];
+        uint32_t* tail = reinterpret_cast<uint32_t*>(out + 12);
+        tail[0] = votes[best];
+        tail[1] = best;
     }
 }
 
@@ -1634,23 +1699,36 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
             if (!overlap) (void)hipGetLastError();
         }
         if (overlap) HIP_TRY(hipEventRecord(ctx->class_fork, stream));
-        for (int k = 0; k < n_classes; ++k) {
+        // From here on side streams may hold launched kernels: an error must not return before they are joined back into
+        // the caller's stream, or the caller could reuse / free d_edges, d_masks and the bucket lists under them.
+        hipError_t first_err = hipSuccess;
+        auto keep = [&](hipError_t e) {
+            if (e != hipSuccess && first_err == hipSuccess) first_err = e;
+            return e == hipSuccess;
+        };
+        int joined = 0;  // side classes whose join event has been recorded
+        for (int k = 0; k < n_classes && first_err == hipSuccess; ++k) {
             a.pair_list = lists + (size_t)k * b->n_pairs;
             a.pair_count = counts + k;
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
-            if (side) HIP_TRY(hipStreamWaitEvent(ls, ctx->class_fork, 0));
+            if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
             hybrid = k == 1 && ctx->hybrid_rows;
             if (hybrid) launch_lds(rows_cap_of(4, fixed_stash));  // 1280 rows in LDS next to the sample stash
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;
-            if (side) HIP_TRY(hipEventRecord(ctx->class_join[k], ls));
+            keep(hipGetLastError());
+            if (side) {
+                if (keep(hipEventRecord(ctx->class_join[k], ls))) joined = k + 1;
+                else (void)hipStreamSynchronize(ls);  // no event to wait on: drain the side stream here
+            }
         }
         ls = stream;
-        if (overlap)
-            for (int k = 0; k < n_classes - 1; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->class_join[k], 0));
+        for (int k = 0; k < joined; ++k)
+            if (!keep(hipStreamWaitEvent(stream, ctx->class_join[k], 0))) (void)hipStreamSynchronize(ctx->class_stream[k]);
+        if (first_err != hipSuccess) return fail(PGI_ERR_DEVICE, hipGetErrorString(first_err));
     }
     HIP_TRY(hipGetLastError());
     return PGI_SUCCESS;
@@ -2114,6 +2192,15 @@ int pgi_score_pose_f64(pgi_ctx* ctx, const double* d_corr, const uint64_t* d_off
     return PGI_SUCCESS;
 }
 
+int pgi_screen_guesses(pgi_ctx* ctx, const uint32_t* d_counts, uint32_t min_count, uint8_t* d_has_guess, uint32_t n_pairs) {
+    if (!ctx || (n_pairs && (!d_counts || !d_has_guess))) return fail(PGI_ERR_INVALID, "null argument");
+    if (n_pairs == 0) return PGI_SUCCESS;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(screen_guesses_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, ctx->stream, d_counts, min_count, d_has_guess, n_pairs);
+    HIP_TRY(hipGetLastError());
+    return PGI_SUCCESS;
+}
+
 int pgi_score_pose_f64_host(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, const double E[9], double tau2,
                             uint32_t early_exit_at, uint32_t* count, uint8_t* h_mask) {
     if (!ctx || !E || !count || (n && !h_corr_aos)) return fail(PGI_ERR_INVALID, "null argument");
@@ -2153,6 +2240,45 @@ int pgi_score_pose_f64_host(pgi_ctx* ctx, const double* h_corr_aos, uint32_t n, 
     *count = reached ? early_exit_at : out[0];  // the reference returns AT that inlier (graph_traversal.h:221-225)
     if (h_mask) memcpy(h_mask, h + o_mask, n);
     return reached ? 1 : 0;
+}
+
+int pgi_pose_from_essential_host(pgi_ctx* ctx, const double E[9], const double* h_corr_aos, uint32_t n, const uint8_t* h_mask,
+                                 double R[9], double t[3], uint32_t* votes, uint32_t* cand) {
+    if (!ctx || !E || !R || !t || (n && !h_corr_aos)) return fail(PGI_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    SlotLease lease(ctx);  // the pool of pgi_estimate_pose / pgi_score_pose_f64_host: re-entrant, no allocation once warm
+    pgi_ctx::PairSlot& S = *lease.S;
+    if (!S.stream) HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    // layout (pinned staging == device scratch): rows (n x 4 f64) | E[9] (+ pad) | mask (n, padded to 8) | out: R[9] t[3] votes cand
+    const size_t o_prm = (size_t)n * 32, o_mask = o_prm + 80, o_out = o_mask + (((size_t)n + 7) & ~(size_t)7), bytes = o_out + 104 + 64;
+    if (bytes > S.bytes) {
+        const size_t cap = bytes + bytes / 2;
+        if (S.d) (void)hipFree(S.d);
+        if (S.h) (void)hipHostFree(S.h);
+        S.d = S.h = nullptr;
+        S.bytes = 0;
+        HIP_TRY(hipMalloc(&S.d, cap));
+        HIP_TRY(hipHostMalloc(&S.h, cap, hipHostMallocDefault));
+        S.bytes = cap;
+    }
+    char* h = (char*)S.h;
+    char* d = (char*)S.d;
+    if (n) memcpy(h, h_corr_aos, (size_t)n * 32);
+    memcpy(h + o_prm, E, 72);
+    const bool masked = h_mask != nullptr && !ctx->prm.vote_all_rows;  // vote_all_rows: the reference's population (pose_utils.h:203)
+    if (masked && n) memcpy(h + o_mask, h_mask, n);
+    HIP_TRY(hipMemcpyAsync(d, h, masked ? o_out : o_mask, hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(decompose_one_kernel, dim3(1), dim3(256), 0, S.stream, (const double*)d, n, (const double*)(d + o_prm),
+                       masked ? (const uint8_t*)(d + o_mask) : nullptr, (double*)(d + o_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h + o_out, d + o_out, 104, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    memcpy(R, h + o_out, 72);
+    memcpy(t, h + o_out + 72, 24);
+    const uint32_t* tail = (const uint32_t*)(h + o_out + 96);
+    if (votes) *votes = tail[0];
+    if (cand) *cand = tail[1];
+    return PGI_SUCCESS;
 }
 
 int pgi_decompose_batch(pgi_ctx* ctx, const pgi_batch* b, const double* d_E, const uint8_t* d_masks,

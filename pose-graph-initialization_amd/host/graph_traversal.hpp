@@ -34,6 +34,19 @@ class SimilarityTable {
           size(num_imgs),
           build_priority_queue(build_priority_queue_),
           image_similarity_threshold(image_similarity_threshold_) {}
+    // Sparse table (round 4): only the listed pairs are stored -- a hash map keyed by the unordered pair -- and every other
+    // off-diagonal cell reads `fill`, the diagonal 1.0 (what a dense table holds after setting every i < j cell to `fill`).
+    // The dense N x N form above is what the reference allocates (imagesimilarity_graph.h:55-65) and what loadFromFile
+    // fills; callers that hand over a candidate LIST (pgih_run_pairs, the scene drivers) need a few values per view, and a
+    // dense table for them costs 200 MB and 12.5 M stores at 5000 views, 3.2 GB at 20 000.
+    struct Sparse {};
+    SimilarityTable(Sparse, size_t num_imgs, double fill_, double image_similarity_threshold_ = 0.0, bool build_priority_queue_ = false)
+        : size(num_imgs),
+          build_priority_queue(build_priority_queue_),
+          image_similarity_threshold(image_similarity_threshold_),
+          sparse(true),
+          fill(fill_) {}
+    bool isSparse() const { return sparse; }
     bool setSimilarity(ViewId from, ViewId to, double val) {
         if (from >= size || to >= size) return false;
         if (build_priority_queue && from != to && image_similarity_threshold <= val) {
@@ -41,12 +54,31 @@ class SimilarityTable {
             views.insert(to);
             view_pair_queue.emplace(val, from, to);
         }
+        if (sparse) {
+            if (from == to) return true;
+            auto ins = listed.emplace(key(from, to), val);
+            if (ins.second) {  // a new pair: it also joins the two views' rows
+                if (rows.size() < size) rows.resize(size);
+                rows[from].emplace_back((uint32_t)to, val);
+                rows[to].emplace_back((uint32_t)from, val);
+            } else {
+                ins.first->second = val;
+                for (auto& e : rows[from]) if (e.first == (uint32_t)to) e.second = val;
+                for (auto& e : rows[to]) if (e.first == (uint32_t)from) e.second = val;
+            }
+            return true;
+        }
         similarity[from][to] = val;
         similarity[to][from] = val;
         return true;
     }
     double getSimilarity(ViewId from, ViewId to) const {
         if (from >= size || to >= size) return -1.0;  // NO_SUCH_VERTEX
+        if (sparse) {
+            if (from == to) return 1.0;
+            auto it = listed.find(key(from, to));
+            return it == listed.end() ? fill : it->second;
+        }
         return similarity[from][to];
     }
     // The similarity matrix file (format: imagesimilarity_graph.h:108-171): N lines of N numbers, "%1.3f" as written by
@@ -59,6 +91,7 @@ class SimilarityTable {
     // once row j has been written.  For a symmetric file that is: each pair once, as (i < j), and never a similarity of
     // exactly 1.0.
     bool loadFromFile(const std::string& fname) {
+        if (sparse) return false;  // the file format is the dense matrix
         std::ifstream file(fname, std::ios::binary);
         if (!file.is_open()) return false;
         const std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
@@ -100,6 +133,49 @@ class SimilarityTable {
         }
         return true;
     }
+    // All similarities TO one view, for a traversal that asks getSimilarity(next, to) for many `next` and one `to` (A*'s
+    // heuristic, graph_traversal.h:847): the dense table's row, or -- sparse -- the view's listed values scattered into the
+    // calling thread's stamped array, so that each question is one load instead of one hash lookup.
+    class RowTo {
+       public:
+        double operator()(ViewId from) const {
+            if (dense) return from < n ? dense[from] : -1.0;
+            if (from >= n) return -1.0;  // NO_SUCH_VERTEX
+            if (from == to) return 1.0;
+            return stamp[from] == epoch ? value[from] : fill;
+        }
+
+       private:
+        friend class SimilarityTable;
+        const double* dense = nullptr;
+        const double* value = nullptr;   // the calling thread's scratch (sized to the table: never resized while in use)
+        const uint32_t* stamp = nullptr;
+        uint32_t epoch = 0;
+        size_t n = 0;
+        ViewId to = 0;
+        double fill = 0.0;
+    };
+    RowTo rowTo(ViewId to) const {
+        RowTo r;
+        r.n = size;
+        r.to = to;
+        r.fill = fill;
+        if (!sparse) {
+            if (to < size) r.dense = similarity[to].data();  // (symmetric by construction: setSimilarity writes both cells)
+            else r.n = 0;
+            return r;
+        }
+        struct Scratch { std::vector<double> value; std::vector<uint32_t> stamp; uint32_t epoch = 0; };
+        static thread_local Scratch sc;
+        if (sc.stamp.size() < size) { sc.stamp.assign(size, 0u); sc.value.assign(size, 0.0); sc.epoch = 0; }
+        if (++sc.epoch == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0u); sc.epoch = 1; }
+        if (to < rows.size())
+            for (const auto& e : rows[to]) { sc.value[e.first] = e.second; sc.stamp[e.first] = sc.epoch; }
+        r.value = sc.value.data();
+        r.stamp = sc.stamp.data();
+        r.epoch = sc.epoch;
+        return r;
+    }
     std::priority_queue<std::tuple<double, ViewId, ViewId>>& getMutablePrioritizedViewPairs() { return view_pair_queue; }
     const std::unordered_set<ViewId>& getKeptViews() const { return views; }
 
@@ -110,6 +186,11 @@ class SimilarityTable {
     const double image_similarity_threshold;
     std::priority_queue<std::tuple<double, ViewId, ViewId>> view_pair_queue;
     std::unordered_set<ViewId> views;
+    bool sparse = false;
+    double fill = 0.0;
+    static uint64_t key(ViewId a, ViewId b) { return a < b ? ((uint64_t)a << 32) | (uint64_t)b : ((uint64_t)b << 32) | (uint64_t)a; }
+    std::unordered_map<uint64_t, double> listed;  // sparse mode: unordered pair -> similarity (ids < 2^32)
+    std::vector<std::vector<std::pair<uint32_t, double>>> rows;  // sparse mode: per view, its listed (other view, similarity)
 };
 
 class VisibilityTable {  // "is there already a path between two views?" (pose_graph_builder.h:456-457, 692)
@@ -118,10 +199,15 @@ class VisibilityTable {  // "is there already a path between two views?" (pose_g
         for (size_t i = 0; i < n; ++i) parent[i] = i;
     }
     bool hasLink(ViewId a, ViewId b) const { return find(a) == find(b); }
-    void addLink(ViewId a, ViewId b) {
-        a = find(a);
-        b = find(b);
-        if (a != b) parent[std::max(a, b)] = std::min(a, b);
+    void addLink(ViewId a, ViewId b) {  // (single writer; hasLink may run concurrently only between commits)
+        const ViewId ra = find(a), rb = find(b), root = std::min(ra, rb);
+        if (ra != rb) parent[std::max(ra, rb)] = root;
+        for (ViewId v : {a, b})  // both walks now end at `root`: point them at it, so the chains hasLink follows stay short
+            while (parent[v] != root && v != root) {
+                const ViewId next = parent[v];
+                parent[v] = root;
+                v = next;
+            }
     }
 
    protected:
@@ -139,16 +225,28 @@ class ImageSimilarityHeuristics {  // graph_traversal.h:569-596
     double getCost(const ViewId& a, const ViewId& b) const {
         return std::clamp(kSimilarityTable.getSimilarity(a, b), 0.0, 1.0);
     }
+    // getCost(., kTo_) for one search: the table's row towards the target, looked up once (SimilarityTable::rowTo)
+    struct CostsTo {
+        SimilarityTable::RowTo row;
+        double operator()(const ViewId& a) const { return std::clamp(row(a), 0.0, 1.0); }
+    };
+    CostsTo costsTo(const ViewId& kTo_) const { return CostsTo{kSimilarityTable.rowTo(kTo_)}; }
 
    protected:
     const SimilarityTable& kSimilarityTable;
 };
 
 // graph_traversal.h:290-348: pose <- T_edge * pose, or T_edge^-1 * pose for a reversed edge
-inline bool recoverPath(const PoseGraph& g, const std::vector<ViewId>& path, SE3d& pose_) {
+inline bool recoverPath(const PoseGraph& g, const std::vector<ViewId>& path, SE3d& pose_, bool frozen = false) {
     pose_ = SE3d();
     for (size_t i = 1; i < path.size(); ++i) {
         const ViewId a = path[i - 1], b = path[i];
+        if (frozen) {  // no writer runs: plain lookups, no copies (PoseGraph::findEdgeFrozen)
+            if (const PoseGraphEdge* e = g.findEdgeFrozen({a, b})) pose_ = e->getValue().getTransform() * pose_;
+            else if (const PoseGraphEdge* r = g.findEdgeFrozen({b, a})) pose_ = r->getValue().getTransform().inverse() * pose_;
+            else return false;
+            continue;
+        }
         if (g.hasEdge(a, b))
             pose_ = g.getEdgeById({a, b}).getValue().getTransform() * pose_;
         else if (g.hasEdge(b, a))
@@ -172,35 +270,76 @@ class AStarTraversal {
           kMaximumDepth(kMaximumDepth_) {}
     static constexpr const char* name() { return "a-star"; }
 
+    // The caller promises that nothing modifies the pose graph while searches run (the wave scheduler: between two
+    // commits); the traversal then reads it without the shared lock, so kCoreNumber search threads do not contend.
+    void setGraphFrozen(bool on) { frozen = on; }
+
     // graph_traversal.h:679-870.  path_ / poses_ receive the (single) recovered path and its chained pose;
     // with a pose test the pose is returned only if the test accepts it (:787-797).
     void getPath(const ViewId kFrom_, const ViewId kTo_, std::vector<ViewId>& path_, std::vector<SE3d>& poses_,
                  size_t& touchedNodes_, size_t& foundPaths_, bool& pathExists_, const PoseTest& test = PoseTest()) const {
-        // (the reference copies the parent list into every open node; here an open node points at a link of a shared chain,
-        //  and the expanded set is a flat list -- the same search, without an allocation per pushed node)
+        // (the reference copies the parent list into every open node; here an open node points at a link of a shared chain.
+        //  The search's working memory -- heap, chain, the set of expanded vertices -- belongs to the calling thread and is
+        //  reused from search to search: no allocation per search once warm, and "already expanded?" is one load: a stamp
+        //  per view id for ids below 2^22, a hash set above)
         struct Link { ViewId vertex; int prev; };
-        struct Node {
-            double edgeCost, nextCost, combined;
-            size_t seq;
+        struct Node {  // an open node's payload; the heap itself holds 16-byte keys that point here
+            double edgeCost, nextCost;
             ViewId vertex;
             int chain;  // link of the parent vertex, -1 at the start vertex
-            size_t depth;
+            uint32_t depth;
         };
-        auto worse = [](const Node& a, const Node& b) {  // max-heap on combined, earlier insertion first
+        struct Key { double combined; uint32_t seq, node; };
+        auto worse = [](const Key& a, const Key& b) {  // max-heap on combined, earlier insertion first
             if (a.combined != b.combined) return a.combined < b.combined;
             return a.seq > b.seq;
         };
-        std::priority_queue<Node, std::vector<Node>, decltype(worse)> openNodes(worse);
-        std::vector<Link> chain;
-        std::vector<ViewId> nodeStates;  // vertices that have been expanded (Open/Closed)
-        size_t seq = 0;
-        openNodes.push(Node{1.0, 0.0, 0.0, seq, kFrom_, -1, 0});  // (1, 0, 0) at :721
+        struct Scratch {
+            std::vector<Key> heap;
+            std::vector<Node> nodes;
+            std::vector<Link> chain;
+            std::vector<uint32_t> stamp;
+            uint32_t epoch = 0;
+            std::unordered_set<ViewId> big;  // ids >= kStampLimit
+        };
+        static thread_local Scratch tls;
+        Scratch& sc = tls;  // (one thread-local lookup per search, not one per visited edge)
+        constexpr ViewId kStampLimit = (ViewId)1 << 22;
+        sc.heap.clear();
+        sc.nodes.clear();
+        sc.chain.clear();
+        sc.big.clear();
+        if (++sc.epoch == 0) {  // wrapped: forget every stamp
+            std::fill(sc.stamp.begin(), sc.stamp.end(), 0u);
+            sc.epoch = 1;
+        }
+        const uint32_t epoch = sc.epoch;
+        auto expanded = [&](ViewId v) {
+            if (v < kStampLimit) return v < sc.stamp.size() && sc.stamp[v] == epoch;
+            return sc.big.count(v) != 0;
+        };
+        auto markExpanded = [&](ViewId v) {
+            if (v < kStampLimit) {
+                if (v >= sc.stamp.size()) sc.stamp.resize(std::max<size_t>(v + 1, 2 * sc.stamp.size()), 0u);
+                sc.stamp[v] = epoch;
+            } else {
+                sc.big.insert(v);
+            }
+        };
+        std::vector<Key>& openNodes = sc.heap;
+        std::vector<Node>& nodes = sc.nodes;
+        std::vector<Link>& chain = sc.chain;
+        uint32_t seq = 0;
+        nodes.push_back(Node{1.0, 0.0, kFrom_, -1, 0});  // (1, 0, 0) at :721
+        openNodes.push_back(Key{0.0, seq, 0});
         pathExists_ = false;
         foundPaths_ = 0;
         const double oneMinusWeight = 1.0 - weight;
+        const auto costTo = kHeuristicsObject.costsTo(kTo_);  // == getCost(., kTo_)
         while (!openNodes.empty()) {
-            const Node node = openNodes.top();
-            openNodes.pop();
+            std::pop_heap(openNodes.begin(), openNodes.end(), worse);
+            const Node node = nodes[openNodes.back().node];
+            openNodes.pop_back();
             ++touchedNodes_;
             if (node.depth > kMaximumDepth) continue;  // :755
             if (node.vertex == kTo_) {                 // :766
@@ -209,7 +348,7 @@ class AStarTraversal {
                 for (int l = node.chain; l >= 0; l = chain[(size_t)l].prev) path_.push_back(chain[(size_t)l].vertex);
                 std::reverse(path_.begin(), path_.end());
                 SE3d pose;
-                if (recoverPath(*kPoseGraph, path_, pose)) {
+                if (recoverPath(*kPoseGraph, path_, pose, frozen)) {
                     ++foundPaths_;
                     if (!test || test(pose)) poses_.push_back(pose);
                 }
@@ -217,17 +356,25 @@ class AStarTraversal {
             }
             chain.push_back(Link{node.vertex, node.chain});
             const int here = (int)chain.size() - 1;
-            if (std::find(nodeStates.begin(), nodeStates.end(), node.vertex) == nodeStates.end()) nodeStates.push_back(node.vertex);
-            if (node.depth < kMaximumDepth)  // :817-820
-                kPoseGraph->forEachEdgeOf(node.vertex, [&](const PoseGraphEdge& e) {
-                    if (e.getScore() < kMinimumInlierRatio) return;  // :830
-                    const ViewId next = node.vertex == e.getDestinationId() ? e.getSourceId() : e.getDestinationId();
-                    const double edgeCost = std::min(node.edgeCost, e.getScore());                             // :843
-                    const double nextCost = std::max(node.nextCost, kHeuristicsObject.getCost(next, kTo_));    // :847
-                    const double combined = weight * edgeCost + oneMinusWeight * nextCost;                     // :851
-                    if (std::find(nodeStates.begin(), nodeStates.end(), next) == nodeStates.end())             // :855
-                        openNodes.push(Node{edgeCost, nextCost, combined, ++seq, next, here, node.depth + 1});
-                });
+            markExpanded(node.vertex);
+            if (node.depth < kMaximumDepth) {  // :817-820
+                auto visitNeighbour = [&](const ViewId next, const double score) {
+                    if (score < kMinimumInlierRatio) return;  // :830
+                    if (expanded(next)) return;                                                    // :855
+                    const double edgeCost = std::min(node.edgeCost, score);                        // :843
+                    const double nextCost = std::max(node.nextCost, costTo(next));                 // :847
+                    const double combined = weight * edgeCost + oneMinusWeight * nextCost;         // :851
+                    nodes.push_back(Node{edgeCost, nextCost, next, here, node.depth + 1});
+                    openNodes.push_back(Key{combined, ++seq, (uint32_t)nodes.size() - 1});
+                    std::push_heap(openNodes.begin(), openNodes.end(), worse);
+                };
+                if (frozen)
+                    kPoseGraph->forEachNeighbourFrozen(node.vertex, visitNeighbour);
+                else
+                    kPoseGraph->forEachEdgeOf(node.vertex, [&](const PoseGraphEdge& e) {
+                        visitNeighbour(node.vertex == e.getDestinationId() ? e.getSourceId() : e.getDestinationId(), e.getScore());
+                    });
+            }
         }
         pathExists_ = !poses_.empty();
     }
@@ -238,6 +385,7 @@ class AStarTraversal {
     const double weight;  // CostComparator::weight (graph_traversal.h:662, set at pose_graph_builder.h:828)
     const double kMinimumInlierRatio;
     const size_t kMaximumDepth;
+    bool frozen = false;
 };
 
 }  // namespace reconstruction

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,22 @@ struct WaveBuf {  // DevBuf's interface over pool memory
         return static_cast<T*>(p);
     }
 };
+// fn(i) for i in [0, n) on up to `threads` host threads (contiguous, equally sized index ranges; the caller's thread takes the
+// first).  What the reference does with `#pragma omp parallel for num_threads(kCoreNumber)` (pose_graph_builder.h:391-392).
+template <class Fn>
+void parallelFor(size_t n, size_t threads, Fn fn) {
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(threads, n), std::max(1u, std::thread::hardware_concurrency())));
+    auto work = [&](size_t t) {
+        const size_t a = n * t / nt, b = n * (t + 1) / nt;
+        for (size_t i = a; i < b; ++i) fn(i);
+    };
+    if (nt == 1) { work(0); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread& th : pool) th.join();
+}
 void h2d(void* d, const void* h, size_t n) {
     if (n && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) throw PgiError("hipMemcpy H2D failed");
 }
@@ -88,32 +105,162 @@ struct DeviceBatch {
 uint32_t PoseGraphBuilder::worldSize() const { return hostComm ? hostComm->world() : 1u; }
 uint32_t PoseGraphBuilder::worldRank() const { return hostComm ? hostComm->rank() : 0u; }
 
-// One page-locked host block and one device block with the same layout: the batch is converted straight into the
-// host block (f64 AoS rows -> f32 SoA, in parallel) and travels as ONE asynchronous-capable copy.  Separate pageable
-// vectors cost 25 ms of staged copies for 30 MB in a fresh process, and nine allocations per wave.
-struct PoseGraphBuilder::Staging {
-    void* host = nullptr;
-    void* dev = nullptr;
-    size_t host_bytes = 0, dev_bytes = 0;
-    ~Staging() {
-        if (host) (void)hipHostFree(host);
-        if (dev) (void)hipFree(dev);
+// The reference's guess path refits every accepted chained pose on the rows inside the UN-squared getInliers bound
+// (graph_traversal.h:149,164 -- at 0.4 px and f = 1000 that is ~24 px), so a pose with a handful of true inliers yields an
+// edge.  Faithful by default; when such edges are more than 5 % of the accepted guesses the run says so once (stderr,
+// rank 0; PGI_QUIET silences it) and counts it ("[Pose estimation] Quirk-only warning").
+void PoseGraphBuilder::warnQuirkOnlyGuesses(size_t quirkOnly, size_t acceptedGuesses) {
+    if (!acceptedGuesses || quirkOnly * 20 <= acceptedGuesses) return;
+    statistics.addCount("[Pose estimation] Quirk-only warning", 1, 1);
+    if (worldRank() != 0 || std::getenv("PGI_QUIET")) return;
+    std::fprintf(stderr,
+                 "pose-graph builder: %zu of %zu accepted A* pose guesses (%.0f %%) have fewer than kMinimumInlierNumber rows inside the "
+                 "squared bound (1.5 thr)^2 -- these edges exist only through the reference's un-squared getInliers comparison "
+                 "(graph_traversal.h:164) and are usually wrong; PoseGraphBuilder::setRotationGuidedGuesses(true) re-estimates chained "
+                 "poses instead (see DESIGN.md section 4-4)\n",
+                 quirkOnly, acceptedGuesses, 100.0 * (double)quirkOnly / (double)acceptedGuesses);
+}
+
+// A few host threads that stay alive between calls (the reference's kCoreNumber OpenMP team, pose_graph_builder.h:391-392):
+// run(n, fn) calls fn(i) for i in [0, n) in contiguous, equally sized index ranges, the caller taking the first.
+class HostPool {
+   public:
+    explicit HostPool(size_t threads) {
+        const size_t n = std::max<size_t>(1, std::min<size_t>(threads, std::max(1u, std::thread::hardware_concurrency())));
+        for (size_t t = 1; t < n; ++t) workers.emplace_back([this, t] { loop(t); });
     }
-    void reserve(size_t hb, size_t db) {
-        if (hb > host_bytes) {
-            if (host) (void)hipHostFree(host);
-            host = nullptr; host_bytes = 0;
-            if (hipHostMalloc(&host, hb + hb / 4, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
-            host_bytes = hb + hb / 4;
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            quit = true;
         }
-        if (db > dev_bytes) {
+        wake.notify_all();
+        for (std::thread& th : workers) th.join();
+    }
+    size_t size() const { return workers.size() + 1; }
+    template <class Fn>
+    void run(size_t n, Fn fn) {
+        const size_t nt = std::min(size(), std::max<size_t>(n, 1));
+        std::function<void(size_t)> body = [&](size_t t) {
+            if (t >= nt) return;
+            const size_t a = n * t / nt, b = n * (t + 1) / nt;
+            for (size_t i = a; i < b; ++i) fn(i);
+        };
+        if (nt == 1) { body(0); return; }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            job = &body;
+            pending = workers.size();
+            ++generation;
+        }
+        wake.notify_all();
+        body(0);
+        std::unique_lock<std::mutex> l(mu);
+        done.wait(l, [&] { return pending == 0; });
+        job = nullptr;
+    }
+
+   private:
+    void loop(size_t t) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(size_t)>* mine;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                wake.wait(l, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+                mine = job;
+            }
+            (*mine)(t);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (--pending == 0) done.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::function<void(size_t)>* job = nullptr;
+    size_t pending = 0;
+    uint64_t generation = 0;
+    bool quit = false;
+};
+
+// Staging of estimatePoses (round 4: a pipeline instead of one block).  The reference hands over one cv::Mat N x 4 CV_64F
+// per pair (pageable, 32 B per row); the device wants the flattened f32 SoA.  At SURVEY 8d's size -- 10^5 pairs, 7.7 * 10^7
+// rows, 2.45 GB of doubles -- converting everything into one page-locked block first cost 0.22 s of a 0.41 s run (a third of
+// it the 1.5 GB page-locked allocation itself).  Now the block's pairs are cut into chunks of ~4 M rows; the host team
+// converts chunk c + 1 into one of three page-locked ring buffers while chunk c travels on a copy stream and the kernels of
+// chunk c - 1 run; ring, device block, streams and events are grow-only and shared by every builder of the process.
+struct PoseGraphBuilder::Staging {
+    static constexpr int kRing = 3;
+    void* dev = nullptr;
+    size_t dev_bytes = 0;
+    void* small = nullptr;  // page-locked per-pair arrays (offsets, thresholds, guesses, screening models)
+    size_t small_bytes = 0;
+    void* ring[kRing] = {nullptr, nullptr, nullptr};
+    size_t ring_bytes = 0;  // each
+    hipStream_t copy = nullptr;
+    hipEvent_t up[kRing] = {nullptr, nullptr, nullptr};
+    hipEvent_t smallUp = nullptr;
+    std::unique_ptr<HostPool> pool;
+    std::mutex busy;  // one estimatePoses at a time per process
+    ~Staging() {
+        if (dev) (void)hipFree(dev);
+        if (small) (void)hipHostFree(small);
+        for (void* r : ring) if (r) (void)hipHostFree(r);
+        for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+        if (smallUp) (void)hipEventDestroy(smallUp);
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+    void init(size_t threads) {
+        if (!copy) {  // highest priority: a copy that shares a priority with queued K1 workgroups is starved by them
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&copy, hipStreamNonBlocking, greatest) != hipSuccess) throw PgiError("hipStreamCreate failed");
+        }
+        for (hipEvent_t& e : up)
+            if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
+        if (!smallUp && hipEventCreateWithFlags(&smallUp, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
+        if (!pool || pool->size() < std::min<size_t>(threads, std::max(1u, std::thread::hardware_concurrency()))) pool.reset(new HostPool(threads));
+    }
+    static void growHost(void*& p, size_t& have, size_t want) {
+        if (want <= have) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; have = 0;
+        if (hipHostMalloc(&p, want + want / 4, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
+        have = want + want / 4;
+    }
+    void reserve(size_t smallBytes, size_t ringBytes, size_t devBytes) {
+        growHost(small, small_bytes, smallBytes);
+        if (ringBytes > ring_bytes) {
+            size_t have = 0;
+            for (void*& r : ring) { have = ring_bytes; growHost(r, have, ringBytes); }
+            ring_bytes = have;
+        }
+        if (devBytes > dev_bytes) {
             if (dev) (void)hipFree(dev);
             dev = nullptr; dev_bytes = 0;
-            if (hipMalloc(&dev, db + db / 4) != hipSuccess) throw PgiError("hipMalloc failed");
-            dev_bytes = db + db / 4;
+            if (hipMalloc(&dev, devBytes + devBytes / 4) != hipSuccess) throw PgiError("hipMalloc failed");
+            dev_bytes = devBytes + devBytes / 4;
         }
     }
+    // Process-wide and never released: page-locking a few hundred MB costs tens of milliseconds, and a process that builds
+    // one pose graph after another (or one builder per configuration) should pay that once.  (Freed by the process's exit;
+    // an explicit teardown would have to run before the HIP runtime's own, which static destruction order does not promise.)
+    static std::shared_ptr<Staging> shared() {
+        static std::shared_ptr<Staging>* inst = new std::shared_ptr<Staging>(new Staging());
+        return *inst;
+    }
 };
+
+#define HIP_OK(x)                                                                                       \
+    do {                                                                                                \
+        const hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) throw PgiError(std::string(#x) + ": " + hipGetErrorString(e_));           \
+    } while (0)
 
 size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
                                        std::vector<pgi_edge>* edges_out, bool screenGuesses, pgi_edge* d_edges_out) {
@@ -123,10 +270,11 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     const Clock::time_point t0 = Clock::now();
     Clock::time_point tp = t0;
     const bool timing = std::getenv("PGI_HOST_TIMING") != nullptr;  // stderr: wall clock per phase of this function
-    auto mark = [&](const char* what) {
-        if (!timing) return;
+    auto mark = [&](const char* what) {  // phase clocks: RunningStatistics "[Pose estimation] <phase>" (+ stderr on request)
         const Clock::time_point now = Clock::now();
-        std::fprintf(stderr, "[estimatePoses] %-34s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - tp).count());
+        const double sec = std::chrono::duration<double>(now - tp).count();
+        statistics.addTime(std::string("[Pose estimation] ") + what, sec, 1);
+        if (timing) std::fprintf(stderr, "[estimatePoses] %-34s %8.3f ms\n", what, 1e3 * sec);
         tp = now;
     };
     // this rank's contiguous, row-balanced block [lo, hi) of the wave
@@ -136,59 +284,72 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     const std::vector<std::pair<size_t, size_t>> blocks = dist::shardBounds(rowsPerPair, world);
     const size_t lo = blocks[rank].first, hi = blocks[rank].second, L = hi - lo;
     std::vector<uint64_t> off(L + 1, 0);
-    uint32_t max_corr = 0;
-    for (size_t k = 0; k < L; ++k) {
-        off[k + 1] = off[k] + rowsPerPair[lo + k];
-        max_corr = std::max(max_corr, (uint32_t)rowsPerPair[lo + k]);
-    }
+    for (size_t k = 0; k < L; ++k) off[k + 1] = off[k] + rowsPerPair[lo + k];
     const size_t rows = off[L];
-    // layout shared by the host and the device block (256-byte aligned pieces)
+    // chunks of whole pairs, ~chunkRows rows each (PGI_HOST_CHUNK_ROWS overrides the default for experiments)
+    size_t chunkRows = (size_t)4 << 20;
+    if (const char* e = std::getenv("PGI_HOST_CHUNK_ROWS")) chunkRows = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+    struct Chunk { size_t k0, k1; uint32_t maxCorr; };
+    std::vector<Chunk> chunks;
+    size_t maxChunkRows = 0;
+    for (size_t k = 0; k < L;) {
+        size_t k1 = k;
+        uint32_t mc = 0;
+        while (k1 < L && (k1 == k || off[k1 + 1] - off[k] <= chunkRows)) {
+            mc = std::max(mc, (uint32_t)rowsPerPair[lo + k1]);
+            ++k1;
+        }
+        chunks.push_back(Chunk{k, k1, mc});
+        maxChunkRows = std::max<size_t>(maxChunkRows, off[k1] - off[k]);
+        k = k1;
+    }
+    // device layout (256-byte aligned pieces): the whole block's SoA rows, the per-pair arrays, masks, screening scratch;
+    // the page-locked `small` block mirrors the per-pair part [o_off, o_small_end)
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_x1 = 0, o_y1 = o_x1 + up(rows * 4), o_x2 = o_y1 + up(rows * 4), o_y2 = o_x2 + up(rows * 4),
                  o_off = o_y2 + up(rows * 4), o_thr = o_off + up((L + 1) * 8), o_guess = o_thr + up(L * 8),
-                 o_has = o_guess + up(L * 96), host_total = o_has + up(L), o_masks = host_total, dev_total = o_masks + up(rows);
-    if (!staging) staging.reset(new Staging());
-    staging->reserve(host_total, dev_total);
-    char* hb = (char*)staging->host;
-    float *x1 = (float*)(hb + o_x1), *y1 = (float*)(hb + o_y1), *x2 = (float*)(hb + o_x2), *y2 = (float*)(hb + o_y2);
-    double *thr = (double*)(hb + o_thr), *guess = (double*)(hb + o_guess);
-    uint8_t* has = (uint8_t*)(hb + o_has);
-    memcpy(hb + o_off, off.data(), (L + 1) * 8);
-    memset(guess, 0, L * 96);
-    memset(has, 0, L);
+                 o_has = o_guess + up(L * 96), o_Eg = o_has + up(L), o_tau = o_Eg + up(L * 72), o_small_end = o_tau + up(L * 8),
+                 o_cnt = o_small_end, o_masks = o_cnt + up(L * 4), dev_total = o_masks + up(rows);
+    if (!staging) staging = Staging::shared();
+    std::lock_guard<std::mutex> stagingBusy(staging->busy);
+    staging->init(kCoreNumber ? kCoreNumber : 1);
+    staging->reserve(o_small_end - o_off, maxChunkRows * 16, dev_total);
+    char* const hs = (char*)staging->small - o_off;  // so that hs + o_* addresses the page-locked mirror
+    char* const db = (char*)staging->dev;
+    double *thr = (double*)(hs + o_thr), *guess = (double*)(hs + o_guess), *Eg = (double*)(hs + o_Eg), *tau2 = (double*)(hs + o_tau);
+    uint8_t* has = (uint8_t*)(hs + o_has);
+    memcpy(hs + o_off, off.data(), (L + 1) * 8);
     bool any_guess = false;
     for (size_t k = 0; k < L; ++k) {  // per-pair arrays: every pair, also those without rows
         const ViewPair& vp = pairs[lo + k];
         thr[k] = vp.normalizedThreshold;
+        has[k] = 0;
         if (!vp.poseGuesses.empty()) {  // the last guess wins (pose_graph_builder.h:974-1029)
             const SE3d& g = vp.poseGuesses.back();
             for (int c2 = 0; c2 < 9; ++c2) guess[12 * k + c2] = g.R[c2];
             for (int c2 = 0; c2 < 3; ++c2) guess[12 * k + 9 + c2] = g.t[c2];
             has[k] = 1;
             any_guess = true;
+        } else {
+            for (int c2 = 0; c2 < 12; ++c2) guess[12 * k + c2] = 0.0;
         }
     }
-    {   // row conversion in parallel over contiguous, row-balanced ranges of pairs
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, kCoreNumber ? kCoreNumber : 1), std::min<size_t>(hw, rows / 65536 + 1)));
-        auto work = [&](size_t t) {
-            const uint64_t r0 = rows * t / nt, r1 = t + 1 == nt ? rows : rows * (t + 1) / nt;
-            // pairs whose first row lies in [r0, r1): the first k with off[k] >= r0 (pairs without rows convert nothing)
-            for (size_t k = (size_t)(std::lower_bound(off.begin(), off.end(), r0) - off.begin()); k < L && off[k] < r1; ++k) {
-                const CorrespondenceMatrix& c = pairs[lo + k].correspondences;
-                for (int r = 0; r < c.rows; ++r) {
-                    const double* q = c.ptr(r);
-                    const size_t o = off[k] + (size_t)r;
-                    x1[o] = (float)q[0]; y1[o] = (float)q[1]; x2[o] = (float)q[2]; y2[o] = (float)q[3];
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (std::thread& th : pool) th.join();
+    const bool screen = any_guess && screenGuesses;
+    std::vector<uint8_t> screened;        // this block's pairs that carried a chained pose into the screening launch
+    std::vector<uint32_t> guessInliers;   // their inlier counts under the SQUARED bound (1.5 thr)^2
+    if (screen) {
+        // InTraversalPoseTester::test for every chained pose of the block, one launch per chunk:
+        // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
+        screened.assign(has, has + L);
+        for (size_t k = 0; k < L; ++k) {
+            for (int c = 0; c < 9; ++c) Eg[9 * k + c] = 0.0;
+            tau2[k] = 0.0;
+            if (!has[k]) { Eg[9 * k] = 1.0; continue; }
+            const Matrix3d E = pose::getEssentialMatrixFromRelativePose(pairs[lo + k].poseGuesses.back());
+            for (int c = 0; c < 9; ++c) Eg[9 * k + c] = E[c];
+            tau2[k] = (1.5 * thr[k]) * (1.5 * thr[k]);
+        }
     }
-    mark("rows f64 AoS -> f32 SoA (host)");
     // the gathered table (P records); this rank's block is written in place at [lo, hi)
     std::unique_ptr<DevBuf> own_all;
     pgi_edge* d_all = d_edges_out;
@@ -196,54 +357,91 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         own_all.reset(new DevBuf(P * sizeof(pgi_edge)));
         d_all = own_all->as<pgi_edge>();
     }
-    std::vector<uint8_t> screened;        // this block's pairs that carried a chained pose into the screening launch
-    std::vector<uint32_t> guessInliers;   // their inlier counts under the SQUARED bound (1.5 thr)^2
+    mark("per-pair arrays (host)");
+    double convertSeconds = 0;
     if (L) {
-        char* db = (char*)staging->dev;
-        h2d(db, hb, any_guess ? host_total : o_guess);  // one copy out of page-locked memory
-        mark("upload");
-        pgi_batch b{};
-        b.d_x1 = (const float*)(db + o_x1); b.d_y1 = (const float*)(db + o_y1); b.d_x2 = (const float*)(db + o_x2); b.d_y2 = (const float*)(db + o_y2);
-        b.d_offsets = (const uint64_t*)(db + o_off); b.d_thr = (const double*)(db + o_thr);
-        b.d_guess_Rt = nullptr; b.d_has_guess = nullptr;
-        b.n_pairs = (uint32_t)L; b.max_corr = max_corr; b.pair_id_base = lo; b.seed = seed;  // ids = positions in `pairs`
-        if (any_guess && screenGuesses) {
-            screened.assign(has, has + L);
-            // InTraversalPoseTester::test for every chained pose of the block in ONE launch:
-            // E = [t]x R (pose_utils.h:74-86), bound (1.5 thr)^2 (:798), accepted at 5 inliers (:809)
-            std::vector<double> Eg(9 * L, 0.0), tau2(L, 0.0);
-            for (size_t k = 0; k < L; ++k) {
-                if (!has[k]) { Eg[9 * k] = 1.0; continue; }
-                const Matrix3d E = pose::getEssentialMatrixFromRelativePose(pairs[lo + k].poseGuesses.back());
-                for (int c = 0; c < 9; ++c) Eg[9 * k + c] = E[c];
-                tau2[k] = (1.5 * thr[k]) * (1.5 * thr[k]);
+        hipStream_t copy = staging->copy;
+        const size_t smallBytes = (screen ? o_small_end : any_guess ? o_Eg : o_guess) - o_off;
+        HIP_OK(hipMemcpyAsync(db + o_off, hs + o_off, smallBytes, hipMemcpyHostToDevice, copy));
+        HIP_OK(hipEventRecord(staging->smallUp, copy));
+        HIP_OK(hipStreamWaitEvent(nullptr, staging->smallUp, 0));  // the engine works on the default stream
+        float* const dcol[4] = {(float*)(db + o_x1), (float*)(db + o_y1), (float*)(db + o_x2), (float*)(db + o_y2)};
+        size_t groupK0 = 0, groupChunks = 0, groupTarget = 1;
+        uint32_t groupMaxCorr = 0;
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            const Chunk& ch = chunks[c];
+            const int slot = (int)(c % Staging::kRing);
+            const size_t r0 = off[ch.k0], cr = off[ch.k1] - r0;
+            if (c >= (size_t)Staging::kRing) HIP_OK(hipEventSynchronize(staging->up[slot]));  // its previous upload has left the buffer
+            float* const hb = (float*)staging->ring[slot];
+            const Clock::time_point tc = Clock::now();
+            if (cr) {
+                // the team converts contiguous row ranges of the chunk; a range starts inside the pair holding its first row
+                const size_t parts = std::min<size_t>(staging->pool->size(), cr / 16384 + 1);
+                staging->pool->run(parts, [&](size_t t) {
+                    const size_t a = r0 + cr * t / parts, z = r0 + cr * (t + 1) / parts;
+                    size_t k = (size_t)(std::upper_bound(off.begin() + ch.k0, off.begin() + ch.k1 + 1, a) - off.begin()) - 1;
+                    for (size_t r = a; r < z; ++k) {
+                        const size_t pairEnd = std::min<size_t>(off[k + 1], z);
+                        const double* q = pairs[lo + k].correspondences.ptr((int)(r - off[k]));
+                        float *x1 = hb + (r - r0), *y1 = x1 + cr, *x2 = y1 + cr, *y2 = x2 + cr;
+                        for (size_t i = 0, m = pairEnd - r; i < m; ++i, q += 4) {
+                            x1[i] = (float)q[0]; y1[i] = (float)q[1]; x2[i] = (float)q[2]; y2[i] = (float)q[3];
+                        }
+                        r = pairEnd;
+                    }
+                });
+                for (int a = 0; a < 4; ++a)
+                    HIP_OK(hipMemcpyAsync(dcol[a] + r0, hb + (size_t)a * cr, cr * 4, hipMemcpyHostToDevice, copy));
             }
-            DevBuf dE(L * 72), dtau(L * 8), dcnt(L * 4);
-            h2d(dE.p, Eg.data(), L * 72);
-            h2d(dtau.p, tau2.data(), L * 8);
-            Engine::check(pgi_score_pose_batch(engine->get(), &b, dE.as<double>(), dtau.as<double>(), dcnt.as<uint32_t>(), nullptr));
-            Engine::check(pgi_synchronize(engine->get()));
-            guessInliers.resize(L);
-            d2h(guessInliers.data(), dcnt.p, L * 4);
-            for (size_t k = 0; k < L; ++k)
-                if (has[k] && guessInliers[k] < 5) has[k] = 0;
-            h2d(db + o_has, has, L);  // the screened flags replace the uploaded ones
+            convertSeconds += std::chrono::duration<double>(Clock::now() - tc).count();
+            HIP_OK(hipEventRecord(staging->up[slot], copy));
+            HIP_OK(hipStreamWaitEvent(nullptr, staging->up[slot], 0));
+            // Kernels are launched per GROUP of uploaded chunks -- 1, 2, then 4 chunks: a launch pays a fixed wind-down while its
+            // last workgroups finish (0.9 ms, DESIGN.md section 7 "The drain"), so the first launch comes early and the later
+            // ones are large.
+            groupMaxCorr = std::max(groupMaxCorr, ch.maxCorr);
+            ++groupChunks;
+            if (groupChunks < groupTarget && c + 1 < chunks.size()) continue;
+            const size_t g0 = groupK0, g1 = ch.k1, n = g1 - g0;
+            pgi_batch b{};
+            b.d_x1 = dcol[0]; b.d_y1 = dcol[1]; b.d_x2 = dcol[2]; b.d_y2 = dcol[3];  // offsets are absolute rows of the block
+            b.d_offsets = (const uint64_t*)(db + o_off) + g0; b.d_thr = (const double*)(db + o_thr) + g0;
+            b.n_pairs = (uint32_t)n; b.max_corr = groupMaxCorr; b.pair_id_base = lo + g0; b.seed = seed;  // ids = positions in `pairs`
+            if (screen) {
+                Engine::check(pgi_score_pose_batch(engine->get(), &b, (const double*)(db + o_Eg) + 9 * g0, (const double*)(db + o_tau) + g0,
+                                                   (uint32_t*)(db + o_cnt) + g0, nullptr));
+                Engine::check(pgi_screen_guesses(engine->get(), (const uint32_t*)(db + o_cnt) + g0, 5, (uint8_t*)(db + o_has) + g0, (uint32_t)n));
+            }
+            if (any_guess) {
+                b.d_guess_Rt = (const double*)(db + o_guess) + 12 * g0;
+                b.d_has_guess = (const uint8_t*)(db + o_has) + g0;
+            }
+            Engine::check(pgi_estimate_pose_batch(engine->get(), &b, d_all + lo + g0, (uint8_t*)(db + o_masks)));
+            groupK0 = g1;
+            groupChunks = 0;
+            groupMaxCorr = 0;
+            groupTarget = std::min<size_t>(groupTarget * 2, 4);
         }
-        if (any_guess) {
-            b.d_guess_Rt = (const double*)(db + o_guess); b.d_has_guess = (const uint8_t*)(db + o_has);
-        }
-        Engine::check(pgi_estimate_pose_batch(engine->get(), &b, d_all + lo, (uint8_t*)(db + o_masks)));
-        Engine::check(pgi_synchronize(engine->get()));  // the batch buffers die with this scope
-        mark("guess screening + estimation kernels");
+        mark("convert + upload + launch (chunks)");
+        statistics.addTime("[Pose estimation] of which row conversion (host team)", convertSeconds, 1);
     }
     // the path's one exchange step (no-op copy in a single process)
     std::vector<uint32_t> counts(world);
     for (uint32_t r = 0; r < world; ++r) counts[r] = (uint32_t)(blocks[r].second - blocks[r].first);
+    Engine::check(pgi_synchronize(engine->get()));
+    mark("wait for the kernels");
     Engine::check(pgi_allgather_edges(engine->get(), d_all + lo, counts.data(), d_all));
     Engine::check(pgi_synchronize(engine->get()));
+    mark("all-gather of the edge records");
     std::vector<pgi_edge> edges(P);
     d2h(edges.data(), d_all, P * sizeof(pgi_edge));
-    mark("free, gather, download");
+    if (screen) {
+        guessInliers.resize(L);
+        d2h(guessInliers.data(), db + o_cnt, L * 4);
+    }
+    mark("download");
+    poseGraph_.reserveEdges(P);
     size_t added = 0, inliers = 0;
     for (size_t i = 0; i < P; ++i) {
         inliers += edges[i].n_inl;
@@ -304,9 +502,11 @@ PoseGraphBuilder::GlobalRotations PoseGraphBuilder::estimateAndAverage(const std
         rows[i] = (uint32_t)pairs[i].correspondences.rows;
     }
     static_assert(sizeof(Matrix3d) == 72, "Matrix3d must be 9 packed doubles");
+    const std::chrono::steady_clock::time_point t_avg = std::chrono::steady_clock::now();
     Engine::check(pgi_rotation_average_edges(engine->get(), table.as<pgi_edge>(), src.data(), dst.data(), rows.data(), (uint32_t)P,
                                              (uint32_t)numViews, rotavgParams, out.rotations[0].data(), &out.iterations,
                                              &out.edgesUsed));
+    statistics.addTime("[Rotation averaging]", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_avg).count(), 1);
     return out;
 }
 
@@ -332,14 +532,20 @@ PoseGraphBuilder::GlobalRotations PoseGraphBuilder::averageRotations(const PoseG
 }
 
 PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& cand, PoseGraph& poseGraph_, size_t waveSize,
-                                                      const SimilarityTable* similarityTable) {
+                                                      const SimilarityTable* similarityTable, uint64_t seedBase) {
     RunStatistics st;
     typedef std::chrono::steady_clock Clock;
-    // descending similarity, ties by (src,dst): the order the reference pops its heap
-    std::stable_sort(cand.begin(), cand.end(), [](const ViewPair& a, const ViewPair& b) {
+    // descending similarity, ties by (src,dst): the order the reference pops its heap.  An index order is sorted, not the
+    // candidate records themselves (10^5 records with their matrices' headers: a stable sort moved each a dozen times).
+    const Clock::time_point tSort = Clock::now();
+    std::vector<uint32_t> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&cand](uint32_t ia, uint32_t ib) {
+        const ViewPair &a = cand[ia], &b = cand[ib];
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
         return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);
     });
+    statistics.addTime("[Scheduler] candidate order", std::chrono::duration<double>(Clock::now() - tSort).count(), 1);
     ViewId maxId = 0;
     for (const ViewPair& vp : cand) maxId = std::max(maxId, std::max(vp.src, vp.dst));
     VisibilityTable visibilityTable(maxId + 1);  // :366-367
@@ -347,7 +553,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
     const uint32_t world = worldSize(), rank = worldRank();
     std::vector<ViewPair> wave;
-    uint64_t seed = 0;
+    uint64_t seed = seedBase;
     auto flush = [&]() {
         if (wave.empty()) return;
         if (pathFinding) {  // findPath (:785-862) on the graph committed by the previous waves
@@ -360,18 +566,28 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
             AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0,
                                                                 kMaximumSearchDepth);
             struct Tally { uint64_t searched = 0, touched = 0, found = 0; } tally;
-            for (size_t i = 0; i < wave.size(); ++i) {
+            // the graph does not change until this wave commits: the searches of the wave are independent and run on
+            // kCoreNumber threads, lock-free (PoseGraph::forEachEdgeOfFrozen); per-pair tallies are summed in pair order
+            traversal.setGraphFrozen(true);
+            std::vector<uint32_t> touchedOf(wave.size(), 0), foundOf(wave.size(), 0);
+            std::vector<uint8_t> searchedOf(wave.size(), 0);
+            for (size_t i = 0; i < wave.size(); ++i) wave[i].poseGuesses.clear();
+            parallelFor(mine.second - mine.first, kCoreNumber ? kCoreNumber : 1, [&](size_t k) {
+                const size_t i = mine.first + k;
                 ViewPair& vp = wave[i];
-                vp.poseGuesses.clear();
-                if (i < mine.first || i >= mine.second) continue;
-                if (!visibilityTable.hasLink(vp.src, vp.dst)) continue;  // kAreViewsVisible (:456-457, 568)
+                if (!visibilityTable.hasLink(vp.src, vp.dst)) return;  // kAreViewsVisible (:456-457, 568)
                 std::vector<ViewId> path;
                 size_t touched = 0, found = 0;
                 bool exists = false;
                 traversal.getPath(vp.src, vp.dst, path, vp.poseGuesses, touched, found, exists);
-                ++tally.searched;
-                tally.touched += touched;
-                tally.found += found;
+                searchedOf[i] = 1;
+                touchedOf[i] = (uint32_t)touched;
+                foundOf[i] = (uint32_t)found;
+            });
+            for (size_t i = mine.first; i < mine.second; ++i) {
+                tally.searched += searchedOf[i];
+                tally.touched += touchedOf[i];
+                tally.found += foundOf[i];
             }
             if (world > 1) {  // the searches' tallies of all ranks (host-side bookkeeping, 24 bytes per rank)
                 const std::vector<Tally> all = hostComm->allgather(tally);
@@ -404,7 +620,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         wave.clear();
     };
     for (size_t i = 0; i < cand.size(); ++i) {
-        ViewPair& vp = cand[i];
+        ViewPair& vp = cand[order[i]];
         if (vp.similarity < kSimilarityThreshold) break;                       // heap holds sim >= threshold only
         if (poseGraph_.hasEdge(vp.src, vp.dst) || poseGraph_.hasEdge(vp.dst, vp.src)) continue;   // :426-431
         if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
@@ -414,6 +630,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         if (wave.size() == waveSize) flush();
     }
     flush();
+    warnQuirkOnlyGuesses(st.quirkOnlyGuesses, st.posesFromGuess);
     return st;
 }
 
@@ -461,6 +678,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                                                                           const SimilarityTable* similarityTable,
                                                                           const MatchLookup* cachedMatches) {
     FeatureRunStatistics st;
+    const size_t quirkOnlyAtStart = statistics.getCount("[Pose estimation] Quirk-only guesses");
     pgi_ctx* ctx = engine->get();
     // features resident in HBM for the whole run: keypoints, row-major descriptors (guided matching) and the
     // transposed copy + norms (brute-force matching)
@@ -473,11 +691,17 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
     std::vector<ViewLayout> lay(V);
     size_t arenaBytes = 0;
     auto take = [&](size_t bytes) { const size_t o = arenaBytes; arenaBytes += (bytes + 255) & ~(size_t)255; return o; };
+    // the raw part -- what the caller hands over: keypoints and descriptors of every view -- comes first and is contiguous,
+    // so that a run of views travels as ONE copy; the arrays derived on the device follow
     for (size_t v = 0; v < V; ++v) {
-        const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
+        const uint32_t n = (uint32_t)views[v].size();
         if (n && (!views[v].keypoints || !views[v].descriptors)) throw PgiError("processFeatures: null feature arrays");
         lay[v].xy = take((size_t)n * 8);
         lay[v].desc = take((size_t)n * PGI_DESC_DIM * 4);
+    }
+    const size_t rawBytes = arenaBytes;
+    for (size_t v = 0; v < V; ++v) {
+        const uint32_t n_pad = pgi_desc_padded((uint32_t)views[v].size());
         lay[v].dt = take((size_t)n_pad * PGI_DESC_DIM * 4);
         lay[v].norm = take((size_t)n_pad * 4);
         lay[v].rm = take((size_t)n_pad * PGI_DESC_DIM * 4);
@@ -491,20 +715,87 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count());
     for (size_t v = 0; v < V; ++v) {
         const uint32_t n = (uint32_t)views[v].size(), n_pad = pgi_desc_padded(n);
+        const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
         float* xy = reinterpret_cast<float*>(ab + lay[v].xy);
         float* desc = reinterpret_cast<float*>(ab + lay[v].desc);
         float* dt = reinterpret_cast<float*>(ab + lay[v].dt);
         float* norm = reinterpret_cast<float*>(ab + lay[v].norm);
         float* rm = reinterpret_cast<float*>(ab + lay[v].rm);
         uint16_t* f16 = reinterpret_cast<uint16_t*>(ab + lay[v].f16);
-        h2d(xy, views[v].keypoints, (size_t)n * 8);
-        h2d(desc, views[v].descriptors, (size_t)n * PGI_DESC_DIM * 4);
-        Engine::check(pgi_desc_prepare(ctx, desc, n, dt, norm));
-        Engine::check(pgi_desc_prepare_screen(ctx, desc, n, rm, f16));
-        const double f = views[v].focalLength, cx = views[v].width / 2.0, cy = views[v].height / 2.0;
         descView[v] = pgi_desc_view{dt, norm, n, n_pad, rm, f16};
         kpView[v] = pgi_keypoint_view{xy, n, 0, f, f, cx, cy};
         featView[v] = pgi_feature_view{xy, desc, n, 0, f, f, cx, cy, views[v].width, views[v].height};
+    }
+    {   // Upload (round 4).  The caller's arrays are pageable (cv::Mat / std::vector / numpy), and hipMemcpy's pageable path is
+        // erratic: the same 1.39 GB took 0.043 s on one box and 0.32-0.36 s on another.  The features now go
+        // through the builder's own page-locked ring: the host team copies a run of views (~64 MB) into a ring buffer, the
+        // buffer travels as one asynchronous copy on the copy stream, the per-view preparation kernels of the run wait for
+        // it on the engine's stream -- while the team already fills the next buffer.  A view whose arrays are page-locked
+        // already (hipHostMalloc / hipHostRegister / pgi_host_register) is copied from where it lies.
+        if (!staging) staging = Staging::shared();
+        std::lock_guard<std::mutex> stagingBusy(staging->busy);
+        staging->init(kCoreNumber ? kCoreNumber : 1);
+        auto pageLocked = [](const void* p) {
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+            return at.type == hipMemoryTypeHost;
+        };
+        const size_t runBytes = (size_t)64 << 20;
+        size_t largestRun = 0;
+        struct Run { size_t v0, v1; };
+        std::vector<Run> runs;
+        for (size_t v = 0; v < V;) {
+            size_t v1 = v;
+            const size_t begin = lay[v].xy;
+            auto endOf = [&](size_t w) { return w + 1 < V ? lay[w + 1].xy : rawBytes; };
+            while (v1 < V && (v1 == v || endOf(v1) - begin <= runBytes)) ++v1;
+            runs.push_back(Run{v, v1});
+            largestRun = std::max(largestRun, endOf(v1 - 1) - begin);
+            v = v1;
+        }
+        staging->reserve(0, largestRun, 0);
+        hipStream_t copy = staging->copy;
+        for (size_t r = 0; r < runs.size(); ++r) {
+            const Run& run = runs[r];
+            const int slot = (int)(r % Staging::kRing);
+            if (r >= (size_t)Staging::kRing) HIP_OK(hipEventSynchronize(staging->up[slot]));
+            char* const hb = (char*)staging->ring[slot];
+            const size_t begin = lay[run.v0].xy, end = run.v1 < V ? lay[run.v1].xy : rawBytes;
+            // pieces of at most 1 MB, so that the team shares a run evenly whatever the views' sizes
+            struct Piece { const char* src; size_t dstOff, bytes; };
+            std::vector<Piece> pieces;
+            bool direct = true;
+            for (size_t v = run.v0; v < run.v1; ++v) direct = direct && (!views[v].size() || (pageLocked(views[v].keypoints) && pageLocked(views[v].descriptors)));
+            for (size_t v = run.v0; v < run.v1 && !direct; ++v) {
+                const size_t n = views[v].size();
+                const char* src[2] = {(const char*)views[v].keypoints, (const char*)views[v].descriptors};
+                const size_t bytes[2] = {n * 8, n * (size_t)PGI_DESC_DIM * 4}, dst[2] = {lay[v].xy - begin, lay[v].desc - begin};
+                for (int a = 0; a < 2; ++a)
+                    for (size_t o = 0; o < bytes[a]; o += (size_t)1 << 20)
+                        pieces.push_back(Piece{src[a] + o, dst[a] + o, std::min<size_t>((size_t)1 << 20, bytes[a] - o)});
+            }
+            if (direct) {
+                for (size_t v = run.v0; v < run.v1; ++v) {
+                    const size_t n = views[v].size();
+                    if (!n) continue;
+                    HIP_OK(hipMemcpyAsync(ab + lay[v].xy, views[v].keypoints, n * 8, hipMemcpyHostToDevice, copy));
+                    HIP_OK(hipMemcpyAsync(ab + lay[v].desc, views[v].descriptors, n * (size_t)PGI_DESC_DIM * 4, hipMemcpyHostToDevice, copy));
+                }
+            } else {
+                staging->pool->run(pieces.size(), [&](size_t i) { memcpy(hb + pieces[i].dstOff, pieces[i].src, pieces[i].bytes); });
+                if (end > begin) HIP_OK(hipMemcpyAsync(ab + begin, hb, end - begin, hipMemcpyHostToDevice, copy));
+            }
+            HIP_OK(hipEventRecord(staging->up[slot], copy));
+            HIP_OK(hipStreamWaitEvent(nullptr, staging->up[slot], 0));  // the engine works on the default stream
+            for (size_t v = run.v0; v < run.v1; ++v) {
+                const uint32_t n = (uint32_t)views[v].size();
+                Engine::check(pgi_desc_prepare(ctx, featView[v].d_desc, n, const_cast<float*>(descView[v].d_desc_t), const_cast<float*>(descView[v].d_norm)));
+                Engine::check(pgi_desc_prepare_screen(ctx, featView[v].d_desc, n, const_cast<float*>(descView[v].d_desc_rm),
+                                                      const_cast<uint16_t*>(descView[v].d_desc_f16)));
+            }
+        }
+        Engine::check(pgi_synchronize(ctx));
+        HIP_OK(hipStreamSynchronize(copy));
     }
     Engine::check(pgi_synchronize(ctx));
     st.secUpload = std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count();
@@ -565,17 +856,19 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         sw.found.assign(n, 0);
         ImageSimilarityHeuristics heuristics(*similarityTable);
         AStarTraversal<ImageSimilarityHeuristics> traversal(&poseGraph_, heuristics, kTraversalHeuristicsWeight, 0.0, kMaximumSearchDepth);
-        for (size_t i = 0; i < n; ++i) {
-            if (!visibilityTable.hasLink(sw.wave[i].src, sw.wave[i].dst)) continue;
+        traversal.setGraphFrozen(true);  // (commits happen between searchWave calls, never during one)
+        // small waves stay on the calling thread: starting threads costs more than a few hundred short searches
+        parallelFor(n, n >= 2048 ? (kCoreNumber ? kCoreNumber : 1) : 1, [&](size_t i) {
+            if (!visibilityTable.hasLink(sw.wave[i].src, sw.wave[i].dst)) return;
             std::vector<ViewId> path;
             std::vector<SE3d> poses;
             bool exists = false;
             traversal.getPath(sw.wave[i].src, sw.wave[i].dst, path, poses, sw.touched[i], sw.found[i], exists);
-            if (poses.empty()) continue;
+            if (poses.empty()) return;
             for (int c = 0; c < 9; ++c) sw.pose[12 * i + c] = poses.back().R[c];
             for (int c = 0; c < 3; ++c) sw.pose[12 * i + 9 + c] = poses.back().t[c];
             sw.found_pose[i] = 1;
-        }
+        });
         sw.searched = true;
         sw.seconds = since(t0);
     };
@@ -967,6 +1260,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         processWave(current, next);
         current = std::move(next);
     }
+    warnQuirkOnlyGuesses(statistics.getCount("[Pose estimation] Quirk-only guesses") - quirkOnlyAtStart, st.posesFromGuess);
     st.trackNumber = tracks.trackNumber();
     if (deviceTracks) {
         uint64_t n = 0;
@@ -977,30 +1271,14 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
 }
 
 namespace pose {
+// pose_utils.h:172-252 -- one re-entrant call on host pointers (pgi_pose_from_essential_host: private slot of the context,
+// no allocation once warm); every row votes, as in the reference (:203)
 int getPoseFromEssentialMatrix(Engine& eng, const Matrix3d& E, const CorrespondenceMatrix& c, Matrix3d& rotation_,
                                Vector3d& translation_) {
-    const size_t n = (size_t)c.rows;
-    std::vector<float> x1(n), y1(n), x2(n), y2(n);
-    for (size_t r = 0; r < n; ++r) {
-        const double* q = c.ptr((int)r);
-        x1[r] = (float)q[0]; y1[r] = (float)q[1]; x2[r] = (float)q[2]; y2[r] = (float)q[3];
-    }
-    DevBuf dx1(n * 4), dy1(n * 4), dx2(n * 4), dy2(n * 4), doff(16), dthr(8), dE(72), dedge(sizeof(pgi_edge));
-    const uint64_t off[2] = {0, n};
-    const double thr = 0;
-    h2d(dx1.p, x1.data(), n * 4); h2d(dy1.p, y1.data(), n * 4); h2d(dx2.p, x2.data(), n * 4); h2d(dy2.p, y2.data(), n * 4);
-    h2d(doff.p, off, 16); h2d(dthr.p, &thr, 8); h2d(dE.p, E.data(), 72);
-    pgi_batch b{};
-    b.d_x1 = dx1.as<float>(); b.d_y1 = dy1.as<float>(); b.d_x2 = dx2.as<float>(); b.d_y2 = dy2.as<float>();
-    b.d_offsets = doff.as<uint64_t>(); b.d_thr = dthr.as<double>(); b.n_pairs = 1; b.max_corr = (uint32_t)n;
-    // all rows vote, as in the reference (pose_utils.h:203)
-    Engine::check(pgi_decompose_batch(eng.get(), &b, dE.as<double>(), nullptr, dedge.as<pgi_edge>()));
-    Engine::check(pgi_synchronize(eng.get()));
-    pgi_edge e;
-    d2h(&e, dedge.p, sizeof e);
-    for (int k = 0; k < 9; ++k) rotation_[k] = e.R[k];
-    for (int k = 0; k < 3; ++k) translation_[k] = e.t[k];
-    return (int)e.votes;
+    uint32_t votes = 0;
+    Engine::check(pgi_pose_from_essential_host(eng.get(), E.data(), c.rows ? c.ptr() : nullptr, (uint32_t)c.rows, nullptr,
+                                               rotation_.data(), translation_.data(), &votes, nullptr));
+    return (int)votes;
 }
 }  // namespace pose
 

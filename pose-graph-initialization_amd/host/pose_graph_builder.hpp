@@ -27,6 +27,7 @@
 #include <shared_mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -75,10 +76,18 @@ struct CorrespondenceMatrix {  // cv::Mat N x 4 CV_64F: [x1 y1 x2 y2], normalise
     int rows = 0;
     static constexpr int cols = 4;
     std::vector<double> data;
+    const double* external = nullptr;  // rows owned by the caller (a cv::Mat header over foreign memory): see viewOf
     CorrespondenceMatrix() = default;
     explicit CorrespondenceMatrix(int n) : rows(n), data((size_t)n * 4) {}
-    double* ptr(int r = 0) { return data.data() + 4 * (size_t)r; }
-    const double* ptr(int r = 0) const { return data.data() + 4 * (size_t)r; }
+    // a header over n rows the caller keeps alive (what cv::Mat(rows, 4, CV_64F, ptr) is): nothing is copied
+    static CorrespondenceMatrix viewOf(const double* p, int n) {
+        CorrespondenceMatrix m;
+        m.rows = n;
+        m.external = p;
+        return m;
+    }
+    double* ptr(int r = 0) { return data.data() + 4 * (size_t)r; }  // owning matrices only
+    const double* ptr(int r = 0) const { return (external ? external : data.data()) + 4 * (size_t)r; }
 };
 
 namespace pose {
@@ -161,55 +170,79 @@ class PoseGraphEdge {  // include/pose_graph.h:28-60; score = inlier ratio (pose
 
 class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing ids)
    public:
+    // Storage (round 4): the edges live in ONE array in insertion order; the id -> edge and vertex -> edges relations are
+    // hash tables of indices into it.  The reference keeps three std::maps keyed by ids (pose_graph.h:214-224), which costs
+    // the A* traversal a tree descent per visited edge; at SURVEY 8d's density (10^5 edges, ~40 per view) that was the
+    // scheduler's largest host cost.  Interface and iteration orders (insertion order everywhere) are unchanged.
     size_t numVertices() const {
         std::shared_lock<std::shared_mutex> l(mu);
-        return vertices.size();
+        return vertex_count;
     }
     size_t numEdges() const {
         std::shared_lock<std::shared_mutex> l(mu);
-        return edges.size();
+        return edge_store.size();
     }
     bool addVertex(ViewId id) {
         std::unique_lock<std::shared_mutex> l(mu);
-        return vertices.emplace(id, PoseGraphVertex(id)).second;
+        if (hasVertexUnlocked(id)) return false;
+        if (id < kDenseIds) {
+            if (id >= vertex_dense.size()) vertex_dense.resize(std::max<size_t>(id + 1, 2 * vertex_dense.size()), 0);
+            vertex_dense[id] = 1;
+        } else {
+            vertex_sparse.emplace(id, PoseGraphVertex(id));
+        }
+        ++vertex_count;
+        return true;
     }
     bool hasVertex(ViewId id) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        return vertices.count(id) != 0;
+        return hasVertexUnlocked(id);
     }
     PoseGraphVertex getVertexById(ViewId id) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = vertices.find(id);
-        return it == vertices.end() ? PoseGraphVertex() : it->second;
+        return hasVertexUnlocked(id) ? PoseGraphVertex(id) : PoseGraphVertex();
     }
     bool hasEdge(ViewId s, ViewId d) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        return edges.count({s, d}) != 0;
+        return edge_index.count({s, d}) != 0;
     }
     // pose_graph.h:201-224: refused unless both vertices exist and the directed edge is new
     bool addEdge(ViewId s, ViewId d, const Pose& T, double score = 1.0) {
         std::unique_lock<std::shared_mutex> l(mu);
-        if (!vertices.count(s) || !vertices.count(d) || edges.count({s, d})) return false;
-        edges.emplace(EdgeId{s, d}, PoseGraphEdge(s, d, T, score));
-        edges_ids.push_back({s, d});
-        edges_of_vertices[s].push_back({s, d});
-        edges_of_vertices[d].push_back({s, d});
+        if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) return false;
+        const uint32_t k = (uint32_t)edge_store.size();
+        if (!edge_index.emplace(EdgeId{s, d}, k).second) return false;
+        edge_store.emplace_back(s, d, T, score);
+        neighboursForUpdate(s).push_back(Neighbour{d, score, k});
+        neighboursForUpdate(d).push_back(Neighbour{s, score, k});
         return true;
+    }
+    // room for n more edges (one rehash instead of a dozen while a wave of 10^4 edges is committed)
+    void reserveEdges(size_t n) {
+        std::unique_lock<std::shared_mutex> l(mu);
+        edge_store.reserve(edge_store.size() + n);
+        edge_index.reserve(edge_index.size() + n);
     }
     PoseGraphEdge getEdgeById(const EdgeId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = edges.find(id);
-        return it == edges.end() ? PoseGraphEdge() : it->second;
+        auto it = edge_index.find(id);
+        return it == edge_index.end() ? PoseGraphEdge() : edge_store[it->second];
     }
     std::vector<EdgeId> getEdgeIds() const {  // insertion order, like the reference's edges_ids
         std::shared_lock<std::shared_mutex> l(mu);
-        return edges_ids;
+        std::vector<EdgeId> ids(edge_store.size());
+        for (size_t k = 0; k < ids.size(); ++k) ids[k] = {edge_store[k].getSourceId(), edge_store[k].getDestinationId()};
+        return ids;
     }
     bool getEdgesByVertex(const ViewId& id, std::vector<EdgeId>& out) const {  // pose_graph.h:139-151
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = edges_of_vertices.find(id);
-        if (it == edges_of_vertices.end()) return false;
-        out = it->second;
+        const std::vector<Neighbour>* nb = neighboursOf(id);
+        if (!nb) return false;
+        out.resize(nb->size());
+        for (size_t k = 0; k < out.size(); ++k) {
+            const PoseGraphEdge& e = edge_store[(*nb)[k].edge];
+            out[k] = {e.getSourceId(), e.getDestinationId()};
+        }
         return true;
     }
     // the edges of a vertex in insertion order, by reference and under ONE shared lock (the traversal's inner loop:
@@ -217,27 +250,69 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     template <class Fn>
     bool forEachEdgeOf(const ViewId& id, Fn fn) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = edges_of_vertices.find(id);
-        if (it == edges_of_vertices.end()) return false;
-        for (const EdgeId& e : it->second) {
-            auto ed = edges.find(e);
-            if (ed != edges.end()) fn(ed->second);
-            else fn(PoseGraphEdge());  // (value semantics for missing ids, as getEdgeById)
-        }
+        return forEachEdgeOfFrozen(id, fn);
+    }
+    // The same WITHOUT the lock, for callers that know no writer runs meanwhile -- the wave scheduler searches the paths of
+    // a whole wave on kCoreNumber threads between two commits (the shared lock's counter is one cache line that twenty
+    // readers would pass around once per visited vertex).
+    template <class Fn>
+    bool forEachEdgeOfFrozen(const ViewId& id, Fn fn) const {
+        const std::vector<Neighbour>* nb = neighboursOf(id);
+        if (!nb) return false;
+        for (const Neighbour& n : *nb) fn(edge_store[n.edge]);
         return true;
+    }
+    // What the A* expansion reads of an edge -- the vertex at its other end and its score -- from a compact per-vertex
+    // array (24 bytes per entry, contiguous) instead of the 200-byte edge records scattered over the store.  No lock.
+    template <class Fn>
+    bool forEachNeighbourFrozen(const ViewId& id, Fn fn) const {
+        const std::vector<Neighbour>* nb = neighboursOf(id);
+        if (!nb) return false;
+        for (const Neighbour& n : *nb) fn(n.other, n.score);
+        return true;
+    }
+    const PoseGraphEdge* findEdgeFrozen(const EdgeId& id) const {  // (no lock: see forEachEdgeOfFrozen)
+        auto it = edge_index.find(id);
+        return it == edge_index.end() ? nullptr : &edge_store[it->second];
     }
     size_t getEdgeNumberByVertex(const ViewId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = edges_of_vertices.find(id);
-        return it == edges_of_vertices.end() ? 0 : it->second.size();
+        const std::vector<Neighbour>* nb = neighboursOf(id);
+        return nb ? nb->size() : 0;
     }
 
    protected:
+    struct EdgeIdHash {
+        size_t operator()(const EdgeId& e) const noexcept {
+            uint64_t h = (uint64_t)e.first * 0x9E3779B97F4A7C15ull ^ ((uint64_t)e.second + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+            return (size_t)(h ^ (h >> 29));
+        }
+    };
+    struct Neighbour { ViewId other; double score; uint32_t edge; };  // edge = position in edge_store
+    // View ids are image indices (types.h:9-14): ids below 2^22 index plain arrays, anything larger falls back to hash maps.
+    static constexpr ViewId kDenseIds = (ViewId)1 << 22;
+    bool hasVertexUnlocked(ViewId id) const {
+        if (id < kDenseIds) return id < vertex_dense.size() && vertex_dense[id] != 0;
+        return vertex_sparse.count(id) != 0;
+    }
+    const std::vector<Neighbour>* neighboursOf(ViewId id) const {  // nullptr while the vertex has no edge
+        if (id < kDenseIds) return id < adjacency_dense.size() && !adjacency_dense[id].empty() ? &adjacency_dense[id] : nullptr;
+        auto it = adjacency_sparse.find(id);
+        return it == adjacency_sparse.end() ? nullptr : &it->second;
+    }
+    std::vector<Neighbour>& neighboursForUpdate(ViewId id) {
+        if (id >= kDenseIds) return adjacency_sparse[id];
+        if (id >= adjacency_dense.size()) adjacency_dense.resize(std::max<size_t>(id + 1, 2 * adjacency_dense.size()));
+        return adjacency_dense[id];
+    }
     mutable std::shared_mutex mu;
-    std::map<ViewId, PoseGraphVertex> vertices;
-    std::map<EdgeId, PoseGraphEdge> edges;
-    std::vector<EdgeId> edges_ids;
-    std::map<ViewId, std::vector<EdgeId>> edges_of_vertices;
+    size_t vertex_count = 0;
+    std::vector<uint8_t> vertex_dense;
+    std::unordered_map<ViewId, PoseGraphVertex> vertex_sparse;
+    std::vector<PoseGraphEdge> edge_store;                         // insertion order
+    std::unordered_map<EdgeId, uint32_t, EdgeIdHash> edge_index;   // (src, dst) -> position in edge_store
+    std::vector<std::vector<Neighbour>> adjacency_dense;           // per vertex, insertion order
+    std::unordered_map<ViewId, std::vector<Neighbour>> adjacency_sparse;
 };
 
 // ---- the engine handle shared by the classes below ---------------------------------------------------
@@ -434,8 +509,9 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // forms the same wave; a rank runs host A* on the committed snapshot only for the pairs of its share, estimates
     // them, the records are all-gathered and every rank commits the whole wave in wave order -- graph, visibility
     // and statistics are identical on all ranks and identical to the single-process run.
+    // seedBase: wave w draws its hypotheses with seed seedBase + w (pgi_batch.seed).
     RunStatistics run(std::vector<ViewPair>& candidatePairs, PoseGraph& poseGraph_, size_t waveSize = 4096,
-                      const class SimilarityTable* similarityTable = nullptr);
+                      const class SimilarityTable* similarityTable = nullptr, uint64_t seedBase = 0);
 
     // The outer API of the reference: void run(Reconstruction&, PoseGraph&) (pose_graph_builder.h:69-71, 173-239) on
     // the workspace named by the constructor's paths (list_with_focals.txt, similarity matrix, image_data.h5,
@@ -513,6 +589,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     uint32_t worldRank() const;
 
    protected:
+    void warnQuirkOnlyGuesses(size_t quirkOnly, size_t acceptedGuesses);
     RunningStatistics statistics;
     dist::HostComm* hostComm = nullptr;
     bool rotationGuidedGuesses = false;

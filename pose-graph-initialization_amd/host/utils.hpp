@@ -89,8 +89,8 @@ class RunningStatistics {
 // results_ gets (name without the "images/" directory, focal length, width, height) per image; totalImageNumber_ the
 // number of images listed.  Parsed strictly, which the reference does not do: a line without
 // a focal length yields focal 0 -- the reference leaves the value uninitialised there; a focal length that is not a
-// number, or a line with more than three fields, makes the whole load fail instead of slipping through atof; empty
-// lines are skipped.  A name without the "images/" prefix is kept whole (the reference cuts seven characters blindly).
+// number makes the whole load fail instead of slipping through atof; fields after the third are ignored and an empty
+// line is a record of its own (empty name, focal 0), both as in the reference, so that line index == view id holds.  A name without the "images/" prefix is kept whole (the reference cuts seven characters blindly).
 // Image sizes are not probed here (the reference reads them with cv::imread) and stay 0.
 inline bool load1DSfMImageList(const std::string& kListPath_, size_t& totalImageNumber_,
                                std::vector<std::tuple<std::string, double, double, double>>& results_) {
@@ -111,12 +111,13 @@ inline bool load1DSfMImageList(const std::string& kListPath_, size_t& totalImage
             if (p == eol) break;
             size_t q = p;
             while (q < eol && !blank(text[q])) ++q;
-            if (nfields == 3) return false;  // a fourth field: not this format
-            field[nfields++] = text.substr(p, q - p);
+            if (nfields < 3) field[nfields++] = text.substr(p, q - p);  // further fields are ignored, as in the reference (:147-160)
             p = q;
         }
         pos = eol + 1;
-        if (nfields == 0) continue;
+        // ONE RECORD PER LINE, blank lines included (utils.h:136-168 counts and pushes every line it reads): the view id of
+        // an image is its line index, and the similarity matrix's rows are numbered the same way -- dropping a blank line
+        // would shift every later view against the matrix.  A blank line yields an empty name with focal length 0.
         double focal = 0.0;
         if (nfields == 3) {
             char* end = nullptr;

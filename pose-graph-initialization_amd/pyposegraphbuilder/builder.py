@@ -57,9 +57,12 @@ class PoseGraphBuilder:
         ok, e, mask = self.engine.estimate_pose(correspondences, threshold, poseGuesses, seed=seed, pair_id=pairId)
         return ok, np.array(e.R).reshape(3, 3), np.array(e.t), mask, int(e.n_inl)
 
-    def run(self, pairs, waveSize=4096, rotationGuided=False):
+    def run(self, pairs, waveSize=4096, seed=0, *, rotationGuided=False, numViews=0):
         """pairs: iterable of dict(src, dst, similarity, correspondences[N,4], threshold).
         Returns the pose graph {(src, dst): dict(R, t, score)}; score = inliers / matches (:645-654).
+        seed: wave w of the run draws its hypotheses with seed + w.  rotationGuided (keyword only): BASELINE config 5's
+        re-estimation of chained poses, set on the C++ builder for THIS call and restored afterwards.  numViews: every
+        view id must be below it (0 = derived from the ids).
 
         This IS the C++ scheduler (host/pose_graph_builder.cpp PoseGraphBuilder::run behind pgih_run_pairs of
         libpgi_host.so, include/pgi_host.h): descending-similarity waves, and -- with kUsePathFinding -- A* pose guesses
@@ -83,17 +86,22 @@ class PoseGraphBuilder:
         n_edges = C.c_uint32(0)
         stats = np.zeros(16, np.uint64)
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
-        rc = lib.pgih_run_pairs(h, P, ptr(src), ptr(dst), ptr(sim), ptr(thr), ptr(off), ptr(corr), int(waveSize), ptr(edges),
-                                len(edges), C.byref(n_edges), ptr(stats))
+        try:
+            rc = lib.pgih_run_pairs(h, int(numViews), P, ptr(src), ptr(dst), ptr(sim), ptr(thr), ptr(off), ptr(corr), int(waveSize),
+                                    int(seed), ptr(edges), len(edges), C.byref(n_edges), ptr(stats))
+            err = lib.pgih_last_error().decode() if rc < 0 else None
+        finally:
+            if rotationGuided:  # the switch belongs to this call, not to the builder
+                lib.pgih_set_rotation_guided(h, 0)
         if rc < 0:
-            raise RuntimeError(lib.pgih_last_error().decode())
+            raise RuntimeError(err)
         self.statistics = dict(zip(("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes",
                                     "poses_from_guess", "hypotheses", "waves", "graph_edges", "quirk_only_guesses"),
                                    (int(v) for v in stats)))
         return {(int(e["src"]), int(e["dst"])): dict(R=e["R"].reshape(3, 3).copy(), t=e["t"].copy(), score=float(e["score"]))
                 for e in edges[:n_edges.value]}
 
-    def runFeatures(self, views, pairs, waveSize=512, rotationGuided=False, deviceTracklets=True):
+    def runFeatures(self, views, pairs, waveSize=512, *, rotationGuided=False, deviceTracklets=True):
         """The loop body of processImages (pose_graph_builder.h:391-709) on in-memory features -- the C++
         PoseGraphBuilder::processFeatures behind pgih_run_features (include/pgi_host.h), marshalled only.
 
@@ -153,8 +161,8 @@ class PoseGraphBuilder:
         lib.pgih_create.argtypes = [C.POINTER(_HostConfig)]
         lib.pgih_destroy.argtypes = [C.c_void_p]
         lib.pgih_set_rotation_guided.argtypes = [C.c_void_p, C.c_int]
-        lib.pgih_run_pairs.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p, C.c_uint32,
-                                                                                     C.POINTER(C.c_uint32), C.c_void_p]
+        lib.pgih_run_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32,
+                                                                                                 C.POINTER(C.c_uint32), C.c_void_p]
         lib.pgih_run_features.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                           C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         enc = lambda s_: str(s_).encode()

@@ -173,6 +173,22 @@ class Engine:
             L.check(rc)
         return rc == 1, int(cnt.value), mask
 
+    def pose_from_essential_host(self, E, corr_aos, mask=None):
+        """pose::getPoseFromEssentialMatrix (pose_utils.h:172-252) for ONE pair with host pointers, re-entrant
+        (pgi_pose_from_essential_host): -> (R[3,3], t[3], votes, cand).  mask None: every row votes (the reference)."""
+        c = np.ascontiguousarray(corr_aos, np.float64).reshape(-1, 4)
+        Ed = np.ascontiguousarray(E, np.float64).reshape(9)
+        n = len(c)
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        if m is not None and len(m) != n:
+            raise ValueError("mask must have one byte per row")
+        R, t = np.zeros(9), np.zeros(3)
+        votes, cand = C.c_uint32(0), C.c_uint32(0)
+        L.check(self._lib.pgi_pose_from_essential_host(self._ctx, Ed.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p) if n else None,
+                                                       C.c_uint32(n), m.ctypes.data_as(C.c_void_p) if m is not None and n else None,
+                                                       R.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), C.byref(votes), C.byref(cand)))
+        return R.reshape(3, 3), t, int(votes.value), int(cand.value)
+
     def decompose_batch(self, b, E, masks=None):
         P = b["n_pairs"]
         E = torch.as_tensor(np.ascontiguousarray(E, np.float64).reshape(P, 9)).to(self.device)

@@ -195,6 +195,116 @@ def make_scene_graph(n_views, k=8, seed=0, median_corr=600, min_corr=60, max_cor
     return dict(R_gt=R_gt, pairs=pairs, sizes=sizes, batch=b, wrong=wrong)
 
 
+def make_scene_graph_dense(n_views, k=40, seed=0, median_corr=600, min_corr=60, max_corr=8000, inlier_lo=0.35,
+                           inlier_hi=0.8, outlier_pair_frac=0.03, noise_px=0.25, block_pairs=4096):
+    """SURVEY 8d's configs 3/4/5 surrogate AT ITS STATED DENSITY (V = 340 / V = 5000, candidate pairs = k nearest views in
+    view direction with k ~ 40, N per pair ~ covisibility with median ~ 600 and cap 8000): the scene of make_scene_graph
+    (cameras on a jittered ring looking at the centre), generated for ~10^5 pairs / ~7 * 10^7 rows in seconds -- every
+    step is a numpy operation over a block of pairs instead of a Python loop over pairs.  One Philox stream per block of pairs
+    (not per pair: a subset of pairs is taken from the generated arrays, see take_pairs).  Same return value as
+    make_scene_graph."""
+    rng = np.random.Generator(np.random.Philox(key=SEED_BASE ^ 0xDE45E ^ (seed << 4)))
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n_views))
+    radius = rng.uniform(9.0, 11.0, n_views)
+    C = np.stack([radius * np.cos(ang), rng.uniform(-0.5, 0.5, n_views), radius * np.sin(ang)], 1)
+    zc = -C / np.linalg.norm(C, axis=1, keepdims=True)
+    jit_axis = rng.standard_normal((n_views, 3))
+    jit_axis /= np.linalg.norm(jit_axis, axis=1, keepdims=True)
+    jit_ang = np.deg2rad(rng.uniform(0, 6.0, n_views))
+    # Rodrigues on all views: z' = z cos a + (k x z) sin a + k (k . z)(1 - cos a)
+    zc = (zc * np.cos(jit_ang)[:, None] + np.cross(jit_axis, zc) * np.sin(jit_ang)[:, None]
+          + jit_axis * (np.einsum("ij,ij->i", jit_axis, zc) * (1 - np.cos(jit_ang)))[:, None])
+    xc = np.cross(np.array([0.0, 1.0, 0.0]), zc)
+    xc /= np.linalg.norm(xc, axis=1, keepdims=True)
+    yc = np.cross(zc, xc)
+    R_gt = np.stack([xc, yc, zc], 1)  # rows = camera axes in world: x_cam = R (X - C)
+    # the k nearest views in view direction: the angles are sorted, so they lie among the k ring neighbours on either side
+    kk = min(k, n_views - 1)
+    steps = np.concatenate([np.arange(-kk, 0), np.arange(1, kk + 1)])
+    nb = (np.arange(n_views)[:, None] + steps[None, :]) % n_views
+    dang = np.abs(np.angle(np.exp(1j * (ang[nb] - ang[:, None]))))
+    order = np.argsort(dang, axis=1, kind="stable")[:, :kk]
+    near = np.take_along_axis(nb, order, 1)
+    rank = np.broadcast_to(np.arange(kk)[None, :], near.shape)
+    i_all = np.repeat(np.arange(n_views), kk)
+    j_all = near.ravel()
+    keep = i_all != j_all
+    lo, hi, rk = np.minimum(i_all, j_all)[keep], np.maximum(i_all, j_all)[keep], rank.ravel()[keep]
+    key = lo.astype(np.int64) * n_views + hi
+    o = np.lexsort((rk, key))
+    key, rk = key[o], rk[o]
+    first = np.concatenate([[True], key[1:] != key[:-1]])  # a pair listed from both ends keeps its smaller rank
+    key, rk = key[first], rk[first]
+    pairs = np.stack([key // n_views, key % n_views], 1).astype(np.int64)
+    E = len(pairs)
+    # rows per pair ~ covisibility: closer views share more of the scene
+    cov = 1.4 - 0.8 * rk / max(kk - 1, 1)
+    sizes = np.clip(rng.lognormal(np.log(median_corr), 0.6, E) * cov, min_corr, max_corr).astype(np.int64)
+    wrong = rng.random(E) < outlier_pair_frac
+    rho = np.where(wrong, 0.0, rng.uniform(inlier_lo, inlier_hi, E))
+    Ri, Rj = R_gt[pairs[:, 0]], R_gt[pairs[:, 1]]
+    Rij = np.einsum("eij,ekj->eik", Rj, Ri)
+    tij = np.einsum("eij,ej->ei", Rj, C[pairs[:, 0]] - C[pairs[:, 1]])
+    tij /= np.linalg.norm(tij, axis=1, keepdims=True)
+    off = np.zeros(E + 1, np.uint64)
+    off[1:] = np.cumsum(sizes)
+    tot = int(off[-1])
+    b = dict(x1=np.empty(tot, np.float32), y1=np.empty(tot, np.float32), x2=np.empty(tot, np.float32),
+             y2=np.empty(tot, np.float32), inlier=np.empty(tot, bool), offsets=off, R=Rij, t=tij)
+    def block(e0):  # one Philox stream per block of pairs: the blocks are independent and run on a few threads
+        rb = np.random.Generator(np.random.Philox(key=SEED_BASE ^ 0xB10C ^ (seed << 4) ^ (e0 << 24)))
+        e1 = min(E, e0 + block_pairs)
+        a, z_ = int(off[e0]), int(off[e1])
+        n = z_ - a
+        pe = np.repeat(np.arange(e0, e1), sizes[e0:e1])
+        inl = rb.random(n) < rho[pe]
+        c = np.empty((n, 4))
+        out_rows = np.nonzero(~inl)[0]
+        c[out_rows, :2] = rb.uniform(-0.45, 0.45, (len(out_rows), 2))
+        c[out_rows, 2:] = rb.uniform(-0.5, 0.5, (len(out_rows), 2))
+        pend = np.nonzero(inl)[0]       # inlier rows still without a point that both views see
+        lim = np.full(len(pend), 0.5)
+        tries = 0
+        while len(pend):
+            m = len(pend)
+            zz = rb.uniform(2.0, 8.0, m)
+            X = np.stack([rb.uniform(-0.45, 0.45, m) * zz, rb.uniform(-0.45, 0.45, m) * zz, zz], 1)
+            pp = pe[pend]
+            Y = np.einsum("mij,mj->mi", Rij[pp], X) + tij[pp]
+            ok = Y[:, 2] > 0.5
+            q = Y[:, :2] / np.where(ok, Y[:, 2], 1.0)[:, None]
+            ok &= (np.abs(q) < lim[:, None]).all(1)
+            done = pend[ok]
+            c[done, :2] = X[ok, :2] / X[ok, 2:3]
+            c[done, 2:] = q[ok]
+            pend, lim = pend[~ok], lim[~ok]
+            tries += 1
+            if tries % 8 == 0:
+                lim = lim * 1.5  # barely overlapping views: widen the destination field of view
+        c += rb.standard_normal((n, 4)) * (noise_px / FOCAL_PX)
+        c = c.astype(np.float32)
+        b["x1"][a:z_], b["y1"][a:z_], b["x2"][a:z_], b["y2"][a:z_] = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+        b["inlier"][a:z_] = inl
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        list(ex.map(block, range(0, E, block_pairs)))
+    return dict(R_gt=R_gt, pairs=pairs, sizes=sizes, batch=b, wrong=wrong)
+
+
+def take_pairs(g, idx):
+    """The pairs `idx` of a scene graph as a make_batch-like SoA (a sample for a parity check against the oracle)."""
+    b = g["batch"]
+    idx = np.asarray(idx, np.int64)
+    n = np.diff(b["offsets"].astype(np.int64))[idx]
+    off = np.zeros(len(idx) + 1, np.uint64)
+    off[1:] = np.cumsum(n)
+    rows = np.concatenate([np.arange(int(b["offsets"][e]), int(b["offsets"][e + 1])) for e in idx]) if len(idx) else np.zeros(0, np.int64)
+    out = {k_: b[k_][rows] for k_ in ("x1", "y1", "x2", "y2", "inlier")}
+    out.update(offsets=off, R=b["R"][idx], t=b["t"][idx])
+    return out
+
+
 def make_descriptors(rng, n_a, n_b, overlap=0.6, noise=0.05, dim=128, duplicates=0):
     """Two RootSIFT-like descriptor sets (non-negative, unit L2 norm): `overlap` of A re-appears in B, perturbed and
     permuted; `duplicates` rows of B are exact copies of other rows (distance ties)."""

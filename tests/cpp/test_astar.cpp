@@ -176,6 +176,15 @@ int main(int argc, char** argv) {
     }
     ImageSimilarityHeuristics h(sim);
     AStarTraversal<ImageSimilarityHeuristics> astar(&g, h, weight, 0.0, depth);
+    // the same searches over a SPARSE table holding the same values and without the graph's lock (what the wave scheduler
+    // runs on kCoreNumber threads): paths, poses and touched-node counts must be identical
+    SimilarityTable sparse(SimilarityTable::Sparse(), V, 0.0);
+    for (uint32_t i = 0; i < V; ++i)
+        for (uint32_t j = i + 1; j < V; ++j)
+            if (sim.getSimilarity(i, j) != 0.0) sparse.setSimilarity(i, j, sim.getSimilarity(i, j));
+    ImageSimilarityHeuristics hs(sparse);
+    AStarTraversal<ImageSimilarityHeuristics> frozen(&g, hs, weight, 0.0, depth);
+    frozen.setGraphFrozen(true);
     std::ofstream out(argv[2], std::ios::binary);
     for (uint32_t q = 0; q < Q; ++q) {
         uint32_t a, b;
@@ -185,6 +194,18 @@ int main(int argc, char** argv) {
         size_t touched = 0, found = 0;
         bool exists = false;
         astar.getPath(a, b, path, poses, touched, found, exists);
+        {
+            std::vector<ViewId> path2;
+            std::vector<SE3d> poses2;
+            size_t touched2 = 0, found2 = 0;
+            bool exists2 = false;
+            frozen.getPath(a, b, path2, poses2, touched2, found2, exists2);
+            if (path2 != path || touched2 != touched || found2 != found || exists2 != exists || poses2.size() != poses.size() ||
+                (!poses.empty() && (poses2[0].R != poses[0].R || poses2[0].t != poses[0].t))) {
+                std::fprintf(stderr, "query %u: the lock-free search over the sparse table differs\n", q);
+                return 4;
+            }
+        }
         const uint32_t n = exists ? (uint32_t)path.size() : 0, t = (uint32_t)touched;
         out.write((const char*)&n, 4);
         out.write((const char*)&t, 4);

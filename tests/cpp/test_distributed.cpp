@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <memory>
 
 #include "distributed.hpp"
 #include "graph_traversal.hpp"
@@ -27,28 +28,49 @@ int main(int argc, char** argv) {
         dist::HostComm comm(env);
         dist::selectDevice(env);
         std::ifstream in(argv[1], std::ios::binary);
-        uint32_t V, P, wave, simKind;  // simKind 0: none, 1: dense V x V doubles, 2: only the candidate pairs' values (others 0)
+        // simKind (low byte) 0: no table, 1: dense V x V doubles follow, 2: only the candidate pairs' values (0 elsewhere: a
+        // sparse table).  Bit 8 set: BULK layout (pyposegraphbuilder/scenes.py write_scene_bulk) -- per-pair arrays first, then
+        // every row as four f32; the rows are widened to the reference's N x 4 CV_64F matrices here, before any timed region
+        uint32_t V, P, wave, simKind;
         in.read((char*)&V, 4); in.read((char*)&P, 4); in.read((char*)&wave, 4); in.read((char*)&simKind, 4);
-        SimilarityTable sim(simKind ? V : 1, 0.0, false);
+        const bool bulk = (simKind & 0x100u) != 0;
+        simKind &= 0xFFu;
+        std::unique_ptr<SimilarityTable> simOwner(simKind == 2 ? new SimilarityTable(SimilarityTable::Sparse(), V, 0.0)
+                                                               : new SimilarityTable(simKind ? V : 1, 0.0, false));
+        SimilarityTable& sim = *simOwner;
         if (simKind == 1) {
             std::vector<double> row(V);
             for (uint32_t i = 0; i < V; ++i) {
                 in.read((char*)row.data(), (size_t)V * 8);
                 for (uint32_t j = i + 1; j < V; ++j) sim.setSimilarity(i, j, row[j]);
             }
-        } else if (simKind == 2) {
-            for (uint32_t i = 0; i < V; ++i)
-                for (uint32_t j = i + 1; j < V; ++j) sim.setSimilarity(i, j, 0.0);
         }
         std::vector<PoseGraphBuilder::ViewPair> pairs(P);
-        for (uint32_t i = 0; i < P; ++i) {
-            uint32_t s, d, n;
-            double thr, simv;
-            in.read((char*)&s, 4); in.read((char*)&d, 4); in.read((char*)&n, 4); in.read((char*)&thr, 8); in.read((char*)&simv, 8);
-            pairs[i].src = s; pairs[i].dst = d; pairs[i].similarity = simv; pairs[i].normalizedThreshold = thr;
-            pairs[i].correspondences = CorrespondenceMatrix((int)n);
-            in.read((char*)pairs[i].correspondences.ptr(), (size_t)n * 32);
-            if (simKind == 2) sim.setSimilarity(s, d, simv);
+        if (bulk) {
+            std::vector<uint32_t> s(P), d(P), n(P);
+            std::vector<double> thr(P), simv(P);
+            in.read((char*)s.data(), (size_t)P * 4); in.read((char*)d.data(), (size_t)P * 4); in.read((char*)n.data(), (size_t)P * 4);
+            in.read((char*)thr.data(), (size_t)P * 8); in.read((char*)simv.data(), (size_t)P * 8);
+            std::vector<float> rows;
+            for (uint32_t i = 0; i < P; ++i) {
+                pairs[i].src = s[i]; pairs[i].dst = d[i]; pairs[i].similarity = simv[i]; pairs[i].normalizedThreshold = thr[i];
+                pairs[i].correspondences = CorrespondenceMatrix((int)n[i]);
+                rows.resize((size_t)n[i] * 4);
+                in.read((char*)rows.data(), (size_t)n[i] * 16);
+                double* q = pairs[i].correspondences.ptr();
+                for (size_t k = 0; k < rows.size(); ++k) q[k] = (double)rows[k];
+                if (simKind == 2) sim.setSimilarity(s[i], d[i], simv[i]);
+            }
+        } else {
+            for (uint32_t i = 0; i < P; ++i) {
+                uint32_t s, d, n;
+                double thr, simv;
+                in.read((char*)&s, 4); in.read((char*)&d, 4); in.read((char*)&n, 4); in.read((char*)&thr, 8); in.read((char*)&simv, 8);
+                pairs[i].src = s; pairs[i].dst = d; pairs[i].similarity = simv; pairs[i].normalizedThreshold = thr;
+                pairs[i].correspondences = CorrespondenceMatrix((int)n);
+                in.read((char*)pairs[i].correspondences.ptr(), (size_t)n * 32);
+                if (simKind == 2) sim.setSimilarity(s, d, simv);
+            }
         }
         if (!in) return 3;
         const bool waves = mode == "waves" || mode == "waves_guided";
@@ -101,6 +123,12 @@ int main(int argc, char** argv) {
                     env.world, env.world == 1 ? "none" : tr == dist::Transport::Rccl ? "rccl" : "host", mode.c_str(), graph.numEdges(),
                     rot.iterations, mode == "shard" ? "estimate + gather + average" : "scheduler run (A*, estimate, gather, commit)", sec_graph,
                     sec_average);
+        // the run's stage clocks (RunningStatistics: the reference's keys plus the phases of estimatePoses), rank 0
+        if (env.rank == 0) {
+            std::printf("stages:");
+            for (const auto& kv : builder.getStatistics().getTimes()) std::printf(" %s=%.4f;", kv.first.c_str(), kv.second.first);
+            std::printf("\n");
+        }
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "test_distributed: %s\n", e.what());

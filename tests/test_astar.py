@@ -155,10 +155,13 @@ def test_text_loaders_parse_strictly(tmp_path):
     out = run(asym, good_list)
     assert out[0] == "load 1" and out[1] == "pairs 4 views 3"
     assert out[2:6] == ["0.900 1 2", "0.600 1 0", "0.500 0 1", "0.300 0 2"]
-    # image list: names without the directory prefix are kept whole, blank lines skipped, bad focal / extra fields refused
-    out = run(sym, "images/a.jpg 0 500\n\nplain.png 1 640.5\r\nimages/nofocal.jpg\n")
+    # image list: names without the directory prefix are kept whole; ONE record per line -- a blank line is an image of its
+    # own (empty name, focal 0), because line index == view id == row of the similarity matrix (reference utils.h:136-168
+    # counts and pushes every line); fields after the third are ignored like the reference does; a bad focal is refused
+    out = run(sym, "images/a.jpg 0 500\n\nplain.png 1 640.5\r\nimages/nofocal.jpg\nimages/e.jpg 0 700 extra\n")
     i = out.index("list 1")
-    assert out[i + 1] == "total 3" and out[i + 2:i + 5] == ["a.jpg 500.0000", "plain.png 640.5000", "nofocal.jpg 0.0000"]
-    for bad in ("images/a.jpg 0 12abc\n", "images/a.jpg 0 500 extra\n", "images/a.jpg 0 -3\n"):
+    assert out[i + 1] == "total 5"
+    assert out[i + 2:i + 7] == ["a.jpg 500.0000", " 0.0000", "plain.png 640.5000", "nofocal.jpg 0.0000", "e.jpg 700.0000"]
+    for bad in ("images/a.jpg 0 12abc\n", "images/a.jpg 0 -3\n"):
         out = run(sym, bad)
         assert "list 0" in out, bad

@@ -215,3 +215,57 @@ def test_gpu_decompose_batch_against_the_literal_rule(eng, k):
     else:
         assert abs(same_t_all / n - TABLE_RHO03_ALL_ROWS) < 0.01
         assert abs(same_t / n - TABLE_RHO03_INLIER_ROWS_T) < 0.01
+
+
+@pytest.mark.gpu
+def test_pose_from_essential_host_seam_from_twenty_threads(eng):
+    """pgi_pose_from_essential_host -- the seam pose::getPoseFromEssentialMatrix (pose_utils.h:172-252) sits behind -- called
+    like the reference would call it: host pointers (E, the N x 4 CV_64F matrix), 20 threads x 200 calls on one context.
+    Every answer equals pgi_decompose_batch on the same rows (all rows voting, and the inlier rows through h_mask) bit for
+    bit, and the literal restatement pgo_ref_pose_from_essential (null vector oriented w >= 0): the same rotation on every
+    pair, the same translation at inlier ratio >= 0.5."""
+    import threading
+    sizes = [120, 257, 600, 64, 2000, 333, 5, 1024]
+    b = S.make_batch(range(9100, 9100 + len(sizes)), sizes, inlier_ratio=0.6)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=3, pair_id_base=9100)
+    edges, masks = eng.estimate_pose_batch(db)
+    est = eng.edges_to_numpy(edges)
+    hm = masks.cpu().numpy()
+    dec_in = eng.edges_to_numpy(eng.decompose_batch(db, est["E"], masks))
+    dec_all = eng.edges_to_numpy(eng.decompose_batch(db, est["E"], None))
+    cases = []
+    for p in range(len(sizes)):
+        a, z = int(b["offsets"][p]), int(b["offsets"][p + 1])
+        corr = np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1).astype(np.float64)
+        lit = O.ref_pose_from_essential(est["E"][p], corr) if est["status"][p] == 1 else None
+        cases.append((corr, est["E"][p], hm[a:z].copy(), dec_all[p], dec_in[p], lit, est["status"][p] == 1))
+    errors = []
+
+    def worker(tid):
+        r = np.random.default_rng(500 + tid)
+        try:
+            for _ in range(200):
+                corr, E, m, d_all, d_in, lit, ok = cases[int(r.integers(len(cases)))]
+                if r.random() < 0.5:
+                    R, t, votes, cand = eng.pose_from_essential_host(E, corr)
+                    exp = d_all
+                else:
+                    R, t, votes, cand = eng.pose_from_essential_host(E, corr, mask=m)
+                    exp = d_in
+                if not (np.array_equal(R.ravel(), exp["R"], equal_nan=True) and np.array_equal(t, exp["t"], equal_nan=True) and votes == exp["votes"] and cand == exp["cand"]):
+                    errors.append((tid, len(corr), votes, int(exp["votes"]), cand, int(exp["cand"])))
+                if ok and lit is not None and exp is d_all:
+                    if np.abs(R.ravel() - lit[0][1].ravel()).max() > 1e-6 or np.abs(t - lit[1][1]).max() > 1e-6:
+                        errors.append((tid, "literal rule differs", len(corr)))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(20)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    # empty matrix: no votes, candidate 0 of the decomposition
+    R, t, votes, cand = eng.pose_from_essential_host(est["E"][0], np.zeros((0, 4)))
+    assert votes == 0 and cand == 0 and abs(np.linalg.det(R) - 1) < 1e-9 and abs(np.linalg.norm(t) - 1) < 1e-9

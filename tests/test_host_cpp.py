@@ -33,7 +33,7 @@ def test_host_library_exports_and_header_symbols():
         assert hasattr(host, s), s
     host.pgih_create.restype = C.c_void_p
     assert not host.pgih_create(None)                       # refused, not crashed
-    assert host.pgih_run_pairs(None, 0, None, None, None, None, None, None, 0, None, 0, None, None) < 0
+    assert host.pgih_run_pairs(None, 0, 0, None, None, None, None, None, None, 0, 0, None, 0, None, None) < 0
     assert host.pgih_run_features(None, 0, None, 0, None, None, None, 0, 1, None, 0, None, None, None) < 0
     # no device here => creation fails loudly instead of falling back to the CPU
     if lib.pgi_device_count() == 0:
