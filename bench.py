@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -651,6 +652,7 @@ def main():
         # as a child process, its own wall clock and stage clocks, warm repetition; global rotation error after gauge
         # alignment, AUC@5 of the estimated edges
         out["graphs"] = graph_level(1)
+        from pyposegraphbuilder import scenes as SC
         # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
         # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
         # -> createCorrespondenceMatrix -> A* guesses -> estimatePose -> guided matching -> tracklets in HBM -- as a child

@@ -26,6 +26,7 @@ struct pgi_ctx {
     pgi_params prm;
     std::mutex mu;
     int max_lds = 0;
+    int n_cus = 256;
     unsigned long long* d_prof = nullptr;
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
@@ -83,4 +84,5 @@ struct pgi_ctx {
     hipStream_t class_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t class_fork = nullptr, class_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int class_overlap = 1;  // env PGI_CLASS_OVERLAP=0: one class after the other on the caller's stream
+    int k1_persistent = 1;  // size-class launches as persistent grids (resident workgroups pull pairs); env PGI_K1_PERSISTENT=0: grid = pairs
 };

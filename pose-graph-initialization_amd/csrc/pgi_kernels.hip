@@ -28,7 +28,10 @@
 
 namespace pgi {
 
-constexpr int NW = 4;          // wavefronts per workgroup
+#ifndef PGI_NW
+#define PGI_NW 4               // (-DPGI_NW=8: the experimental 8-wavefront build, `make libpgi_nw8.so`; DESIGN.md section 7 "Round 4")
+#endif
+constexpr int NW = PGI_NW;     // wavefronts per workgroup
 constexpr int NT = NW * 64;    // threads per workgroup
 constexpr int QCAP = 40;       // models per wavefront pass (4 hypotheses x 10 roots)
 constexpr double QMAGIC = 393216.0;  // 1.5 * 2^18: summands rounded to multiples of 2^-34
@@ -73,6 +76,7 @@ struct K1Args {
     unsigned long long* prof;  // kProfSlots counters (profiling builds) or nullptr
     const uint32_t* pair_list;   // size bucket: indices of the pairs of this launch (nullptr: all pairs)
     const uint32_t* pair_count;  // number of valid entries in pair_list
+    uint32_t* pair_head;         // persistent class grids: next unclaimed entry of pair_list (nullptr: entry = blockIdx.x)
     // Rows consumed in place from page-locked host memory (nullptr: the rows are at x1..y2).  K1 reads every row once
     // while staging; rows that do not fit in LDS are copied to x1..y2 (then a device mirror) on the way.
     const float* src_x1;
@@ -470,15 +474,9 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
 }
 
 template <int LDS_PTS, bool GUESS>
-__global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pair, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index: uniform, lives in an SGPR
-    uint32_t pair = blockIdx.x;
-    if (a.pair_list) {  // this launch serves one size bucket (its own LDS size => its own occupancy)
-        if (blockIdx.x >= *a.pair_count) return;
-        pair = a.pair_list[blockIdx.x];
-    }
     const uint64_t o = a.off[pair];
     const uint32_t n = (uint32_t)(a.off[pair + 1] - o);
     const uint32_t npad = (n + 63u) & ~63u;
@@ -1073,6 +1071,53 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
     prof.flush(a.prof, lane);
 }
 
+// The kernel: one pair per workgroup (grid = pairs), or -- a size-bucket launch -- workgroups that take entries of the
+// bucket's list: entry blockIdx.x when the grid covers the whole list, or (round 4, the default for the variants WITHOUT the
+// guess path) as a PERSISTENT grid of as many workgroups as the chip keeps resident, each taking whatever entry the shared
+// head counter hands out next until the list is empty; the claimed index travels through the first word of the row area,
+// which is dead between pairs.  No 10 000-workgroup grid of an empty class rides along any more, and BASELINE config 2's
+// launch is 3.5 % shorter (6.35 -> 6.13 ms, identical results: scripts/k1_variants_ab.sh).  The loop around the fit costs
+// registers -- 2 / 26 / 4 spilled VGPRs in the three variants, none of them inside the hypothesis passes (same time as the
+// loop-free build at every N when the grid covers the list) -- but 64-164 in the guess variants, which therefore keep the
+// one-pair form (-DPGI_K1_LOOP_GUESS builds them with the loop for experiments).
+template <int LDS_PTS, bool GUESS>
+__global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PGI_K1_LOOP_GUESS
+    constexpr bool kLoop = true;
+#else
+    constexpr bool kLoop = !GUESS;
+#endif
+    if constexpr (kLoop) {
+        const bool persistent = a.pair_list != nullptr && a.pair_head != nullptr;  // uniform
+        uint32_t slot = blockIdx.x;
+        for (;;) {
+            if (persistent) {
+                uint32_t* claim = reinterpret_cast<uint32_t*>(smem);
+                if (threadIdx.x == 0) *claim = atomicAdd(a.pair_head, 1u);
+                __syncthreads();
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)*claim);
+                __syncthreads();  // everyone has read the claim: the row area is free again
+            }
+            uint32_t pair = slot;
+            if (a.pair_list) {  // this launch serves one size bucket (its own LDS size => its own occupancy)
+                if (slot >= *a.pair_count) return;
+                pair = a.pair_list[slot];
+            }
+            estimate_pair<LDS_PTS, GUESS>(a, pair, smem);
+            if (!persistent) return;
+            __syncthreads();  // the pair's results are written, its LDS state is dead
+        }
+    } else {
+        uint32_t pair = blockIdx.x;
+        if (a.pair_list) {
+            if (blockIdx.x >= *a.pair_count) return;
+            pair = a.pair_list[blockIdx.x];
+        }
+        estimate_pair<LDS_PTS, GUESS>(a, pair, smem);
+    }
+}
+
 // Size buckets: dynamic LDS is per launch, so ragged batches are split by row count and every bucket
 // is launched with the LDS (hence the occupancy) its pairs need.  caps[b] = largest row count of
 // bucket b (ascending: 4, 3, 2, 1 workgroups per CU); pairs above caps[3] go to bucket 4 (rows stay in HBM/L2).
@@ -1495,6 +1540,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (cus > 0) c->resident_wgs = 3 * cus;
+    c->n_cus = cus > 0 ? cus : 256;
     // K1 may use the whole LDS of a CU for staged rows
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
@@ -1503,6 +1549,7 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
     if (const char* e = getenv("PGI_CLASS_OVERLAP")) c->class_overlap = atoi(e);
+    if (const char* e = getenv("PGI_K1_PERSISTENT")) c->k1_persistent = atoi(e);
     if (const char* e = getenv("PGI_HOST_DIRECT")) c->host_direct = atoi(e);
     if (const char* e = getenv("PGI_MATCH_WAVES")) c->match_waves = atoi(e);
     if (const char* e = getenv("PGI_MATCH_SCREEN")) c->match_screen = atoi(e);
@@ -1632,6 +1679,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.prof = ctx->d_prof;
     a.pair_list = nullptr;
     a.pair_count = nullptr;
+    a.pair_head = nullptr;
     a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
     a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1639,24 +1687,34 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
     auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) { return k1_rows_cap(ctx, wgs_per_cu, fixed_bytes); };
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
-    const uint32_t cap4 = rows_cap(4), cap3 = rows_cap(3), cap2 = rows_cap(2), cap1 = rows_cap(1);
+    // (the experimental 8-wavefront build runs two workgroups per CU where the default runs four: its row caps are those of
+    //  half as many workgroups, and it has no hybrid class -- 2 000 rows fit whole)
+    constexpr int kWgScale = NW / 4;
+    const uint32_t cap4 = rows_cap(std::max(1, 4 / kWgScale)), cap3 = rows_cap(std::max(1, 3 / kWgScale)),
+                   cap2 = rows_cap(std::max(1, 2 / kWgScale)), cap1 = rows_cap(1);
     bool hybrid = false;
+    int class_wgs = 4;        // workgroups per CU of the class being launched (sizes a persistent grid)
     hipStream_t ls = stream;  // the stream the next launch goes to (a class's side stream when classes overlap)
+    // grid of a launch: one workgroup per pair, or -- persistent class launch -- as many as stay resident at once
+    auto grid_of = [&]() {
+        if (!a.pair_head) return dim3(b->n_pairs);
+        return dim3(std::min<uint32_t>(b->n_pairs, (uint32_t)(ctx->n_cus * class_wgs)));
+    };
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + (hybrid ? fixed_stash : fixed);
         if (hybrid) {  // first cap_rows rows in LDS, the tail from HBM/L2
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), grid_of(), dim3(NT), lds, ls, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), grid_of(), dim3(NT), lds, ls, a);
         } else {
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), dim3(b->n_pairs), dim3(NT), lds, ls, a);
+            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), grid_of(), dim3(NT), lds, ls, a);
+            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), grid_of(), dim3(NT), lds, ls, a);
         }
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), dim3(b->n_pairs), dim3(NT), fixed_stash, ls, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), dim3(b->n_pairs), dim3(NT), fixed_stash, ls, a);
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), grid_of(), dim3(NT), fixed_stash, ls, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), grid_of(), dim3(NT), fixed_stash, ls, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
@@ -1669,7 +1727,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
         if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // bucket by row count on the device, one launch per occupancy class
         if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
-        const size_t need = ((size_t)5 * b->n_pairs + 8) * sizeof(uint32_t);
+        const size_t need = ((size_t)5 * b->n_pairs + 16) * sizeof(uint32_t);  // counts[8] | heads[8] | five lists
         if (need > *bucket_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (*bucket) (void)hipFree(*bucket);
@@ -1679,8 +1737,9 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
             *bucket_cap = need;
         }
         uint32_t* counts = *bucket;
-        uint32_t* lists = *bucket + 8;
-        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), stream));
+        uint32_t* heads = *bucket + 8;
+        uint32_t* lists = *bucket + 16;
+        HIP_TRY(hipMemsetAsync(counts, 0, 16 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(bucket_pairs_kernel, dim3((b->n_pairs + 255) / 256), dim3(256), 0, stream, b->d_offsets,
                            b->n_pairs, cap4, cap3, cap2, cap1, lists, counts);
         const uint32_t caps[4] = {cap4, cap3, cap2, cap1};
@@ -1710,12 +1769,18 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
         for (int k = 0; k < n_classes && first_err == hipSuccess; ++k) {
             a.pair_list = lists + (size_t)k * b->n_pairs;
             a.pair_count = counts + k;
+#ifdef PGI_K1_LOOP_GUESS
+            a.pair_head = ctx->k1_persistent ? heads + k : nullptr;
+#else
+            a.pair_head = ctx->k1_persistent && !guesses ? heads + k : nullptr;  // (the guess variants have no loop)
+#endif
+            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? 4 / kWgScale : k == 1 && ctx->hybrid_rows && NW == 4 ? 4 : std::max(1, (4 - k) / kWgScale);
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
             if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
-            hybrid = k == 1 && ctx->hybrid_rows;
+            hybrid = k == 1 && ctx->hybrid_rows && NW == 4;
             if (hybrid) launch_lds(rows_cap_of(4, fixed_stash));  // 1280 rows in LDS next to the sample stash
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;

@@ -20,6 +20,7 @@
 #include "pgi_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -771,10 +772,23 @@ static void forest_bfs_init(uint32_t V, const std::vector<std::vector<ForestEdge
 
 // The solve proper.  The rotation-graph edges are already in HBM at d_rot (RotEdgeDev[n_edges]); the host holds only
 // their endpoints, the initial rotations and the root flags.
+// PGI_ROTAVG_TIMING=1: wall clock of the host-visible phases on stderr (diagnosis only)
+struct PhaseClock {
+    bool on = std::getenv("PGI_ROTAVG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rotavg timing] %-44s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t n_views, uint32_t n_edges, const uint32_t* h_src,
                         const uint32_t* h_dst, const RotEdgeDev* d_rot, const std::vector<double>& R,
                         const std::vector<uint8_t>& is_root, const std::vector<std::vector<ForestEdge>>& forest, double* h_R_out,
                         uint32_t* h_iters_out) {
+    PhaseClock clk;
     // CSR adjacency, incidences in edge order
     std::vector<uint32_t> ptr(n_views + 1, 0), aedge(2 * (size_t)n_edges), aother(2 * (size_t)n_edges);
     std::vector<int8_t> asign(2 * (size_t)n_edges);
@@ -891,6 +905,8 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rot_solve_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tree_lds));
     }
+    if (clk.on) (void)hipStreamSynchronize(st);
+    clk.mark("solve: adjacency, allocation, uploads");
     bool use_tree = false;  // set once the Jacobi-preconditioned solve has run into its iteration cap
     const bool trace = std::getenv("PGI_ROTAVG_TRACE") != nullptr;
     pgi_rotavg_params prm = prm_in;
@@ -1019,6 +1035,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
         }
         if (stats[0] < prm.tol) break;
     }
+    clk.mark("solve: outer iterations");
     HIP_TRY(hipMemcpyAsync(h_R_out, d + o_R, V * 72, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h_iters_out) *h_iters_out = iters;
@@ -1090,6 +1107,7 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    PhaseClock clk;
     // (status, n_inl) of every record: an 8-byte column of the 200-byte table
     struct Meta { int32_t status; uint32_t n_inl; };
     std::vector<Meta> meta(n_pairs);
@@ -1111,9 +1129,11 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
     }
     const uint32_t nE = (uint32_t)idx.size();
     if (h_edges_used) *h_edges_used = nE;
+    clk.mark("edges: status column to the host, edge list");
     std::vector<uint32_t> tree;
     std::vector<std::vector<ForestEdge>> adj;
     spanning_forest(n_views, src.data(), dst.data(), wt.data(), nE, tree, adj);
+    clk.mark("edges: maximum-weight spanning forest (host)");
     std::vector<double> R;
     std::vector<uint8_t> is_root;
     if (nE == 0) {
@@ -1147,7 +1167,9 @@ int pgi_rotation_average_edges(pgi_ctx* ctx, const pgi_edge* d_edges, const uint
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<uint32_t> slot(nE, 0u);  // edge -> position in the forest list
     for (size_t k = 0; k < nT; ++k) slot[tree[k]] = (uint32_t)k;
+    clk.mark("edges: device edge table, forest rotations back");
     forest_bfs_init(n_views, adj, [&](uint32_t e) { return &treeR[9 * (size_t)slot[e]]; }, R, is_root);
+    clk.mark("edges: forest initialisation (host)");
     return rotavg_solve(ctx, prm, n_views, nE, src.data(), dst.data(), d_rot, R, is_root, adj, h_R_out, h_iters_out);
 }
 

@@ -211,7 +211,8 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         std::unique_lock<std::shared_mutex> l(mu);
         if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) return false;
         const uint32_t k = (uint32_t)edge_store.size();
-        if (!edge_index.emplace(EdgeId{s, d}, k).second) return false;
+        if (s == 0xFFFFFFFFull && d == 0xFFFFFFFFull) return false;  // (the packed key of this one pair is the table's empty mark)
+        if (!edge_index.insert(EdgeId{s, d}, k)) return false;
         edge_store.emplace_back(s, d, T, score);
         neighboursForUpdate(s).push_back(Neighbour{d, score, k});
         neighboursForUpdate(d).push_back(Neighbour{s, score, k});
@@ -220,13 +221,14 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     // room for n more edges (one rehash instead of a dozen while a wave of 10^4 edges is committed)
     void reserveEdges(size_t n) {
         std::unique_lock<std::shared_mutex> l(mu);
-        edge_store.reserve(edge_store.size() + n);
-        edge_index.reserve(edge_index.size() + n);
+        const size_t want = edge_store.size() + n;  // geometric: a reserve per wave must not re-house the graph every time
+        if (want > edge_store.capacity()) edge_store.reserve(std::max(want, 2 * edge_store.capacity()));
+        edge_index.reserve(want > edge_store.capacity() ? want : edge_store.capacity());
     }
     PoseGraphEdge getEdgeById(const EdgeId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
-        auto it = edge_index.find(id);
-        return it == edge_index.end() ? PoseGraphEdge() : edge_store[it->second];
+        const uint32_t k = edge_index.find(id);
+        return k == EdgeIndex::npos ? PoseGraphEdge() : edge_store[k];
     }
     std::vector<EdgeId> getEdgeIds() const {  // insertion order, like the reference's edges_ids
         std::shared_lock<std::shared_mutex> l(mu);
@@ -272,8 +274,8 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         return true;
     }
     const PoseGraphEdge* findEdgeFrozen(const EdgeId& id) const {  // (no lock: see forEachEdgeOfFrozen)
-        auto it = edge_index.find(id);
-        return it == edge_index.end() ? nullptr : &edge_store[it->second];
+        const uint32_t k = edge_index.find(id);
+        return k == EdgeIndex::npos ? nullptr : &edge_store[k];
     }
     size_t getEdgeNumberByVertex(const ViewId& id) const {
         std::shared_lock<std::shared_mutex> l(mu);
@@ -310,7 +312,74 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     std::vector<uint8_t> vertex_dense;
     std::unordered_map<ViewId, PoseGraphVertex> vertex_sparse;
     std::vector<PoseGraphEdge> edge_store;                         // insertion order
-    std::unordered_map<EdgeId, uint32_t, EdgeIdHash> edge_index;   // (src, dst) -> position in edge_store
+    // (src, dst) -> position in edge_store.  Ids below 2^32 (every real case) live in an open-addressing table of packed
+    // 64-bit keys -- no node allocation per edge, one probe sequence in one array; anything larger in a std hash map.
+    class EdgeIndex {
+       public:
+        static constexpr uint32_t npos = 0xFFFFFFFFu;
+        uint32_t find(const EdgeId& id) const {
+            if ((id.first | id.second) >> 32) {
+                auto it = big.find(id);
+                return it == big.end() ? npos : it->second;
+            }
+            if (keys.empty()) return npos;
+            const uint64_t k = pack(id);
+            for (size_t i = slot(k);; i = (i + 1) & (keys.size() - 1)) {
+                if (keys[i] == k) return vals[i];
+                if (keys[i] == kEmpty) return npos;
+            }
+        }
+        size_t count(const EdgeId& id) const { return find(id) != npos; }
+        bool insert(const EdgeId& id, uint32_t v) {  // false if the id is already there
+            if ((id.first | id.second) >> 32) return big.emplace(id, v).second;
+            if ((used + 1) * 2 > keys.size()) grow(std::max<size_t>(64, 2 * keys.size()));
+            const uint64_t k = pack(id);
+            for (size_t i = slot(k);; i = (i + 1) & (keys.size() - 1)) {
+                if (keys[i] == k) return false;
+                if (keys[i] == kEmpty) {
+                    keys[i] = k;
+                    vals[i] = v;
+                    ++used;
+                    return true;
+                }
+            }
+        }
+        void reserve(size_t n) {
+            size_t cap = 64;
+            while (cap < 2 * n) cap *= 2;
+            if (cap > keys.size()) grow(cap);
+        }
+
+       private:
+        static constexpr uint64_t kEmpty = ~0ull;  // (src, dst) = (2^32 - 1, 2^32 - 1) is routed to `big` below
+        static uint64_t pack(const EdgeId& id) { return ((uint64_t)id.first << 32) | (uint64_t)id.second; }
+        size_t slot(uint64_t k) const {
+            k *= 0x9E3779B97F4A7C15ull;
+            return (size_t)(k ^ (k >> 29)) & (keys.size() - 1);
+        }
+        void grow(size_t cap) {
+            std::vector<uint64_t> ok(cap, kEmpty);
+            std::vector<uint32_t> ov(cap, 0);
+            ok.swap(keys);
+            ov.swap(vals);
+            used = 0;
+            for (size_t i = 0; i < ok.size(); ++i)
+                if (ok[i] != kEmpty) {
+                    for (size_t j = slot(ok[i]);; j = (j + 1) & (keys.size() - 1))
+                        if (keys[j] == kEmpty) {
+                            keys[j] = ok[i];
+                            vals[j] = ov[i];
+                            ++used;
+                            break;
+                        }
+                }
+        }
+        std::vector<uint64_t> keys;
+        std::vector<uint32_t> vals;
+        size_t used = 0;
+        std::unordered_map<EdgeId, uint32_t, EdgeIdHash> big;
+    };
+    EdgeIndex edge_index;
     std::vector<std::vector<Neighbour>> adjacency_dense;           // per vertex, insertion order
     std::unordered_map<ViewId, std::vector<Neighbour>> adjacency_sparse;
 };
@@ -474,9 +543,13 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // all-gathered (pgi_allgather_edges: RCCL over xGMI, or the host transport when ranks share a device) and every
     // rank commits the identical full table.  d_edges_out (optional): receives the gathered table, still in HBM
     // (pairs.size() records; caller-allocated), e.g. to feed pgi_rotation_average_edges without a host round trip.
+    // prepareGuesses (optional): called on the host with ranges [first, last) of `pairs` -- this rank's launch groups, in
+    // order -- before the range's rows are staged; it may fill poseGuesses of exactly those pairs (the scheduler runs its A*
+    // searches there, so that they overlap the device's work on the previous group).
     size_t estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed = 0,
                          std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false,
-                         pgi_edge* d_edges_out = nullptr);
+                         pgi_edge* d_edges_out = nullptr,
+                         const std::function<void(size_t, size_t)>* prepareGuesses = nullptr);
 
     // BASELINE config 4: shard -> estimate -> gather -> replicated L1/IRLS rotation averaging; the gathered records
     // stay in HBM between the exchange and the solve.  R_i are world->camera, one per view id < numViews.

@@ -115,6 +115,10 @@ def run_ranks(cmd, world, timeout=1500, extra_env=None):
         outs.append((p.returncode, o, e))
     for rc, o, e in outs:
         assert rc == 0, (rc, o[-2000:], e[-2000:])
+    if os.environ.get("PGI_SHOW_STDERR"):  # diagnosis: the ranks' stderr (PGI_HOST_TIMING / PGI_ROTAVG_TIMING lines)
+        import sys
+        for _, _, e in outs:
+            sys.stderr.write(e)
     return [o for _, o, _ in outs]
 
 

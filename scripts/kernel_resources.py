@@ -10,7 +10,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi.so")
+LIB = os.environ.get("PGI_LIB", os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi.so"))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 FILT = "c++filt"
 

@@ -77,9 +77,7 @@ int main(int argc, char** argv) {
         // PGI_DRIVER_REPS > 1 (bench.py, scripts/config45_bench.py): the whole build -> run -> write cycle is repeated inside
         // this process, one timing line per repetition; the last one is the warm figure (code objects, allocations, staging)
         const int reps = std::max(1, std::atoi(std::getenv("PGI_DRIVER_REPS") ? std::getenv("PGI_DRIVER_REPS") : "1"));
-        const std::vector<PoseGraphBuilder::ViewPair> pairs0 = reps > 1 ? pairs : std::vector<PoseGraphBuilder::ViewPair>();
-        for (int rep = 0; rep < reps; ++rep) {
-        if (rep) pairs = pairs0;  // run() sorts and moves from its candidate list
+        for (int rep = 0; rep < reps; ++rep) {  // (run() leaves its candidate list as it found it: no copy per repetition)
         PoseGraphBuilder builder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", waves, true, true);
         if (mode == "waves_guided") builder.setRotationGuidedGuesses(true);  // config 5: rotation-guided re-estimation
         const dist::Transport tr = dist::attach(builder.getEngine(), comm);

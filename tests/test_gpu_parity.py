@@ -457,8 +457,11 @@ def test_degenerate_inputs_match_oracle_and_terminate(eng):
 
 
 def test_size_bucketed_launches_match_oracle(eng):
-    """>= 64 pairs spanning every occupancy class (<= 2176 and <= 3904 rows: 4-wave workgroups; <= 7872: 8-wave
-    workgroups; <= 9024: 4-wave, one per CU; beyond: rows from HBM)."""
+    """>= 64 pairs spanning every occupancy class of launch_estimate (csrc/pgi_kernels.hip; all classes are 256-thread /
+    four-wavefront workgroups): <= 1344 rows staged in LDS at four workgroups per CU; <= 2176 the hybrid class (1280 rows in
+    LDS, the tail from HBM/L2, still four per CU); <= 3904 in LDS at two per CU; larger pairs read every row from HBM/L2.
+    The classes run as persistent grids (resident workgroups pull pairs from the class's list), with PGI_K1_PERSISTENT=0 as
+    one workgroup per list entry: the same bytes either way."""
     sizes = ([60, 300, 2300, 1500, 4000, 2176, 2177, 900] * 9)[:68] + [9100, 9024, 7000, 7900]
     ids = np.arange(15000, 15000 + len(sizes))
     b = S.make_batch(ids, sizes)
@@ -472,6 +475,20 @@ def test_size_bucketed_launches_match_oracle(eng):
     # a second call reuses the bucket workspace and is bit-identical
     edges2, masks2 = eng.estimate_pose_batch(db)
     assert np.array_equal(edges.cpu().numpy(), edges2.cpu().numpy())
+    # the one-workgroup-per-entry form of the class launches (a fresh context reads the switch) gives the same bytes
+    import os
+    from pyposegraphbuilder import Engine
+    os.environ["PGI_K1_PERSISTENT"] = "0"
+    try:
+        eng2 = Engine()
+    finally:
+        del os.environ["PGI_K1_PERSISTENT"]
+    try:
+        db2 = eng2.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=4, pair_id_base=15000)
+        edges3, masks3 = eng2.estimate_pose_batch(db2)
+        assert np.array_equal(edges.cpu().numpy(), edges3.cpu().numpy()) and np.array_equal(masks.cpu().numpy(), masks3.cpu().numpy())
+    finally:
+        eng2.close()
 
 
 @pytest.mark.gpu
