@@ -548,19 +548,50 @@ __global__ __launch_bounds__(kCgBlock) void cg_init_kernel(uint32_t n_views, con
 constexpr int kRowLanes = 16;
 constexpr int kRowsPerBlock = kCgBlock / kRowLanes;
 
-__device__ bool deliver_partial(const double v[6], double* __restrict__ partial, CgState* __restrict__ st, int tid) {
-    __shared__ bool last;
-    if (tid == 0) {
-        for (int c = 0; c < 6; ++c) partial[6 * blockIdx.x + c] = v[c];
-        __threadfence();  // the partials leave this XCD's L2 before the ticket is taken
-        last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1u;
+// Sum of 256 values per component (6 components) with EXACTLY the association of block_sum3_256's tree -- entry t takes
+// entry t + s for s = 128, 64, ..., 1 -- but with two barriers instead of eighteen: the two upper steps go through LDS, the
+// six lower ones are shuffles inside wavefront 0 (lane t + lane t + s for t < s is the same addition).  Every thread
+// returns the block's sums.
+__device__ void block_sum6_256(double v[6], double* red /* 6 * 256 */, int tid) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) red[256 * c + tid] = v[c];
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) red[256 * c + tid] += red[256 * c + tid + 128];
     }
     __syncthreads();
-    if (last) __threadfence();  // and the last workgroup reads the others' from memory
-    return last;
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double x = red[256 * c + tid] + red[256 * c + tid + 64];
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) x += __shfl_down(x, sft);  // lane t (< sft) gets x_t + x_{t + sft}
+            if (tid == 0) red[256 * c] = x;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = red[256 * c];
+    __syncthreads();
 }
 
-// init_pass: alpha = beta = 0 (x and r stay, p becomes z, q becomes 0): produces s0 = A z0, gamma0, delta0, alpha0
+// The scalars of one PCG iteration, derived from the block partials (gamma, delta per axis) of the PREVIOUS launch.
+struct CgScalars {
+    double alpha[3], beta[3], rz[3], rz0[3], iters;
+    bool done;
+};
+
+// ONE launch per PCG iteration (round 4 form).  Round 3 ended every launch with a grid-wide hand-over: each workgroup
+// published its partial sums behind an agent-scope fence, took a ticket, and the last one to arrive reduced all partials and
+// wrote the next scalars -- a fence, an atomic and a serial tail on the critical path of a 15 us kernel.  Now a launch only
+// WRITES its block's partials; the NEXT launch starts by reducing the previous launch's partials -- every workgroup
+// redundantly, in the same fixed order (strided sums, then the 256-entry tree), so every workgroup holds the same bits --
+// and derives alpha, beta and the stopping test from them.  Partials and the scalar state are double-buffered by launch
+// parity, so nothing is read and written in the same launch.  mode 1: the init pass (alpha = beta = 0; x and r stay, p
+// becomes z, q becomes 0: produces s0 = A z0 and the partials of gamma0, delta0); mode 0: an iteration; mode 2: only the
+// reduction and the state record (what the host reads between chunks of launches), no vector is touched.
+// Same arithmetic in the same order as the round-3 kernel: the rotations are bit-identical.
 __global__ __launch_bounds__(kCgBlock) void cg_iteration_kernel(uint32_t n_views, const uint32_t* __restrict__ adj_ptr,
                                                                 const uint32_t* __restrict__ adj_edge,
                                                                 const uint32_t* __restrict__ adj_other,
@@ -568,15 +599,60 @@ __global__ __launch_bounds__(kCgBlock) void cg_iteration_kernel(uint32_t n_views
                                                                 const double* __restrict__ diag, double* __restrict__ x,
                                                                 double* __restrict__ p, const double* r_old, double* r_new,
                                                                 const double* q_old, double* q_new, const double* s_old,
-                                                                double* s_new, int init_pass, double tol,
-                                                                double* __restrict__ partial, CgState* __restrict__ st) {
-    __shared__ double red[3 * kCgBlock];
-    if (!init_pass && st->done) return;
+                                                                double* s_new, int mode, int prev_was_init, double tol,
+                                                                const double* __restrict__ part_prev, double* __restrict__ part_next,
+                                                                uint32_t n_blocks, const CgState* __restrict__ st_prev,
+                                                                CgState* __restrict__ st_next) {
+    __shared__ double red[6 * kCgBlock];
     const int tid = threadIdx.x, sub = tid & (kRowLanes - 1);
-    const uint32_t k = blockIdx.x * kRowsPerBlock + (uint32_t)(tid / kRowLanes);
     double alpha[3] = {0, 0, 0}, beta[3] = {0, 0, 0};
-    if (!init_pass)
-        for (int c = 0; c < 3; ++c) { alpha[c] = st->alpha[c]; beta[c] = st->beta[c]; }
+    if (mode != 1) {
+        if (st_prev->done) {  // (uniform) converged earlier: keep the record where the host reads it
+            if (blockIdx.x == 0 && tid == 0) *st_next = *st_prev;
+            return;
+        }
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t b = tid; b < n_blocks; b += kCgBlock)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += part_prev[6 * (size_t)b + c];
+        block_sum6_256(v, red, tid);
+        bool done = true;
+        double rz_new[3], rz0[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double g = v[c], dl = v[3 + c];
+            if (prev_was_init) {
+                rz0[c] = g;
+                beta[c] = 0.0;
+                alpha[c] = dl > 0.0 ? g / dl : 0.0;
+                done &= !(g > 0.0);
+            } else {
+                rz0[c] = st_prev->rz0[c];
+                const double a_prev = st_prev->alpha[c];
+                const double bt = st_prev->rz[c] > 0.0 ? g / st_prev->rz[c] : 0.0;
+                const double den = a_prev != 0.0 ? dl - bt * g / a_prev : dl;
+                beta[c] = bt;
+                alpha[c] = den > 0.0 ? g / den : 0.0;
+                done &= !(g > tol * tol * rz0[c]);
+            }
+            rz_new[c] = g;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                st_next->rz[c] = rz_new[c];
+                st_next->rz0[c] = rz0[c];
+                st_next->alpha[c] = alpha[c];
+                st_next->beta[c] = beta[c];
+            }
+            st_next->iters = prev_was_init ? 0.0 : st_prev->iters + 1.0;
+            st_next->done = done;
+            st_next->mean_step = 0.0;
+            st_next->ticket = 0;
+        }
+        if (done || mode == 2) return;  // (uniform)
+    }
+    const uint32_t k = blockIdx.x * kRowsPerBlock + (uint32_t)(tid / kRowLanes);
     double gd[6] = {0, 0, 0, 0, 0, 0};  // gamma (3), delta (3)
     if (k < n_views) {
         const bool free_k = !is_root[k];
@@ -618,36 +694,10 @@ __global__ __launch_bounds__(kCgBlock) void cg_iteration_kernel(uint32_t n_views
             }
         }
     }
-    block_sum3_256(gd, red, tid);
-    block_sum3_256(gd + 3, red, tid);
-    if (!deliver_partial(gd, partial, st, tid)) return;
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = tid; b < gridDim.x; b += kCgBlock)
-        for (int c = 0; c < 6; ++c) v[c] += partial[6 * (size_t)b + c];
-    block_sum3_256(v, red, tid);
-    block_sum3_256(v + 3, red, tid);
-    if (tid == 0) {
-        bool done = true;
-        for (int c = 0; c < 3; ++c) {
-            const double g = v[c], dl = v[3 + c];
-            if (init_pass) {
-                st->rz0[c] = g;
-                st->beta[c] = 0.0;
-                st->alpha[c] = dl > 0.0 ? g / dl : 0.0;
-                done &= !(g > 0.0);
-            } else {
-                const double bt = st->rz[c] > 0.0 ? g / st->rz[c] : 0.0;
-                const double den = alpha[c] != 0.0 ? dl - bt * g / alpha[c] : dl;
-                st->beta[c] = bt;
-                st->alpha[c] = den > 0.0 ? g / den : 0.0;
-                done &= !(g > tol * tol * st->rz0[c]);
-            }
-            st->rz[c] = g;
-        }
-        st->iters = init_pass ? 0.0 : st->iters + 1.0;
-        st->done = done;
-        st->ticket = 0;
-    }
+    block_sum6_256(gd, red, tid);
+    if (tid == 0)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) part_next[6 * (size_t)blockIdx.x + c] = gd[c];
 }
 
 __global__ __launch_bounds__(kCgBlock) void cg_step_norm_kernel(uint32_t n_views, const double* __restrict__ x,
@@ -711,9 +761,20 @@ struct ForestEdge {
 // Kruskal on (weight desc, edge index asc); returns the forest's edge list and its adjacency
 static void spanning_forest(uint32_t V, const uint32_t* src, const uint32_t* dst, const double* weight, uint32_t nE,
                             std::vector<uint32_t>& tree, std::vector<std::vector<ForestEdge>>& adj) {
+    // (weight desc, edge index asc) as ONE integer key per edge -- the order-preserving bit pattern of the weight, inverted, above
+    // the index -- sorted by value: the same order as a stable sort by weight, without a comparator that chases two indices per
+    // comparison (6.9 -> 1.6 ms at 10^5 edges)
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(nE);
+    for (uint32_t e = 0; e < nE; ++e) {
+        uint64_t u;
+        const double wv = weight[e] == 0.0 ? 0.0 : weight[e];  // (-0.0 and +0.0 compare equal: one key)
+        memcpy(&u, &wv, 8);
+        u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);  // ascending in the value
+        keyed[e] = {~u, e};                                  // descending
+    }
+    std::sort(keyed.begin(), keyed.end());
     std::vector<uint32_t> order(nE);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    for (uint32_t e = 0; e < nE; ++e) order[e] = keyed[e].second;
     std::vector<uint32_t> parent(V);
     std::iota(parent.begin(), parent.end(), 0u);
     auto find = [&](uint32_t a) {
@@ -871,8 +932,8 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                  o_root = carve(V), o_omega = carve(E * 24), o_w = carve(E * 8), o_diag = carve(V * 8),
                  o_x = carve(V * 24), o_r = carve(V * 24), o_p = carve(V * 24), o_Ap = carve(V * 24), o_r2 = carve(V * 24), o_q2 = carve(V * 24), o_s = carve(V * 24),
                  o_s2 = carve(V * 24),
-                 o_stats = carve(16), o_cg = carve(sizeof(CgState)),
-                 o_part = carve(6 * 8 * ((V + kRowsPerBlock - 1) / kRowsPerBlock + 1)),
+                 o_stats = carve(16), o_cg = carve(4 * sizeof(CgState)),  // two launch parities + the record the host reads
+                 o_part = carve(2 * 6 * 8 * ((V + kRowsPerBlock - 1) / kRowsPerBlock + 1)),  // block partials, by launch parity
                  // tree path
                  o_tptr = carve((V + 1) * 4), o_tedge = carve(2 * E * 4), o_tother = carve(2 * E * 4), o_tsign = carve(2 * E),
                  o_tn2o = carve(V * 4), o_tpe = carve(V * 4), o_tsz = carve(V * 4), o_ten = carve(V * 4), o_tex = carve(V * 4),
@@ -957,26 +1018,37 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
             double* rbuf[2] = {(double*)(d + o_r), (double*)(d + o_r2)};
             double* qbuf[2] = {(double*)(d + o_Ap), (double*)(d + o_q2)};
             double* sbuf[2] = {(double*)(d + o_s), (double*)(d + o_s2)};
-            int cur = 0;  // buffers holding the vectors of the last finished iteration
-            HIP_TRY(hipMemsetAsync(d + o_cg + offsetof(CgState, ticket), 0, sizeof(unsigned int), st));
+            double* pbuf[2] = {part, part + 6 * ((size_t)nbp + 1)};
+            CgState* record = cst + 2;  // written by the reduce-only launch, read by the host
+            int cur = 0;           // buffers holding the vectors of the last finished iteration
+            uint32_t launch = 0;   // launches so far: launch j reads parity (j - 1) & 1 of partials / state, writes parity j & 1
+            HIP_TRY(hipMemsetAsync(cst, 0, 3 * sizeof(CgState), st));
             HIP_TRY(hipMemsetAsync(qbuf[0], 0, V * 24, st));
             HIP_TRY(hipMemsetAsync(sbuf[0], 0, V * 24, st));
-            auto iterate = [&](int init_pass) {
-                hipLaunchKernelGGL(cg_iteration_kernel, dim3(nbp), dim3(kCgBlock), 0, st, n_views, (const uint32_t*)(d + o_ptr),
+            auto iterate = [&](int mode) {  // 1: init pass, 0: iteration, 2: reduce the last launch's partials into `record`
+                const int prev = (int)((launch + 1) & 1u), next = (int)(launch & 1u);
+                hipLaunchKernelGGL(cg_iteration_kernel, dim3(mode == 2 ? 1u : nbp), dim3(kCgBlock), 0, st, n_views, (const uint32_t*)(d + o_ptr),
                                    (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const uint8_t*)(d + o_root),
                                    (const double*)(d + o_w), (const double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_p),
                                    (const double*)rbuf[cur], rbuf[cur ^ 1], (const double*)qbuf[cur], qbuf[cur ^ 1],
-                                   (const double*)sbuf[cur], sbuf[cur ^ 1], init_pass, 1e-10, part, cst);
-                cur ^= 1;
+                                   (const double*)sbuf[cur], sbuf[cur ^ 1], mode, launch == 1 ? 1 : 0, 1e-10, (const double*)pbuf[prev],
+                                   pbuf[next], nbp, (const CgState*)(cst + prev), mode == 2 ? record : cst + next);
+                if (mode != 2) {
+                    cur ^= 1;
+                    ++launch;
+                }
             };
             iterate(1);
             int done = 0;
+            uint32_t chunk_len = 16;  // launches between two looks at the record: 16, 32, 64, ... (a look costs a round trip)
             for (uint32_t ci = 0; ci < prm.cg_iters;) {
-                const uint32_t chunk = std::min<uint32_t>(16, prm.cg_iters - ci);  // kernels no-op once converged
+                const uint32_t chunk = std::min<uint32_t>(chunk_len, prm.cg_iters - ci);  // kernels no-op once converged
                 for (uint32_t q = 0; q < chunk; ++q) iterate(0);
                 ci += chunk;
+                chunk_len = std::min<uint32_t>(2 * chunk_len, 64);
+                iterate(2);
                 CgState hs;
-                HIP_TRY(hipMemcpyAsync(&hs, cst, sizeof hs, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&hs, record, sizeof hs, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 done = hs.done;
                 if (done) break;
@@ -1026,7 +1098,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                 cg_it = -std::max(its[0], std::max(its[1], its[2]));  // printed negative: tree-preconditioned iterations
             } else if (n_views > kSingleWgViews) {
                 CgState hs;
-                HIP_TRY(hipMemcpyAsync(&hs, d + o_cg, sizeof hs, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&hs, d + o_cg + 2 * sizeof(CgState), sizeof hs, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 cg_it = hs.iters;
             }

@@ -16,7 +16,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PEAK_F32, PEAK_F64 = 157.3e12, 78.6e12
 
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def read(tag, kernel="estimate_pose_kernel<2, false>"):
@@ -31,6 +31,14 @@ def read(tag, kernel="estimate_pose_kernel<2, false>"):
             f = line.split(")")[-1].split()
             calls, avg_us = int(f[0]), float(f[2])
     return vals, avg_us, calls
+
+
+def unprofiled_kernel_us():
+    try:
+        line = [ln for ln in open(os.path.join(OUT, "%s_k1_unprofiled_bench.json" % TAG)) if ln.startswith("{")][-1]
+        return round(1e3 * json.loads(line)["roofline"]["kernel_ms"], 1)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -57,6 +65,12 @@ def main():
         "source_sha256": open(os.path.join(OUT, "%s_k1_source_sha256.txt" % TAG)).read().strip(),
         "git_head": sys.argv[2] if len(sys.argv) > 2 else None,
         "kernel_us_trace_avg": avg_us, "dispatches": calls,
+        # the same bench command without the profiler on the same lease (HIP events on the launch stream): what the profiled
+        # average is to be reconciled with -- the profiler adds a few per cent
+        "kernel_us_events_same_box": unprofiled_kernel_us(),
+        "launch_shape": "size-class launches are persistent grids (256 CUs x 4 resident workgroups pull pairs from the class's "
+                        "list); the empty <= 1344-row class of this workload is a grid of 1024 workgroups that exit at once -- "
+                        "round 3's 10 000-workgroup grid of that class (3.9 ms in the trace, overlapped) is gone",
         "hbm_bytes_per_launch": round(fetch_b + write_b), "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]),
         "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
         "correction": "FETCH_SIZE x2 on gfx950 (64 B tallied per 128-B request); WRITE_SIZE as reported",

@@ -1,14 +1,16 @@
 # K1 (estimate_pose_kernel) on BASELINE config 2: kernel trace + PMC passes (each in its own run, never combined with
 # other trace domains; the program sits directly after `--`), summarised into gpurun_out/<tag>_k1_*.txt; the sha256 of
 # the kernel sources that were profiled is recorded next to them.  scripts/k1_pmc_json.py <tag> turns the sums into
-# profiles/<tag>_k1_pmc.json.  Usage (GPU box): bash scripts/profile_k1.sh r03
-T=${1:-r03}
+# profiles/<tag>_k1_pmc.json.  Usage (GPU box): bash scripts/profile_k1.sh r04
+T=${1:-r04}
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p $R/gpurun_out
 cd $R
 python3 -c "import sys; sys.path.insert(0, 'pose-graph-initialization_amd'); from pyposegraphbuilder import _lib as L; print(L.kernel_source_sha256())" > gpurun_out/${T}_k1_source_sha256.txt
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-variants"
+# the same command WITHOUT the profiler, on this very lease: its HIP-event kernel time is what the profiled averages are read against
+python3 $ARGS > gpurun_out/${T}_k1_unprofiled_bench.json 2> gpurun_out/${T}_k1_unprofiled_bench.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_k1_trace -o $T -- python3 $ARGS > gpurun_out/${T}_k1_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 -d gpurun_out/${T}_k1_flops -o $T -- python3 $ARGS > gpurun_out/${T}_k1_flops.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_MFMA SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d gpurun_out/${T}_k1_mix -o $T -- python3 $ARGS > gpurun_out/${T}_k1_mix.log 2>&1

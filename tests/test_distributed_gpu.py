@@ -41,7 +41,7 @@ def scene(request, tmp_path_factory):
     return dict(name=request.param, g=g, path=path, dir=d, V=V, wave=wave, dense=dense)
 
 
-CONFIG5_REFERENCE_GUESS_BOUND_DEG = {"v340": 1.0, "v5000": 5.0}   # mean global rotation error with the reference's guess path
+CONFIG5_REFERENCE_GUESS_BOUND_DEG = {"v340": 0.5, "v5000": 2.0}   # mean global rotation error with the reference's guess path (measured 0.11 / 0.74)
 
 
 def _rotations(blob, V):
