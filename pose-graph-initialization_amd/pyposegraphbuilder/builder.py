@@ -132,10 +132,15 @@ class PoseGraphBuilder:
         stats = np.zeros(24, np.uint64)
         stages = np.zeros(8, np.float64)
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
-        rc = lib.pgih_run_features(h, len(views), vrec, P, ptr(src), ptr(dst), ptr(sim), int(waveSize), int(bool(deviceTracklets)), ptr(edges),
-                                   len(edges), C.byref(n_edges), ptr(stats), ptr(stages))
+        try:
+            rc = lib.pgih_run_features(h, len(views), vrec, P, ptr(src), ptr(dst), ptr(sim), int(waveSize), int(bool(deviceTracklets)), ptr(edges),
+                                       len(edges), C.byref(n_edges), ptr(stats), ptr(stages))
+            err = lib.pgih_last_error().decode() if rc < 0 else None
+        finally:
+            if rotationGuided:  # the switch belongs to this call, not to the builder
+                lib.pgih_set_rotation_guided(h, 0)
         if rc < 0:
-            raise RuntimeError(lib.pgih_last_error().decode())
+            raise RuntimeError(err)
         names = ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
                  "waves", "graph_edges", "quirk_only_guesses")
         self.statistics = dict(zip(names, (int(v) for v in stats)))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_k2_pmc.json from the summaries of scripts/profile_k2.sh <tag> (usage: k2_pmc_json.py r03 [git head]):
+"""profiles/<tag>_k2_pmc.json from the summaries of scripts/profile_k2.sh <tag> (usage: k2_pmc_json.py r04 [git head]):
 HBM-side traffic of score_pose_kernel (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE) per launch, its trace
 average, and the hash of the kernel sources that were profiled (bench.py replays the traffic only while it matches)."""
 import json
@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P, N = 10000, 2000
 
 

@@ -1,4 +1,4 @@
-# config 3 from features at full size under rocprofv3 (kernel trace + stats): which kernels make up the 0.32 s?
+# config 3 from features at full size under rocprofv3 (kernel trace + stats): which kernels make up the 0.18 s?
 # Usage (GPU box): bash scripts/profile_config3.sh [modes, default 2]
 M=${1:-2}
 set -x
@@ -12,7 +12,7 @@ from pyposegraphbuilder import scenes as SC, synthetic as S
 views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
 SC.write_feature_scene("/tmp/config3_features.bin", views, cam, sim, pairs, 512)
 PY
-PGI_DRIVER_REPS=2 rocprofv3 --kernel-trace --stats -d gpurun_out/r03_config3_trace -o r03 -- pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out $M > gpurun_out/r03_config3_trace.log 2>&1
-python3 scripts/rocpd_summary.py $(find gpurun_out/r03_config3_trace -name "*.db" | head -1) > gpurun_out/r03_config3_trace_summary.txt 2>&1
-head -40 gpurun_out/r03_config3_trace_summary.txt | cut -c1-150; cat gpurun_out/r03_config3_trace.log | tail -5
+PGI_DRIVER_REPS=2 rocprofv3 --kernel-trace --stats -d gpurun_out/r04_config3_trace -o r04 -- pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out $M > gpurun_out/r04_config3_trace.log 2>&1
+python3 scripts/rocpd_summary.py $(find gpurun_out/r04_config3_trace -name "*.db" | head -1) > gpurun_out/r04_config3_trace_summary.txt 2>&1
+head -40 gpurun_out/r04_config3_trace_summary.txt | cut -c1-150; cat gpurun_out/r04_config3_trace.log | tail -5
 rm -f /tmp/config3_features.bin /tmp/config3_features.out

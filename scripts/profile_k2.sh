@@ -1,7 +1,7 @@
 # K2 (score_pose_kernel) alone on config 2's shape: kernel trace + FETCH_SIZE / WRITE_SIZE passes (separate runs; the
 # program directly after `--`); scripts/k2_pmc_json.py <tag> writes profiles/<tag>_k2_pmc.json.
-# Usage (GPU box): bash scripts/profile_k2.sh r03
-T=${1:-r03}
+# Usage (GPU box): bash scripts/profile_k2.sh r04
+T=${1:-r04}
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p $R/gpurun_out

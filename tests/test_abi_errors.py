@@ -29,6 +29,8 @@ def test_null_context_is_rejected_everywhere():
         lambda: lib.pgi_rotation_average_edges(z, z, z, z, z, 0, 1, None, z, z, z),
         lambda: lib.pgi_comm_unique_id(z),
         lambda: lib.pgi_score_pose_f64_host(z, z, 4, z, 1.0, 5, None, z),
+        lambda: lib.pgi_pose_from_essential_host(z, z, z, 4, z, z, z, None, None),
+        lambda: lib.pgi_screen_guesses(z, z, 5, z, 4),
         lambda: lib.pgi_tracklets_add_batch(z, None, 1), lambda: lib.pgi_tracklets_get_batch(z, z, z, 1, 1, 2, z, z, z),
         lambda: lib.pgi_tracklets_info(z, None, None, None), lambda: lib.pgi_tracklets_track(z, 0, z, 0, None),
     ]
@@ -205,3 +207,54 @@ def test_rccl_communicator_of_one_rank(eng):
     finally:
         L.check(lib.pgi_comm_destroy(ctx))
     assert eng.comm_info() == (1, 0, "none")
+
+
+@pytest.mark.gpu
+def test_host_scheduler_entry_validates_caller_data(capfd):
+    """pgih_run_pairs (include/pgi_host.h) sizes host tables from the caller's view ids: ids beyond n_views (or, with n_views = 0,
+    beyond PGIH_MAX_VIEWS), decreasing offsets and null rows are refused with a message, before anything is allocated from
+    them; a well-formed call still works afterwards, takes a seed, and says so when most accepted guesses are quirk-only."""
+    from pyposegraphbuilder import PoseGraphBuilder, scenes as SC
+    b = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", True, True, True)
+    try:
+        lib, h = b._host()
+        src, dst = np.array([0, 1], np.uint32), np.array([1, 2], np.uint32)
+        sim, thr = np.array([0.9, 0.8]), np.array([7.5e-4, 7.5e-4])
+        off = np.array([0, 60, 120], np.uint64)
+        corr = np.zeros((120, 4))
+        edges = np.zeros(4, [("src", "<u4"), ("dst", "<u4"), ("score", "<f8"), ("R", "<f8", 9), ("t", "<f8", 3)])
+        n_edges = C.c_uint32(0)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+
+        def call(n_views, src_, dst_, off_, corr_ptr):
+            return lib.pgih_run_pairs(h, n_views, 2, ptr(src_), ptr(dst_), ptr(sim), ptr(thr), ptr(off_), corr_ptr, 64, 0, ptr(edges), 4,
+                                      C.byref(n_edges), None)
+        assert call(2, src, dst, off, ptr(corr)) < 0 and b"out of range" in lib.pgih_last_error()          # id 2 with n_views = 2
+        big = np.array([1, 0xFFFFFFFF], np.uint32)
+        assert call(0, src, big, off, ptr(corr)) < 0 and b"PGIH_MAX_VIEWS" in lib.pgih_last_error()       # derived count unbounded
+        assert call(3, src, dst, np.array([0, 60, 30], np.uint64), ptr(corr)) < 0 and b"offsets" in lib.pgih_last_error()
+        assert call(3, src, dst, off, None) < 0 and b"null" in lib.pgih_last_error()
+        assert call(3, src, dst, off, ptr(corr)) == 0 and n_edges.value == 0                                 # all-zero rows: no edge, no crash
+        # a real run through the Python class: seed accepted, rotationGuided keyword-only and not sticky, warning on quirk-only guesses
+        g, wave = SC.make_scene("v340_thin")
+        bt, simv = g["batch"], SC.pair_similarity(g)
+        pairs = []
+        for e, (i, j) in enumerate(g["pairs"]):
+            a, z = int(bt["offsets"][e]), int(bt["offsets"][e + 1])
+            pairs.append(dict(src=int(i), dst=int(j), similarity=float(simv[e]), threshold=7.5e-4,
+                              correspondences=np.stack([bt["x1"][a:z], bt["y1"][a:z], bt["x2"][a:z], bt["y2"][a:z]], 1)))
+        with pytest.raises(TypeError):
+            b.run(pairs, wave, 0, True)                      # rotationGuided cannot be passed positionally any more
+        capfd.readouterr()
+        g0 = b.run(pairs, waveSize=wave, seed=0, numViews=340)
+        err = capfd.readouterr().err
+        assert b.statistics["quirk_only_guesses"] * 20 > b.statistics["poses_from_guess"] and "setRotationGuidedGuesses" in err
+        g7 = b.run(pairs, waveSize=wave, seed=7)
+        assert set(g0) != set(g7) or any(not np.array_equal(g0[k]["R"], g7[k]["R"]) for k in g0 if k in g7)  # another seed, other draws
+        gg = b.run(pairs, waveSize=wave, rotationGuided=True)
+        assert b.statistics["quirk_only_guesses"] == 0
+        again = b.run(pairs, waveSize=wave, seed=0)          # the switch did not stick, the run is reproducible
+        assert set(again) == set(g0) and all(np.array_equal(again[k]["R"], g0[k]["R"]) and again[k]["score"] == g0[k]["score"] for k in g0)
+        assert len(gg) > 0
+    finally:
+        b.close()
