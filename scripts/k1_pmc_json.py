@@ -68,9 +68,11 @@ def main():
         # the same bench command without the profiler on the same lease (HIP events on the launch stream): what the profiled
         # average is to be reconciled with -- the profiler adds a few per cent
         "kernel_us_events_same_box": unprofiled_kernel_us(),
-        "launch_shape": "size-class launches are persistent grids (256 CUs x 4 resident workgroups pull pairs from the class's "
-                        "list); the empty <= 1344-row class of this workload is a grid of 1024 workgroups that exit at once -- "
-                        "round 3's 10 000-workgroup grid of that class (3.9 ms in the trace, overlapped) is gone",
+        "launch_shape": "size-class launches are persistent grids (256 CUs x 4 resident workgroups pull pairs from the class's list "
+                        "through an atomic head).  An EMPTY class still shows milliseconds in the kernel trace (estimate_pose_kernel<1, false> "
+                        "on this workload): its workgroups are queued on a side stream behind the other class's resident workgroups, which "
+                        "hold every LDS slot until their list runs dry -- the time is waiting for a slot, each workgroup exits at once "
+                        "when it gets one",
         "hbm_bytes_per_launch": round(fetch_b + write_b), "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]),
         "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
         "correction": "FETCH_SIZE x2 on gfx950 (64 B tallied per 128-B request); WRITE_SIZE as reported",

@@ -68,3 +68,40 @@ def test_wave_scheduler_with_astar_guesses(tmp_path):
     assert st1[2] > 0 and st1[3] > 0 and st1[5] > 0.3 * st1[3]
     assert st1[6] < 0.8 * st0[6]
     print("no-A*: %d hyps; A*: searched %d found %d used %d, %d hyps" % (st0[6], st1[2], st1[3], st1[5], st1[6]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["waves", "waves_guided"])
+def test_wave_scheduler_equals_the_cpu_restatement(tmp_path, mode):
+    """The whole scheduled run -- candidate order, waves, visibility, A* guesses on the committed graph, the 5-inlier
+    screening, estimatePose with and without guesses, commits -- against oracle/scheduler_oracle.py, a CPU-only restatement
+    built from the other oracles (A*, K2's scoring, pgo_estimate_pose_batch): every scheduler counter equal, the same edges in
+    the same order with the same scores, rotations and translations to 1e-9 (the decomposition's last bits differ between
+    device and oracle by <= 1e-13, which the chained guesses inherit)."""
+    import oracle_lib as O
+    import scheduler_oracle as SO
+    from pyposegraphbuilder import scenes as SC
+    V, wave = 80, 64
+    g = S.make_scene_graph(V, k=8, seed=5, outlier_pair_frac=0.03)
+    path = str(tmp_path / "scene.bin")
+    SC.write_scene(path, g, wave, sim_kind=2)
+    SC.run_ranks([SC.EXE, path, str(tmp_path / mode), mode], 1, extra_env={"PGI_QUIET": "1"})
+    stats, edges = SC.read_waves(open(str(tmp_path / mode) + ".0", "rb").read())
+    b, sim = g["batch"], SC.pair_similarity(g)
+    table = {}
+    pairs = []
+    for e, (i, j) in enumerate(g["pairs"]):
+        a, z = int(b["offsets"][e]), int(b["offsets"][e + 1])
+        table[(int(i), int(j))] = table[(int(j), int(i))] = float(sim[e])
+        pairs.append(dict(src=int(i), dst=int(j), similarity=float(sim[e]), thr=7.5e-4, x1=b["x1"][a:z], y1=b["y1"][a:z],
+                          x2=b["x2"][a:z], y2=b["y2"][a:z]))
+    lookup = lambda p, q: 1.0 if p == q else table.get((p, q), 0.0)
+    st, ref = SO.run_waves(O, pairs, lookup, V, wave, path_finding=True, rotation_guided=(mode == "waves_guided"))
+    for key in ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
+                "waves", "graph_edges", "quirk_only_guesses"):
+        assert stats[key] == st[key], (key, stats[key], st[key])
+    assert stats["paths_found"] > 0 and stats["poses_from_guess"] > 0 and stats["waves"] >= 3
+    assert len(edges) == len(ref)
+    for got, (s_, d_, score, R, t) in zip(edges, ref):
+        assert (int(got["src"]), int(got["dst"])) == (s_, d_) and got["score"] == score
+        assert np.abs(got["R"].reshape(3, 3) - R).max() < 1e-9 and np.abs(got["t"] - t).max() < 1e-9
