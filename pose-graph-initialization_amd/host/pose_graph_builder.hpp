@@ -206,6 +206,25 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         std::shared_lock<std::shared_mutex> l(mu);
         return edge_index.count({s, d}) != 0;
     }
+    // (s, d) or (d, s): the scheduler's "is this pair already an edge?" (pose_graph_builder.h:426-431) under one lock
+    bool hasEdgeBetween(ViewId s, ViewId d) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        return edge_index.count({s, d}) != 0 || edge_index.count({d, s}) != 0;
+    }
+    // both endpoints of a candidate pair (pose_graph.h addVertex twice), one lock
+    void addVertexPair(ViewId a, ViewId b) {
+        std::unique_lock<std::shared_mutex> l(mu);
+        for (const ViewId id : {a, b}) {
+            if (hasVertexUnlocked(id)) continue;
+            if (id < kDenseIds) {
+                if (id >= vertex_dense.size()) vertex_dense.resize(std::max<size_t>(id + 1, 2 * vertex_dense.size()), 0);
+                vertex_dense[id] = 1;
+            } else {
+                vertex_sparse.emplace(id, PoseGraphVertex(id));
+            }
+            ++vertex_count;
+        }
+    }
     // pose_graph.h:201-224: refused unless both vertices exist and the directed edge is new
     bool addEdge(ViewId s, ViewId d, const Pose& T, double score = 1.0) {
         std::unique_lock<std::shared_mutex> l(mu);
