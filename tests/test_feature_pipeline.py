@@ -181,3 +181,58 @@ def test_python_run_features_is_the_cpp_pipeline(tmp_path, rotationGuided):
         assert sum(b.stage_seconds.values()) > 0
     finally:
         b.close()
+
+
+def small_scene():
+    rng = np.random.default_rng(43)
+    views, poses, cam = S.make_feature_views(rng, n_views=8, n_points=1500, n_clutter=500, desc_noise=0.012)
+    V = len(views)
+    sim = np.zeros((V, V))
+    pairs = []
+    for i in range(V):
+        for j in range(i + 1, V):
+            shared = len(set(views[i]["point_id"][views[i]["point_id"] >= 0]) & set(views[j]["point_id"]))
+            sim[i, j] = sim[j, i] = round(0.2 + 0.7 * shared / 1500 + 0.001 * ((3 * i + j) % 7), 3)
+            pairs.append((i, j, sim[i, j]))
+    # one view with few keypoints: its first pair is descriptor-matched and committed; with epipolar hashing its later pairs find
+    # 30-51 tracklet matches -- quick pairs below kMinimumPointNumber, counted and skipped (:550-551), and one just above it
+    views[V - 1] = {k: v[:130] for k, v in views[V - 1].items()}
+    return views, poses, cam, sim, pairs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
+def test_feature_pipeline_equals_the_cpu_restatement(tmp_path, mode):
+    """The whole feature-level run -- quick matching from tracklets, descriptor matching, createCorrespondenceMatrix, A*
+    guesses and their screening, estimatePose, commits, guided matching on the new poses, tracklet updates -- against
+    oracle/pipeline_oracle.py, a CPU-only restatement over the other oracles: every counter equal, the same edges with the same
+    scores, poses to 1e-9 (the decomposition's last bits differ between device and oracle by <= 1e-13 and chained guesses
+    inherit them).  Modes: 1 path finding, 2 + epipolar hashing (tracklets in HBM), 3 the same with the host store, 4 with
+    rotation-guided re-estimation of the chained poses."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    import pipeline_oracle as PO
+    views, poses, cam, sim, pairs = small_scene()
+    wave = 4
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    SC.write_feature_scene(fin, views, cam, sim, pairs, wave)
+    r = subprocess.run([EXE, fin, fout, mode], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    (st, edges), = parse(open(fout, "rb").read(), 1)
+    got = dict(zip(SC.PIPELINE_KEYS, st))
+    lookup = lambda p, q: 1.0 if p == q else float(sim[p, q])
+    ref, ref_edges, fragile = PO.run_features(O, views, cam, pairs, lookup, wave, path_finding=True, hashing=mode != "1",
+                                              rotation_guided=mode == "4")
+    assert fragile == 0   # (no guided-matching row sat in the 1e-7 don't-care band of a bin edge; otherwise pick another seed)
+    for key in SC.PIPELINE_KEYS:
+        assert got[key] == ref[key], (key, got[key], ref[key])
+    assert got["waves"] >= 6 and got["paths_found"] > 0 and got["poses_from_guess"] > 0
+    if mode != "1":   # skipped quick pairs; guided matching cut at kMaximumPointNumberForEpipolarHashing on all pairs but one
+        assert got["too_few_matches"] >= 4 and got["quick_matching_runs"] > got["guided_matching_runs"] > 0 and got["track_number"] > 0
+        assert 100 * (got["guided_matching_runs"] - 1) <= got["guided_matches_added"] < 100 * got["guided_matching_runs"]
+    assert edges.keys() == ref_edges.keys() and len(edges) >= 21
+    for key, (sc, R, t) in edges.items():
+        rs, rR, rt = ref_edges[key]
+        assert sc == rs, key
+        assert np.abs(R.reshape(3, 3) - rR).max() < 1e-9 and np.abs(t - rt).max() < 1e-9, key
