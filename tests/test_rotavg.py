@@ -106,6 +106,56 @@ def test_hip_rotation_averaging_on_sequence_graphs(V, reach, comps, capfd, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,reach,comps", [(3000, 12, 1), (5000, 20, 1), (4000, 10, 2)])
+def test_hip_rotation_averaging_on_dense_band_graphs(V, reach, comps, capfd, monkeypatch):
+    """Band graphs too dense for the tree path (more than 8 edges per view) on which every Jacobi solve would run into the cap
+    -- config 4's shape: the breadth-first walk from the gauge view is deep, so the solver takes the two-level preconditioner
+    (aggregates of neighbouring views, coarse matrix inverted on the device per outer step) and SOLVES its systems, like the
+    oracle's sparse direct solves: same fixed point, as many outer iterations, the same bits twice."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_ROTAVG_TRACE", "1")
+    eng = Engine()
+    src, dst, Rrel, w, Rgt = sequence_graph(V, reach, 1.0, 0.05, seed=17, components=comps)
+    assert len(src) > 8 * V
+    R, iters = eng.rotation_average(src, dst, Rrel, w, V)
+    trace = capfd.readouterr().err
+    Ro, iters_o = RO.rotation_average(V, src, dst, Rrel, w)
+    d = np.einsum("kij,kmj->kim", R, Ro)
+    ang = np.arccos(np.clip((np.trace(d, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    two = [int(ln.split("):")[1].split()[0]) for ln in trace.splitlines() if "(two-level)" in ln]
+    print("V %d reach %d: %d outer iterations (oracle %d), max diff %.2e rad, two-level iterations %s" % (V, reach, iters, iters_o, ang.max(), two))
+    assert len(two) == iters and max(two[1:]) < 150   # (the first L1 step may still run into the cap of 200)
+    assert ang.max() < 1e-5, (ang.max(), iters, iters_o)
+    assert abs(iters - iters_o) <= 1 and iters < 40
+    R2, iters2 = eng.rotation_average(src, dst, Rrel, w, V)
+    assert iters2 == iters and np.array_equal(R, R2)
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,k,noise,outl,comps", [(50, 6, 1.0, 0.15, 1), (340, 20, 1.0, 0.2, 1), (30, 4, 0.5, 0.1, 3), (1500, 12, 2.0, 0.25, 1),
+                                                  (5000, 20, 1.0, 0.15, 1)])
+def test_two_level_solver_forced_on_well_conditioned_graphs(V, k, noise, outl, comps, monkeypatch):
+    """PGI_ROTAVG_TWO_LEVEL=2 sends every solve through the two-level kernels, also where Jacobi would do (random graphs, tiny
+    graphs with two or three aggregates, several components): the same answers as the oracle."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_ROTAVG_TWO_LEVEL", "2")
+    eng = Engine()
+    src, dst, Rrel, w, Rgt, _ = RO.make_graph(V, k, noise, outl, seed=7, components=comps)
+    R, iters = eng.rotation_average(src, dst, Rrel, w, V)
+    if V <= 1500:
+        Ro, iters_o = RO.rotation_average(V, src, dst, Rrel, w)
+        d = np.einsum("kij,kmj->kim", R, Ro)
+        ang = np.arccos(np.clip((np.trace(d, axis1=1, axis2=2) - 1) / 2, -1, 1))
+        assert ang.max() < 1e-5 and abs(iters - iters_o) <= 1, (ang.max(), iters, iters_o)
+    if comps == 1:
+        assert RO.align_error_deg(R, Rgt).mean() < max(0.5, noise)
+    R2, iters2 = eng.rotation_average(src, dst, Rrel, w, V)
+    assert iters2 == iters and np.array_equal(R, R2)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch):
     """5000 views x ~21 edges per view: the first L1 solve runs into the 200-iteration cap, but the spanning forest is a
     far worse preconditioner there (1 380 iterations against 19) -- the solver must not switch."""
@@ -115,7 +165,7 @@ def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch
     src, dst, Rrel, w, Rgt, _ = RO.make_graph(5000, 20, noise_deg=1.0, outlier_frac=0.15, seed=2)
     R, iters = eng.rotation_average(src, dst, Rrel, w, 5000)
     trace = capfd.readouterr().err
-    assert "(L1): 200 PCG" in trace and "): -" not in trace
+    assert "(L1): 200 PCG" in trace and "): -" not in trace and "two-level" not in trace
     assert iters <= 12 and RO.align_error_deg(R, Rgt).mean() < 0.5
     eng.close()
 
