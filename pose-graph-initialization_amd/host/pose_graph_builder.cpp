@@ -264,8 +264,10 @@ struct PoseGraphBuilder::Staging {
 
 size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
                                        std::vector<pgi_edge>* edges_out, bool screenGuesses, pgi_edge* d_edges_out,
-                                       const std::function<void(size_t, size_t)>* prepareGuesses) {
+                                       const std::function<void(size_t, size_t)>* prepareGuesses,
+                                       std::function<size_t()>* deferredInsertion) {
     const size_t P = pairs.size();
+    if (deferredInsertion) *deferredInsertion = nullptr;
     if (!P) return 0;
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t0 = Clock::now();
@@ -461,17 +463,26 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         d2h(guessInliers.data(), db + o_cnt, L * 4);
     }
     mark("download");
-    poseGraph_.reserveEdges(P);
     size_t added = 0, inliers = 0;
-    for (size_t i = 0; i < P; ++i) {
-        inliers += edges[i].n_inl;
-        if (edges[i].status != PGI_EDGE_OK) continue;  // caller `continue`s (pose_graph_builder.h:641-642)
-        SE3d T;
-        for (int c = 0; c < 9; ++c) T.R[c] = edges[i].R[c];
-        for (int c = 0; c < 3; ++c) T.t[c] = edges[i].t[c];
-        const double score = (double)edges[i].n_inl / (double)std::max(1, pairs[i].correspondences.rows);
-        poseGraph_.addEdge(pairs[i].src, pairs[i].dst, Pose(T), score);  // :645-654
-        ++added;
+    for (size_t i = 0; i < P; ++i) inliers += edges[i].n_inl;
+    // the edges in pair order (pose_graph_builder.h:645-654; a failed pair is skipped, :641-642), one locked batch
+    auto insertAll = [&pairs, &poseGraph_, P](const std::vector<pgi_edge>& e) {
+        std::vector<PoseGraph::NewEdge> items;
+        items.reserve(P);
+        for (size_t i = 0; i < P; ++i) {
+            if (e[i].status != PGI_EDGE_OK) continue;
+            items.push_back(PoseGraph::NewEdge{pairs[i].src, pairs[i].dst, (double)e[i].n_inl / (double)std::max(1, pairs[i].correspondences.rows),
+                                               e[i].R, e[i].t});
+        }
+        poseGraph_.addEdges(items.data(), items.size());
+        return items.size();
+    };
+    if (deferredInsertion && edges_out) {
+        // The caller runs it -- on another thread, next to the rotation averaging, which reads the DEVICE table and never the
+        // host graph -- and joins before it returns; *edges_out holds the records by then (moved below) and outlives the call.
+        *deferredInsertion = [insertAll, edges_out]() { return insertAll(*edges_out); };
+    } else {
+        added = insertAll(edges);
     }
     mark("pose graph insertion");
     // Guard for the reference-faithful guess path (guess_quirk = 1, graph_traversal.h:149,164): a chained pose passes the
@@ -514,7 +525,24 @@ PoseGraphBuilder::GlobalRotations PoseGraphBuilder::estimateAndAverage(const std
         poseGraph_.addVertex(vp.dst);
     }
     DevBuf table(P * sizeof(pgi_edge));
-    estimatePoses(pairs, poseGraph_, seed, edges_out, false, table.as<pgi_edge>());
+    // The pose graph is filled on a second thread WHILE the device averages the rotations (10^5 edges: 0.03 s of host work
+    // -- 200-byte records into fresh memory -- next to 0.02 s of averaging that reads only the device table).
+    std::vector<pgi_edge> edgesLocal;
+    std::vector<pgi_edge>* edgesHeld = edges_out ? edges_out : &edgesLocal;
+    std::function<size_t()> insertion;
+    estimatePoses(pairs, poseGraph_, seed, edgesHeld, false, table.as<pgi_edge>(), nullptr, &insertion);
+    double insertSeconds = 0;
+    std::thread inserter;
+    if (insertion)
+        inserter = std::thread([&]() {
+            const std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+            insertion();
+            insertSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+        });
+    struct Join {
+        std::thread& t;
+        ~Join() { if (t.joinable()) t.join(); }
+    } join{inserter};
     std::vector<uint32_t> src(P), dst(P), rows(P);
     for (size_t i = 0; i < P; ++i) {
         src[i] = (uint32_t)pairs[i].src;
@@ -527,6 +555,8 @@ PoseGraphBuilder::GlobalRotations PoseGraphBuilder::estimateAndAverage(const std
                                              (uint32_t)numViews, rotavgParams, out.rotations[0].data(), &out.iterations,
                                              &out.edgesUsed));
     statistics.addTime("[Rotation averaging]", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_avg).count(), 1);
+    if (inserter.joinable()) inserter.join();
+    statistics.addTime("[Pose estimation] pose graph insertion (beside the averaging)", insertSeconds, 1);
     return out;
 }
 

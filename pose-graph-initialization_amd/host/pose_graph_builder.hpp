@@ -237,6 +237,50 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         neighboursForUpdate(d).push_back(Neighbour{s, score, k});
         return true;
     }
+    // A wave of edges under ONE lock, each with addEdge's rule (both vertices present, id not yet there); returns how many went
+    // in.  The per-vertex lists are grown once for the whole wave (at 10^5 edges and ~40 per view, one addEdge per edge spent
+    // most of its 0.3 us on the lock and on re-housing those lists).
+    struct NewEdge {
+        ViewId src, dst;
+        double score;
+        const double* R;  // 9, row-major
+        const double* t;  // 3
+    };
+    size_t addEdges(const NewEdge* items, size_t n) {
+        std::unique_lock<std::shared_mutex> l(mu);
+        const size_t want = edge_store.size() + n;
+        if (want > edge_store.capacity()) edge_store.reserve(std::max(want, 2 * edge_store.capacity()));
+        edge_index.reserve(want);
+        degree_scratch.clear();
+        for (size_t i = 0; i < n; ++i)
+            for (ViewId v : {items[i].src, items[i].dst})
+                if (v < kDenseIds) {
+                    if (v >= degree_scratch.size()) degree_scratch.resize(std::max<size_t>(v + 1, 2 * degree_scratch.size()), 0);
+                    ++degree_scratch[v];
+                }
+        if (degree_scratch.size() > adjacency_dense.size()) adjacency_dense.resize(degree_scratch.size());
+        for (size_t v = 0; v < degree_scratch.size(); ++v)
+            if (degree_scratch[v]) {
+                std::vector<Neighbour>& nb = adjacency_dense[v];
+                if (nb.size() + degree_scratch[v] > nb.capacity()) nb.reserve(std::max<size_t>(nb.size() + degree_scratch[v], 2 * nb.capacity()));
+            }
+        size_t added = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const ViewId s = items[i].src, d = items[i].dst;
+            if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) continue;
+            if (s == 0xFFFFFFFFull && d == 0xFFFFFFFFull) continue;
+            const uint32_t k = (uint32_t)edge_store.size();
+            if (!edge_index.insert(EdgeId{s, d}, k)) continue;
+            SE3d T;
+            for (int c = 0; c < 9; ++c) T.R[c] = items[i].R[c];
+            for (int c = 0; c < 3; ++c) T.t[c] = items[i].t[c];
+            edge_store.emplace_back(s, d, Pose(T), items[i].score);
+            neighboursForUpdate(s).push_back(Neighbour{d, items[i].score, k});
+            neighboursForUpdate(d).push_back(Neighbour{s, items[i].score, k});
+            ++added;
+        }
+        return added;
+    }
     // room for n more edges (one rehash instead of a dozen while a wave of 10^4 edges is committed)
     void reserveEdges(size_t n) {
         std::unique_lock<std::shared_mutex> l(mu);
@@ -400,6 +444,7 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     };
     EdgeIndex edge_index;
     std::vector<std::vector<Neighbour>> adjacency_dense;           // per vertex, insertion order
+    std::vector<uint32_t> degree_scratch;                          // addEdges: new edges per vertex of the wave
     std::unordered_map<ViewId, std::vector<Neighbour>> adjacency_sparse;
 };
 
@@ -565,10 +610,14 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // prepareGuesses (optional): called on the host with ranges [first, last) of `pairs` -- this rank's launch groups, in
     // order -- before the range's rows are staged; it may fill poseGuesses of exactly those pairs (the scheduler runs its A*
     // searches there, so that they overlap the device's work on the previous group).
+    // deferredInsertion (optional, needs edges_out): the edges are NOT put into poseGraph_; the function receives the closure
+    // that does it (returns the number of edges; reads *edges_out, pairs and poseGraph_, which must outlive it) -- for a caller
+    // with device work of its own to run meanwhile (estimateAndAverage).  The return value is 0 then.
     size_t estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed = 0,
                          std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false,
                          pgi_edge* d_edges_out = nullptr,
-                         const std::function<void(size_t, size_t)>* prepareGuesses = nullptr);
+                         const std::function<void(size_t, size_t)>* prepareGuesses = nullptr,
+                         std::function<size_t()>* deferredInsertion = nullptr);
 
     // BASELINE config 4: shard -> estimate -> gather -> replicated L1/IRLS rotation averaging; the gathered records
     // stay in HBM between the exchange and the solve.  R_i are world->camera, one per view id < numViews.
