@@ -166,6 +166,9 @@ int main(int argc, char** argv) {
             in.read((char*)&s, 8);
             if (i < j) sim.setSimilarity(i, j, s);
         }
+    std::vector<PoseGraph::NewEdge> batch;
+    std::vector<Matrix3d> batch_R;
+    std::vector<Vector3d> batch_t;
     for (uint32_t e = 0; e < E; ++e) {
         uint32_t s, d;
         SE3d T;
@@ -173,6 +176,34 @@ int main(int argc, char** argv) {
         in.read((char*)&s, 4); in.read((char*)&d, 4);
         in.read((char*)T.R.data(), 72); in.read((char*)T.t.data(), 24); in.read((char*)&score, 8);
         g.addEdge(s, d, Pose(T), score);
+        batch_R.push_back(T.R); batch_t.push_back(T.t);
+        batch.push_back(PoseGraph::NewEdge{s, d, score, nullptr, nullptr});
+    }
+    {   // the same edges through addEdges (one locked batch per half, as the wave scheduler commits them) -- with an edge
+        // given twice and one to a vertex the graph does not have, both of which must be refused like addEdge refuses them
+        PoseGraph g2;
+        for (uint32_t v = 0; v < V; ++v) g2.addVertex(v);
+        for (size_t i = 0; i < batch.size(); ++i) { batch[i].R = batch_R[i].data(); batch[i].t = batch_t[i].data(); }
+        std::vector<PoseGraph::NewEdge> first(batch.begin(), batch.begin() + batch.size() / 2), second(batch.begin() + batch.size() / 2, batch.end());
+        if (!first.empty()) second.push_back(first[0]);
+        if (!batch.empty()) second.push_back(PoseGraph::NewEdge{V + 7, 0, 0.5, batch_R[0].data(), batch_t[0].data()});
+        const size_t added = g2.addEdges(first.data(), first.size()) + g2.addEdges(second.data(), second.size());
+        bool same = added == g.numEdges() && g2.numEdges() == g.numEdges() && g2.getEdgeIds() == g.getEdgeIds();
+        for (uint32_t v = 0; v < V && same; ++v) {
+            std::vector<EdgeId> a, b;
+            const bool ha = g.getEdgesByVertex(v, a), hb = g2.getEdgesByVertex(v, b);
+            same = ha == hb && a == b;
+        }
+        for (const EdgeId& id : g.getEdgeIds()) {
+            const PoseGraphEdge ea = g.getEdgeById(id), eb = g2.getEdgeById(id);
+            same = same && ea.getScore() == eb.getScore() && ea.getValue().getRotation() == eb.getValue().getRotation() &&
+                   ea.getValue().getTranslation() == eb.getValue().getTranslation() &&
+                   ea.getValue().getEssentialMatrix() == eb.getValue().getEssentialMatrix();
+        }
+        if (!same) {
+            std::fprintf(stderr, "addEdges differs from addEdge\n");
+            return 5;
+        }
     }
     ImageSimilarityHeuristics h(sim);
     AStarTraversal<ImageSimilarityHeuristics> astar(&g, h, weight, 0.0, depth);
