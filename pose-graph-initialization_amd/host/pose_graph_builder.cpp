@@ -834,10 +834,16 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         }
         staging->reserve(0, largestRun, 0);
         hipStream_t copy = staging->copy;
+        // (where the host's time goes: printed with PGI_PIPELINE_TIMING, and whenever the stage is far slower than PCIe allows)
+        auto nowS = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tWait = 0, tStage = 0, tPrep = 0;
         for (size_t r = 0; r < runs.size(); ++r) {
             const Run& run = runs[r];
             const int slot = (int)(r % Staging::kRing);
+            double tm = nowS();
             if (r >= (size_t)Staging::kRing) HIP_OK(hipEventSynchronize(staging->up[slot]));
+            tWait += nowS() - tm;
+            tm = nowS();
             char* const hb = (char*)staging->ring[slot];
             const size_t begin = lay[run.v0].xy, end = run.v1 < V ? lay[run.v1].xy : rawBytes;
             // pieces of at most 1 MB, so that the team shares a run evenly whatever the views' sizes
@@ -866,15 +872,24 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             }
             HIP_OK(hipEventRecord(staging->up[slot], copy));
             HIP_OK(hipStreamWaitEvent(nullptr, staging->up[slot], 0));  // the engine works on the default stream
+            tStage += nowS() - tm;
+            tm = nowS();
             for (size_t v = run.v0; v < run.v1; ++v) {
                 const uint32_t n = (uint32_t)views[v].size();
                 Engine::check(pgi_desc_prepare(ctx, featView[v].d_desc, n, const_cast<float*>(descView[v].d_desc_t), const_cast<float*>(descView[v].d_norm)));
                 Engine::check(pgi_desc_prepare_screen(ctx, featView[v].d_desc, n, const_cast<float*>(descView[v].d_desc_rm),
                                                       const_cast<uint16_t*>(descView[v].d_desc_f16)));
             }
+            tPrep += nowS() - tm;
         }
+        double tm = nowS();
         Engine::check(pgi_synchronize(ctx));
         HIP_OK(hipStreamSynchronize(copy));
+        const double tDrain = nowS() - tm, all = tWait + tStage + tPrep + tDrain;
+        if (std::getenv("PGI_PIPELINE_TIMING") || all > 0.1 + rawBytes / 10.0e9)
+            std::fprintf(stderr, "[processFeatures] upload of %.2f GB in %zu runs: waiting for a ring buffer %.3f s, host copies into the ring + copy "
+                                 "calls %.3f s, preparation launches %.3f s, waiting for the device at the end %.3f s\n",
+                         rawBytes / 1e9, runs.size(), tWait, tStage, tPrep, tDrain);
     }
     Engine::check(pgi_synchronize(ctx));
     st.secUpload = std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count();
