@@ -668,7 +668,8 @@ def main():
                 del fviews
                 import subprocess
                 r = subprocess.run([SC.PIPELINE_EXE, fin, fout, "024"], capture_output=True, text=True, timeout=1200,
-                                   env=dict(os.environ, PGI_DRIVER_REPS="3"))
+                                   env=dict(os.environ, PGI_DRIVER_REPS="4"))
+                slow = [ln for ln in r.stderr.splitlines() if "[processFeatures] upload of" in ln]
                 feat = {"views": 340, "keypoints_per_view": round(kp_mean), "candidate_pairs": len(fpairs), "wave": 512,
                         "descriptor_bytes": int(340 * kp_mean * 512), "generation_s": round(gen_f, 1)}
                 if r.returncode == 0:
@@ -679,6 +680,7 @@ def main():
                         kf = dict(zip(SC.PIPELINE_KEYS, stf))
                         errf = np.array([S.rot_err_deg(ef[key][1], fposes[key[1]][0] @ fposes[key[0]][0].T) for key in ef])
                         feat[label] = {"features_to_graph_s": tim[mode]["seconds"], "all_repetitions_s": tim[mode]["all_seconds"],
+                                       "repetition_reported": tim[mode]["repetition"],  # the median of the warm repetitions
                                        "stages_s": tim[mode]["stages"],
                                        "pairs_per_s": round(len(fpairs) / tim[mode]["seconds"], 1), "edges": len(ef),
                                        "descriptor_matching_runs": kf["matching_runs"], "tracklet_quick_matching_runs": kf["quick_matching_runs"],
@@ -686,6 +688,8 @@ def main():
                                        "poses_from_guess": kf["poses_from_guess"], "quirk_only_guesses": kf["quirk_only_guesses"],
                                        "edge_rot_err_auc_at_5deg": round(S.auc_at(np.concatenate([errf, np.full(len(fpairs) - len(ef), np.inf)]), 5.0), 4),
                                        "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
+                    if slow:  # the upload stage reports itself when it is far slower than PCIe allows (a shared box now and then)
+                        feat["slow_uploads"] = slow[:6]
                 else:
                     feat["error"] = r.stderr[-500:]
             out["config3_from_features"] = feat
