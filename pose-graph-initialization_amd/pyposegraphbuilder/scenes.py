@@ -153,21 +153,40 @@ def read_waves(blob):
     return dict(zip(WAVES_KEYS, st)), np.frombuffer(blob, rec, n, 8 * len(WAVES_KEYS))
 
 
-def seconds_of(stdout):
-    """the driver's own wall clock: (graph seconds, rotation-averaging seconds)"""
+def _repetitions(stdout):
+    """[(graph seconds, rotation-averaging seconds)] per repetition of the driver (PGI_DRIVER_REPS), and the index of the one
+    reported: the median of the warm repetitions (all but the first, which allocates) by total time"""
     import re
-    lines = [ln for ln in stdout.splitlines() if "seconds:" in ln]  # the last repetition (PGI_DRIVER_REPS) is the warm one
-    vals = re.findall(r"(?<![\w.])\d+\.\d+(?![\w.])", lines[-1].split("seconds:")[1])
-    return float(vals[0]), float(vals[1])
+    reps = []
+    for ln in stdout.splitlines():
+        if "seconds:" in ln:
+            vals = re.findall(r"(?<![\w.])\d+\.\d+(?![\w.])", ln.split("seconds:")[1])
+            reps.append((float(vals[0]), float(vals[1])))
+    warm = list(range(1, len(reps))) if len(reps) > 1 else [0]
+    k = sorted(warm, key=lambda i: reps[i][0] + reps[i][1])[(len(warm) - 1) // 2]
+    return reps, k
+
+
+def seconds_of(stdout):
+    """the driver's own wall clock: (graph seconds, rotation-averaging seconds) of the median warm repetition"""
+    reps, k = _repetitions(stdout)
+    return reps[k]
+
+
+def all_seconds_of(stdout):
+    """graph + rotation-averaging seconds of every repetition, in order"""
+    return [round(a + b, 4) for a, b in _repetitions(stdout)[0]]
 
 
 def stages_of(stdout):
-    """the driver's `stages:` line of the last repetition: {RunningStatistics time key: seconds}"""
+    """the driver's `stages:` line of the repetition seconds_of reports: {RunningStatistics time key: seconds}"""
     import re
     lines = [ln for ln in stdout.splitlines() if ln.startswith("stages:")]
     if not lines:
         return {}
-    return {k.strip(): float(v) for k, v in re.findall(r"([^=;]+)=([0-9.]+);", lines[-1][len("stages:"):])}
+    reps, k = _repetitions(stdout)
+    line = lines[k] if len(lines) == len(reps) else lines[-1]
+    return {k2.strip(): float(v) for k2, v in re.findall(r"([^=;]+)=([0-9.]+);", line[len("stages:"):])}
 
 
 # ---- feature-level scenes (tests/cpp/test_pipeline.cpp: PoseGraphBuilder::processFeatures) -------------------------------------

@@ -82,5 +82,17 @@ def test_driver_output_parsers():
            "stages: [A*]=0.0123; [Pose estimation]=0.0450; [Pose estimation] convert + upload + launch (chunks)=0.0012;\n"
            "rank 0/1 transport none mode shard edges 15011 rotavg iters 10 | seconds: estimate + gather + average 0.0500, rotation averaging 0.0100\n"
            "stages: [A*]=0.0100; [Rotation averaging]=0.0200;\n")
-    assert SC.seconds_of(out) == (0.05, 0.01)                          # the last repetition
+    assert SC.seconds_of(out) == (0.05, 0.01)                          # two repetitions: the warm one
     assert SC.stages_of(out) == {"[A*]": 0.01, "[Rotation averaging]": 0.02}
+    # four repetitions: the median of the three warm ones (an outlier, wherever it falls, is listed but not reported)
+    more = out + ("rank 0/1 ... | seconds: estimate + gather + average 0.4000, rotation averaging 0.0100\nstages: [A*]=0.3000;\n"
+                  "rank 0/1 ... | seconds: estimate + gather + average 0.0550, rotation averaging 0.0100\nstages: [A*]=0.0150;\n")
+    assert SC.seconds_of(more) == (0.055, 0.01) and SC.stages_of(more) == {"[A*]": 0.015}
+    assert SC.all_seconds_of(more) == [0.06, 0.06, 0.41, 0.065]
+    pipe = ("mode 4: 10 pairs -> 9 edges in 0.300 s (x)\n        seconds: upload + prepare 0.100, A* 0.004\n"
+            "mode 4: 10 pairs -> 9 edges in 0.171 s (x)\n        seconds: upload + prepare 0.027, A* 0.004\n"
+            "mode 4: 10 pairs -> 9 edges in 0.491 s (x)\n        seconds: upload + prepare 0.343, A* 0.004\n"
+            "mode 4: 10 pairs -> 9 edges in 0.175 s (x)\n        seconds: upload + prepare 0.029, A* 0.004\n")
+    t = SC.pipeline_timings(pipe)[4]
+    assert t["seconds"] == 0.175 and t["repetition"] == 3 and t["stages"]["upload + prepare"] == 0.029
+    assert t["all_seconds"] == [0.3, 0.171, 0.491, 0.175]
