@@ -138,8 +138,67 @@ static int shards(char** argv) {
     return 0;
 }
 
+// "graphops" mode of tests/cpp/test_astar.cpp: a script of PoseGraph operations in, their results out
+static int graphops(char** argv) {
+    std::ifstream in(argv[2]);
+    std::ofstream out(argv[3]);
+    PoseGraph g;
+    std::string op;
+    auto poseOf = [](double score) {
+        SE3d T;
+        T.t = {{score, 2.0 * score, -score}};
+        return T;
+    };
+    while (in >> op) {
+        if (op == "V") {
+            ViewId v; in >> v;
+            out << (g.addVertex(v) ? 1 : 0) << "\n";
+        } else if (op == "P") {
+            ViewId a, b; in >> a >> b;
+            g.addVertexPair(a, b);
+            out << g.numVertices() << "\n";
+        } else if (op == "E") {
+            ViewId s, d; double sc; in >> s >> d >> sc;
+            out << (g.addEdge(s, d, Pose(poseOf(sc)), sc) ? 1 : 0) << "\n";
+        } else if (op == "B") {
+            size_t n; in >> n;
+            std::vector<PoseGraph::NewEdge> items(n);
+            std::vector<SE3d> poses(n);
+            for (size_t i = 0; i < n; ++i) {
+                in >> items[i].src >> items[i].dst >> items[i].score;
+                poses[i] = poseOf(items[i].score);
+            }
+            for (size_t i = 0; i < n; ++i) { items[i].R = poses[i].R.data(); items[i].t = poses[i].t.data(); }
+            out << g.addEdges(items.data(), n) << "\n";
+        } else if (op == "H") {
+            ViewId s, d; in >> s >> d;
+            out << (g.hasEdge(s, d) ? 1 : 0) << " " << (g.hasEdgeBetween(s, d) ? 1 : 0) << "\n";
+        } else if (op == "G") {
+            ViewId s, d; in >> s >> d;
+            const PoseGraphEdge e = g.getEdgeById({s, d});
+            if (e.isUndefined()) out << "none\n";
+            else out << e.getSourceId() << " " << e.getDestinationId() << " " << e.getScore() << " " << e.getValue().getTranslation()[1] << "\n";
+        } else if (op == "N") {
+            ViewId v; in >> v;
+            std::vector<EdgeId> ids;
+            const bool has = g.getEdgesByVertex(v, ids);
+            out << (has ? 1 : 0) << " " << g.getEdgeNumberByVertex(v);
+            for (const EdgeId& id : ids) out << " " << id.first << ":" << id.second;
+            out << "\n";
+        } else if (op == "I") {
+            out << g.numVertices() << " " << g.numEdges();
+            for (const EdgeId& id : g.getEdgeIds()) out << " " << id.first << ":" << id.second;
+            out << "\n";
+        } else {
+            return 3;
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 7 && std::string(argv[1]) == "formats") return formats(argv);
+    if (argc >= 4 && std::string(argv[1]) == "graphops") return graphops(argv);
     if (argc >= 4 && std::string(argv[1]) == "tracklets") return tracklets(argv);
     if (argc >= 3 && std::string(argv[1]) == "hostcomm") {
         try {

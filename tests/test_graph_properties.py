@@ -1,0 +1,94 @@
+"""PoseGraph (host/pose_graph_builder.hpp: flat edge array, open-addressing index, per-vertex neighbour lists) against the
+dictionary model of oracle/astar_oracle.py under RANDOM operation sequences (hypothesis): addVertex / addVertexPair / addEdge /
+addEdges batches / lookups, over small ids (collisions, duplicates, refusals), ids beyond 2^22 (the hash-map side of the vertex
+table) and beyond 2^32 (the std::unordered_map side of the edge index)."""
+import os
+import subprocess
+import sys
+
+from hypothesis import given, settings, strategies as st
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_astar")
+
+IDS = st.one_of(st.integers(0, 7), st.sampled_from([4194303, 4194304, 4194310, 2 ** 32 - 1, 2 ** 32 + 5, 2 ** 33 + 1]))
+SCORE = st.integers(1, 999).map(lambda k: k / 1000.0)
+EDGE = st.tuples(IDS, IDS, SCORE)
+OP = st.one_of(st.tuples(st.just("V"), IDS), st.tuples(st.just("P"), IDS, IDS), st.tuples(st.just("E"), EDGE),
+               st.tuples(st.just("B"), st.lists(EDGE, min_size=0, max_size=12)), st.tuples(st.just("H"), IDS, IDS),
+               st.tuples(st.just("G"), IDS, IDS), st.tuples(st.just("N"), IDS), st.tuples(st.just("I")))
+
+
+class Model:
+    def __init__(self):
+        self.vertices, self.edges, self.order, self.by_vertex = set(), {}, [], {}
+
+    def add_edge(self, s, d, sc):
+        if s not in self.vertices or d not in self.vertices or (s, d) in self.edges:
+            return False
+        if s == d == 2 ** 32 - 1:   # the one pair whose packed key is the index's empty mark: refused (pose_graph_builder.hpp)
+            return False
+        self.edges[(s, d)] = sc
+        self.order.append((s, d))
+        self.by_vertex.setdefault(s, []).append((s, d))
+        self.by_vertex.setdefault(d, []).append((s, d))
+        return True
+
+    def run(self, op):
+        k = op[0]
+        if k == "V":
+            new = op[1] not in self.vertices
+            self.vertices.add(op[1])
+            return "1" if new else "0"
+        if k == "P":
+            self.vertices.update(op[1:3])
+            return str(len(self.vertices))
+        if k == "E":
+            return "1" if self.add_edge(*op[1]) else "0"
+        if k == "B":
+            return str(sum(1 for e in op[1] if self.add_edge(*e)))
+        if k == "H":
+            s, d = op[1], op[2]
+            return "%d %d" % ((s, d) in self.edges, (s, d) in self.edges or (d, s) in self.edges)
+        if k == "G":
+            s, d = op[1], op[2]
+            if (s, d) not in self.edges:
+                return "none"
+            sc = self.edges[(s, d)]
+            return "%d %d %s %s" % (s, d, repr_cpp(sc), repr_cpp(2.0 * sc))
+        if k == "N":
+            lst = self.by_vertex.get(op[1], [])
+            return " ".join(["1" if lst else "0", str(len(lst))] + ["%d:%d" % e for e in lst])
+        return " ".join([str(len(self.vertices)), str(len(self.order))] + ["%d:%d" % e for e in self.order])
+
+
+def repr_cpp(x):
+    return "%g" % x   # std::ostream's default formatting of a double
+
+
+def script(ops):
+    lines = []
+    for op in ops:
+        if op[0] == "E":
+            lines.append("E %d %d %r" % op[1])
+        elif op[0] == "B":
+            lines.append("B %d" % len(op[1]))
+            lines += ["%d %d %r" % e for e in op[1]]
+        else:
+            lines.append(" ".join(str(x) for x in op))
+    return "\n".join(lines) + "\n"
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(OP, min_size=1, max_size=60))
+def test_pose_graph_equals_the_dictionary_model(tmp_path_factory, ops):
+    d = tmp_path_factory.mktemp("graphops")
+    fin, fout = str(d / "ops.txt"), str(d / "out.txt")
+    open(fin, "w").write(script(ops))
+    r = subprocess.run([EXE, "graphops", fin, fout], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = open(fout).read().splitlines()
+    m = Model()
+    want = [m.run(op) for op in ops]
+    assert got == want
