@@ -73,6 +73,14 @@ def test_config4_sharded_estimate_gather_average(scene):
         S.auc_at(np.where(ok, np.array([S.rot_err_deg(edges["R"][e].reshape(3, 3), g["batch"]["R"][e]) for e in range(P)]), np.inf)[~g["wrong"]], 5.0),
         gerr.mean()))
     assert gerr.mean() < (1.5 if scene["name"] == "v5000_ring" else 0.5)
+    if V <= 340:
+        # ... and they are the oracle's for these edges (sparse direct solves; weight = inliers / rows as estimateAndAverage sets it)
+        rows = np.diff(g["batch"]["offsets"].astype(np.int64))
+        Ro, iters_o = RO.rotation_average(V, g["pairs"][ok, 0], g["pairs"][ok, 1], edges["R"][ok].reshape(-1, 3, 3),
+                                          edges["n_inl"][ok] / np.maximum(rows[ok], 1))
+        dR = np.einsum("kij,kmj->kim", _rotations(single, V), Ro)
+        ang = np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1))
+        assert ang.max() < 1e-5 and abs(int(hdr[2]) - iters_o) <= 1, (ang.max(), hdr[2], iters_o)
     # uneven blocks really happened (row-balanced cut of ragged pairs)
     from pyposegraphbuilder import distributed as D
     lo_hi = D.shard_bounds(np.diff(g["batch"]["offsets"].astype(np.int64)), 2)
