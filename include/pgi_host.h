@@ -35,6 +35,11 @@ typedef struct {           /* one edge of the resulting pose graph (pose_graph.h
                             * waves, graph edges, quirk-only guesses, rest 0 */
 
 const char* pgih_last_error(void);
+/* One process per GPU: restricts the calling thread -- and every thread it starts later -- to the CPUs of the NUMA node the
+ * HIP device hangs on (device < 0: the current one), what `numactl --cpunodebind` does in a launcher; memory touched first
+ * afterwards lands on that node.  Call it before the inputs are read.  Returns the node, or -1 when nothing was done (one node,
+ * sysfs unreadable, refused by a cpuset, PGI_HOST_NUMA=0).  Never an error. */
+int pgih_bind_process_to_device_node(int device);
 pgih_builder* pgih_create(const pgih_config* cfg);   /* NULL on failure (no HIP device: there is no CPU fallback) */
 void pgih_destroy(pgih_builder* b);
 /* pgi_params.guess_mode of the builder's engine: 1 = rotation-guided re-estimation of chained poses (BASELINE config 5) */

@@ -56,6 +56,12 @@ extern "C" {
 
 const char* pgih_last_error(void) { return g_error.c_str(); }
 
+int pgih_bind_process_to_device_node(int device) {
+    int node = -1;
+    guarded("pgih_bind_process_to_device_node", [&]() { node = reconstruction::PoseGraphBuilder::bindProcessToDeviceNode(device); return 0; });
+    return node;
+}
+
 pgih_builder* pgih_create(const pgih_config* c) {
     if (!c) {
         g_error = "pgih_create: null configuration";

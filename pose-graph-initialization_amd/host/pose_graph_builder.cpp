@@ -14,6 +14,9 @@
 #include <cstring>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
+
 namespace reconstruction {
 
 namespace {
@@ -123,6 +126,58 @@ void PoseGraphBuilder::warnQuirkOnlyGuesses(size_t quirkOnly, size_t acceptedGue
 
 // A few host threads that stay alive between calls (the reference's kCoreNumber OpenMP team, pose_graph_builder.h:391-392):
 // run(n, fn) calls fn(i) for i in [0, n) in contiguous, equally sized index ranges, the caller taking the first.
+// The CPUs of the NUMA node a HIP device hangs on (sysfs; empty when that cannot be told)
+static std::vector<int> deviceLocalCpus(int dev, int* node_out) {
+    std::vector<int> cpus;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return cpus; }
+    for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    int node = -1;
+    if (std::FILE* f = std::fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node_out) *node_out = node;
+    if (node < 0) return cpus;
+    char path[96];
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    std::FILE* f = std::fopen(path, "r");
+    if (!f) return cpus;
+    int a = 0, b = 0;
+    while (std::fscanf(f, "%d", &a) == 1) {  // "0-63,128-191"
+        b = a;
+        int ch = std::fgetc(f);
+        if (ch == '-') {
+            if (std::fscanf(f, "%d", &b) != 1) break;
+            ch = std::fgetc(f);
+        }
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) cpus.push_back(c);
+        if (ch != ',') break;
+    }
+    std::fclose(f);
+    return cpus;
+}
+
+// What `numactl --cpunodebind` does for a one-process-per-GPU launch: the calling thread (and every thread it starts later:
+// the host team, the runtime's helpers) may only run on the CPUs of the NUMA node the device hangs on, and the memory it
+// touches first lands there.  The builder's host side reads the caller's matrices, writes the page-locked ring and drives
+// the copy engine: on a two-socket host, a process living on the far socket ran config 5 of the dense V = 5000 scene in
+// 0.16-0.18 s against 0.14 s (scripts/numa_probe.sh; binding only the team's workers changed nothing -- the data and the
+// calling thread are what matters).  Call it FIRST, before the inputs are read.  Returns the node, -1 when nothing was done
+// (single node, sysfs unreadable, refused by a cpuset, PGI_HOST_NUMA=0).
+int PoseGraphBuilder::bindProcessToDeviceNode(int device) {
+    if (const char* e = std::getenv("PGI_HOST_NUMA")) if (e[0] == '0') return -1;
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    int node = -1;
+    const std::vector<int> cpus = deviceLocalCpus(dev, &node);
+    if (cpus.empty()) return -1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    return sched_setaffinity(0, sizeof set, &set) == 0 ? node : -1;
+}
+
 class HostPool {
    public:
     explicit HostPool(size_t threads) {

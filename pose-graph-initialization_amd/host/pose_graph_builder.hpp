@@ -711,6 +711,9 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // the reference's `RunningStatistics statistics` (pose_graph_builder.h:385): filled by run / processFeatures with
     // the reference's key names, printed by run(Reconstruction&, PoseGraph&) like :712
     RunningStatistics& getStatistics() { return statistics; }
+    // One process per GPU: keep this process on the CPUs (and, by first touch, the memory) of the NUMA node the device hangs
+    // on -- call it before the inputs are read.  device < 0: the current HIP device.  Returns the node or -1 (see the .cpp).
+    static int bindProcessToDeviceNode(int device = -1);
     // BASELINE config 5: use the A* chain's ROTATION only and re-estimate the translation direction on the GPU
     // (pgi_params.guess_mode = 1) instead of the reference's score -> refit of the chained pose (mode 0).  The chained
     // translation is a sum of unit baselines and therefore meaningless; with this switch on, run() hands every chained

@@ -11,7 +11,7 @@ def __getattr__(name):  # torch-dependent parts are imported lazily
     if name in ("Engine",):
         from .engine import Engine
         return Engine
-    if name in ("PoseGraphBuilder", "findEssentialMatrix"):
+    if name in ("PoseGraphBuilder", "findEssentialMatrix", "bindProcessToDeviceNode"):
         from . import builder
         return getattr(builder, name)
     raise AttributeError(name)

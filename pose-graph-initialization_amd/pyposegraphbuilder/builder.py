@@ -30,6 +30,21 @@ class _HostView(_C.Structure):  # pgih_view
 _GRAPH_EDGE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("score", "<f8"), ("R", "<f8", 9), ("t", "<f8", 3)])  # pgih_graph_edge
 
 
+def bindProcessToDeviceNode(device=-1):
+    """One process per GPU: keep this process -- the calling thread and every thread it starts later -- on the CPUs of the NUMA
+    node the HIP device hangs on (device < 0: the current one), what `numactl --cpunodebind` does in a launcher; arrays created
+    afterwards land on that node.  Call it before the inputs are created.  Returns the node, or -1 when nothing was done
+    (pgih_bind_process_to_device_node of libpgi_host.so)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libpgi_host.so")
+    if not os.path.exists(path):
+        raise RuntimeError("libpgi_host.so not built (%s): make -C pose-graph-initialization_amd" % path)
+    lib = C.CDLL(path)
+    lib.pgih_bind_process_to_device_node.argtypes = [C.c_int]
+    return int(lib.pgih_bind_process_to_device_node(int(device)))
+
+
 class PoseGraphBuilder:
     def __init__(self, kCoreNumber=20, kMaximumTrackletNumber=5000, kMaximumSearchDepth=5, kMaximumPathNumber=100,
                  kMinimumInlierNumber=20, kMinimumPointNumber=50, kMaximumPointNumberForEpipolarHashing=100,

@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
         const dist::LaunchEnv env = dist::LaunchEnv::fromEnvironment();
         dist::HostComm comm(env);
         dist::selectDevice(env);
+        PoseGraphBuilder::bindProcessToDeviceNode();  // (what a launcher's --cpunodebind does; before the scene is read)
         std::ifstream in(argv[1], std::ios::binary);
         // simKind (low byte) 0: no table, 1: dense V x V doubles follow, 2: only the candidate pairs' values (0 elsewhere: a
         // sparse table).  Bit 8 set: BULK layout (pyposegraphbuilder/scenes.py write_scene_bulk) -- per-pair arrays first, then

@@ -15,6 +15,7 @@ using namespace reconstruction;
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
+    PoseGraphBuilder::bindProcessToDeviceNode();  // (what a launcher's --cpunodebind does; before the features are read)
     std::ifstream in(argv[1], std::ios::binary);
     uint32_t V, P, wave;
     in.read((char*)&V, 4); in.read((char*)&P, 4); in.read((char*)&wave, 4);
