@@ -124,6 +124,11 @@ void pgi_default_params(pgi_params* p);
 pgi_ctx* pgi_create(int device, const pgi_params* params);
 void pgi_destroy(pgi_ctx* ctx);
 int pgi_set_stream(pgi_ctx* ctx, void* hip_stream);
+/* The stream the context enqueues on right now (NULL = the default stream): what a caller that feeds the context from
+ * its own copy stream must order its events against (hipStreamWaitEvent(*out, ev)). */
+int pgi_get_stream(pgi_ctx* ctx, void** hip_stream_out);
+/* The HIP device ordinal the context was created on (pgi_create's `device`, resolved when it was < 0). */
+int pgi_get_device(pgi_ctx* ctx, int* device_out);
 int pgi_set_params(pgi_ctx* ctx, const pgi_params* params);
 int pgi_get_params(pgi_ctx* ctx, pgi_params* params);
 int pgi_synchronize(pgi_ctx* ctx);

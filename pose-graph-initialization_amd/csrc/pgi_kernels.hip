@@ -1628,6 +1628,19 @@ int pgi_set_stream(pgi_ctx* ctx, void* s) {
     return PGI_SUCCESS;
 }
 
+int pgi_get_stream(pgi_ctx* ctx, void** out) {
+    if (!ctx || !out) return fail(PGI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *out = (void*)ctx->stream;
+    return PGI_SUCCESS;
+}
+
+int pgi_get_device(pgi_ctx* ctx, int* out) {
+    if (!ctx || !out) return fail(PGI_ERR_INVALID, "null argument");
+    *out = ctx->device;
+    return PGI_SUCCESS;
+}
+
 int pgi_set_params(pgi_ctx* ctx, const pgi_params* p) {
     if (!ctx || !p) return fail(PGI_ERR_INVALID, "null argument");
     if (!(p->confidence > 0.0 && p->confidence < 1.0)) return fail(PGI_ERR_INVALID, "confidence must be in (0,1)");

@@ -131,6 +131,12 @@ class SimilarityTable {
                 view_pair_queue.emplace(v, i, j);
             }
         }
+        // a file is written cell by cell and need not be symmetric; rowTo() may hand out a row in place of a column only
+        // while it is (setSimilarity keeps it so; nothing else writes cells)
+        symmetric = true;
+        for (size_t i = 0; i < N && symmetric; ++i)
+            for (size_t j = i + 1; j < N; ++j)
+                if (similarity[i][j] != similarity[j][i]) { symmetric = false; break; }
         return true;
     }
     // All similarities TO one view, for a traversal that asks getSimilarity(next, to) for many `next` and one `to` (A*'s
@@ -160,13 +166,18 @@ class SimilarityTable {
         r.n = size;
         r.to = to;
         r.fill = fill;
-        if (!sparse) {
-            if (to < size) r.dense = similarity[to].data();  // (symmetric by construction: setSimilarity writes both cells)
-            else r.n = 0;
-            return r;
-        }
         struct Scratch { std::vector<double> value; std::vector<uint32_t> stamp; uint32_t epoch = 0; };
         static thread_local Scratch sc;
+        if (!sparse) {
+            if (to >= size) { r.n = 0; return r; }
+            if (symmetric) { r.dense = similarity[to].data(); return r; }  // row == column: no gather
+            // an asymmetric file (loadFromFile): the heuristic is similarity[next][to] (graph_traversal.h:847), i.e. the
+            // COLUMN of `to` -- gathered once per search into the calling thread's scratch
+            if (sc.value.size() < size) { sc.stamp.assign(size, 0u); sc.value.assign(size, 0.0); sc.epoch = 0; }
+            for (size_t from = 0; from < size; ++from) sc.value[from] = similarity[from][to];
+            r.dense = sc.value.data();
+            return r;
+        }
         if (sc.stamp.size() < size) { sc.stamp.assign(size, 0u); sc.value.assign(size, 0.0); sc.epoch = 0; }
         if (++sc.epoch == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0u); sc.epoch = 1; }
         if (to < rows.size())
@@ -187,6 +198,7 @@ class SimilarityTable {
     std::priority_queue<std::tuple<double, ViewId, ViewId>> view_pair_queue;
     std::unordered_set<ViewId> views;
     bool sparse = false;
+    bool symmetric = true;  // dense mode: similarity[i][j] == similarity[j][i] for all cells (false only after an asymmetric file)
     double fill = 0.0;
     static uint64_t key(ViewId a, ViewId b) { return a < b ? ((uint64_t)a << 32) | (uint64_t)b : ((uint64_t)b << 32) | (uint64_t)a; }
     std::unordered_map<uint64_t, double> listed;  // sparse mode: unordered pair -> similarity (ids < 2^32)

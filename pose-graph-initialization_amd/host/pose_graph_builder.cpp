@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 
 #include <pthread.h>
@@ -158,6 +159,19 @@ static std::vector<int> deviceLocalCpus(int dev, int* node_out) {
     return cpus;
 }
 
+// The stream the context enqueues on NOW (pgi_set_stream may have moved it off the default stream): uploads on the staging
+// copy stream are ordered against it with events, never against a stream assumed to be the default one.
+static int engineDevice(pgi_ctx* ctx) {
+    int d = -1;
+    Engine::check(pgi_get_device(ctx, &d));
+    return d;
+}
+static hipStream_t engineStream(pgi_ctx* ctx) {
+    void* s = nullptr;
+    Engine::check(pgi_get_stream(ctx, &s));
+    return (hipStream_t)s;
+}
+
 // What `numactl --cpunodebind` does for a one-process-per-GPU launch: the calling thread (and every thread it starts later:
 // the host team, the runtime's helpers) may only run on the CPUs of the NUMA node the device hangs on, and the memory it
 // touches first lands there.  The builder's host side reads the caller's matrices, writes the page-locked ring and drives
@@ -172,9 +186,15 @@ int PoseGraphBuilder::bindProcessToDeviceNode(int device) {
     int node = -1;
     const std::vector<int> cpus = deviceLocalCpus(dev, &node);
     if (cpus.empty()) return -1;
-    cpu_set_t set;
+    // An explicit launcher binding wins (taskset, torchrun/SLURM per-rank pinning, a cpuset): only CPUs the process may
+    // already run on are kept.  Nothing is done when the inherited mask is already inside the node, or does not meet it.
+    cpu_set_t inherited, set;
+    CPU_ZERO(&inherited);
+    if (sched_getaffinity(0, sizeof inherited, &inherited) != 0) return -1;
     CPU_ZERO(&set);
-    for (int c : cpus) CPU_SET(c, &set);
+    for (int c : cpus) if (CPU_ISSET(c, &inherited)) CPU_SET(c, &set);
+    if (CPU_COUNT(&set) == 0) return -1;                           // bound elsewhere on purpose: leave it
+    if (CPU_COUNT(&set) == CPU_COUNT(&inherited)) return node;     // already a subset of the node
     return sched_setaffinity(0, sizeof set, &set) == 0 ? node : -1;
 }
 
@@ -202,6 +222,7 @@ class HostPool {
             for (size_t i = a; i < b; ++i) fn(i);
         };
         if (nt == 1) { body(0); return; }
+        std::lock_guard<std::mutex> one(callers);  // one job at a time: the pool is shared by every builder on the device
         {
             std::lock_guard<std::mutex> l(mu);
             job = &body;
@@ -209,10 +230,15 @@ class HostPool {
             ++generation;
         }
         wake.notify_all();
+        struct Join {  // also when fn throws on the calling thread: the workers still run `body`, which lives in this frame
+            HostPool& p;
+            ~Join() {
+                std::unique_lock<std::mutex> l(p.mu);
+                p.done.wait(l, [&] { return p.pending == 0; });
+                p.job = nullptr;
+            }
+        } join{*this};
         body(0);
-        std::unique_lock<std::mutex> l(mu);
-        done.wait(l, [&] { return pending == 0; });
-        job = nullptr;
     }
 
    private:
@@ -235,7 +261,7 @@ class HostPool {
         }
     }
     std::vector<std::thread> workers;
-    std::mutex mu;
+    std::mutex mu, callers;
     std::condition_variable wake, done;
     std::function<void(size_t)>* job = nullptr;
     size_t pending = 0;
@@ -305,9 +331,15 @@ struct PoseGraphBuilder::Staging {
     // Process-wide and never released: page-locking a few hundred MB costs tens of milliseconds, and a process that builds
     // one pose graph after another (or one builder per configuration) should pay that once.  (Freed by the process's exit;
     // an explicit teardown would have to run before the HIP runtime's own, which static destruction order does not promise.)
-    static std::shared_ptr<Staging> shared() {
-        static std::shared_ptr<Staging>* inst = new std::shared_ptr<Staging>(new Staging());
-        return *inst;
+    // One per DEVICE: the block, the events and the copy stream belong to the device that was current when they were made
+    // (pgi_create(device) allows several devices per process); the builder's engine names the device.
+    static std::shared_ptr<Staging> shared(int device) {
+        static std::mutex m;
+        static std::map<int, std::shared_ptr<Staging>>* inst = new std::map<int, std::shared_ptr<Staging>>();
+        std::lock_guard<std::mutex> l(m);
+        std::shared_ptr<Staging>& s = (*inst)[device];
+        if (!s) s.reset(new Staging());
+        return s;
     }
 };
 
@@ -368,8 +400,9 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
                  o_off = o_y2 + up(rows * 4), o_thr = o_off + up((L + 1) * 8), o_guess = o_thr + up(L * 8),
                  o_has = o_guess + up(L * 96), o_Eg = o_has + up(L), o_tau = o_Eg + up(L * 72), o_small_end = o_tau + up(L * 8),
                  o_cnt = o_small_end, o_masks = o_cnt + up(L * 4), dev_total = o_masks + up(rows);
-    if (!staging) staging = Staging::shared();
+    if (!staging) staging = Staging::shared(engineDevice(engine->get()));
     std::lock_guard<std::mutex> stagingBusy(staging->busy);
+    HIP_OK(hipSetDevice(engineDevice(engine->get())));  // this thread's allocations, stream and events belong to the engine's device
     staging->init(kCoreNumber ? kCoreNumber : 1);
     staging->reserve(o_small_end - o_off, maxChunkRows * 16, dev_total);
     char* const hs = (char*)staging->small - o_off;  // so that hs + o_* addresses the page-locked mirror
@@ -424,7 +457,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         hipStream_t copy = staging->copy;
         HIP_OK(hipMemcpyAsync(db + o_off, hs + o_off, o_guess - o_off, hipMemcpyHostToDevice, copy));  // offsets, thresholds
         HIP_OK(hipEventRecord(staging->smallUp, copy));
-        HIP_OK(hipStreamWaitEvent(nullptr, staging->smallUp, 0));  // the engine works on the default stream
+        HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->smallUp, 0));  // the stream the engine enqueues on
         float* const dcol[4] = {(float*)(db + o_x1), (float*)(db + o_y1), (float*)(db + o_x2), (float*)(db + o_y2)};
         size_t groupK0 = 0, groupChunks = 0, groupTarget = 1;
         uint32_t groupMaxCorr = 0;
@@ -464,7 +497,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             }
             convertSeconds += std::chrono::duration<double>(Clock::now() - tc).count();
             HIP_OK(hipEventRecord(staging->up[slot], copy));
-            HIP_OK(hipStreamWaitEvent(nullptr, staging->up[slot], 0));
+            HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->up[slot], 0));
             // Kernels are launched per GROUP of uploaded chunks -- 1, 2, then 4 chunks: a launch pays a fixed wind-down while its
             // last workgroups finish (0.9 ms, DESIGN.md section 7 "The drain"), so the first launch comes early and the later
             // ones are large.
@@ -484,7 +517,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
                     HIP_OK(hipMemcpyAsync(db + o_tau + g0 * 8, hs + o_tau + g0 * 8, n * 8, hipMemcpyHostToDevice, copy));
                 }
                 HIP_OK(hipEventRecord(staging->smallUp, copy));
-                HIP_OK(hipStreamWaitEvent(nullptr, staging->smallUp, 0));
+                HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->smallUp, 0));
                 if (screen) {
                     Engine::check(pgi_score_pose_batch(engine->get(), &b, (const double*)(db + o_Eg) + 9 * g0, (const double*)(db + o_tau) + g0,
                                                        (uint32_t*)(db + o_cnt) + g0, nullptr));
@@ -672,8 +705,12 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         double searchSeconds = 0;
         std::function<void(size_t, size_t)> searchRange;
         if (pathFinding) {
-            if (!staging) staging = Staging::shared();
-            staging->init(kCoreNumber ? kCoreNumber : 1);
+            if (!staging) staging = Staging::shared(engineDevice(engine->get()));
+            {
+                std::lock_guard<std::mutex> stagingBusy(staging->busy);  // init may replace the team another builder is using
+                HIP_OK(hipSetDevice(engineDevice(engine->get())));
+                staging->init(kCoreNumber ? kCoreNumber : 1);
+            }
             heuristics.reset(new ImageSimilarityHeuristics(*similarityTable));
             traversal.reset(new AStarTraversal<ImageSimilarityHeuristics>(&poseGraph_, *heuristics, kTraversalHeuristicsWeight, 0.0, kMaximumSearchDepth));
             traversal->setGraphFrozen(true);
@@ -879,8 +916,9 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         // buffer travels as one asynchronous copy on the copy stream, the per-view preparation kernels of the run wait for
         // it on the engine's stream -- while the team already fills the next buffer.  A view whose arrays are page-locked
         // already (hipHostMalloc / hipHostRegister / pgi_host_register) is copied from where it lies.
-        if (!staging) staging = Staging::shared();
+        if (!staging) staging = Staging::shared(engineDevice(engine->get()));
         std::lock_guard<std::mutex> stagingBusy(staging->busy);
+        HIP_OK(hipSetDevice(engineDevice(engine->get())));
         staging->init(kCoreNumber ? kCoreNumber : 1);
         auto pageLocked = [](const void* p) {
             hipPointerAttribute_t at{};
@@ -939,7 +977,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
                 if (end > begin) HIP_OK(hipMemcpyAsync(ab + begin, hb, end - begin, hipMemcpyHostToDevice, copy));
             }
             HIP_OK(hipEventRecord(staging->up[slot], copy));
-            HIP_OK(hipStreamWaitEvent(nullptr, staging->up[slot], 0));  // the engine works on the default stream
+            HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->up[slot], 0));  // the stream the engine enqueues on
             tStage += nowS() - tm;
             tm = nowS();
             for (size_t v = run.v0; v < run.v1; ++v) {

@@ -230,7 +230,6 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         std::unique_lock<std::shared_mutex> l(mu);
         if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) return false;
         const uint32_t k = (uint32_t)edge_store.size();
-        if (s == 0xFFFFFFFFull && d == 0xFFFFFFFFull) return false;  // (the packed key of this one pair is the table's empty mark)
         if (!edge_index.insert(EdgeId{s, d}, k)) return false;
         edge_store.emplace_back(s, d, T, score);
         neighboursForUpdate(s).push_back(Neighbour{d, score, k});
@@ -268,7 +267,6 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         for (size_t i = 0; i < n; ++i) {
             const ViewId s = items[i].src, d = items[i].dst;
             if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) continue;
-            if (s == 0xFFFFFFFFull && d == 0xFFFFFFFFull) continue;
             const uint32_t k = (uint32_t)edge_store.size();
             if (!edge_index.insert(EdgeId{s, d}, k)) continue;
             SE3d T;
@@ -381,7 +379,7 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
        public:
         static constexpr uint32_t npos = 0xFFFFFFFFu;
         uint32_t find(const EdgeId& id) const {
-            if ((id.first | id.second) >> 32) {
+            if (inBig(id)) {
                 auto it = big.find(id);
                 return it == big.end() ? npos : it->second;
             }
@@ -394,7 +392,7 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         }
         size_t count(const EdgeId& id) const { return find(id) != npos; }
         bool insert(const EdgeId& id, uint32_t v) {  // false if the id is already there
-            if ((id.first | id.second) >> 32) return big.emplace(id, v).second;
+            if (inBig(id)) return big.emplace(id, v).second;
             if ((used + 1) * 2 > keys.size()) grow(std::max<size_t>(64, 2 * keys.size()));
             const uint64_t k = pack(id);
             for (size_t i = slot(k);; i = (i + 1) & (keys.size() - 1)) {
@@ -414,7 +412,8 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         }
 
        private:
-        static constexpr uint64_t kEmpty = ~0ull;  // (src, dst) = (2^32 - 1, 2^32 - 1) is routed to `big` below
+        static constexpr uint64_t kEmpty = ~0ull;  // the one pair that packs to it, (2^32 - 1, 2^32 - 1), lives in `big`
+        static bool inBig(const EdgeId& id) { return ((id.first | id.second) >> 32) != 0 || pack(id) == kEmpty; }
         static uint64_t pack(const EdgeId& id) { return ((uint64_t)id.first << 32) | (uint64_t)id.second; }
         size_t slot(uint64_t k) const {
             k *= 0x9E3779B97F4A7C15ull;

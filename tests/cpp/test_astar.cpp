@@ -37,6 +37,17 @@ static int formats(char** argv) {
     st.addCount("[Pose estimation] Runs", 1);
     std::fprintf(out, "stat %.1f %zu %.1f\n", st.getTime("[Pose estimation]"), st.getCount("[Pose estimation] Runs"),
                  st.getAverageTime("[Pose estimation]").first);
+    {   // the A* heuristic's per-search view of the table (costsTo(to)(next)) must be getCost(next, to) cell for cell --
+        // on an asymmetric file that is the COLUMN of `to`, not its row (reference graph_traversal.h:847)
+        ImageSimilarityHeuristics h(sim);
+        const size_t N = (size_t)std::atoi(argv[3]);
+        size_t bad = 0;
+        for (size_t to = 0; to <= N; ++to) {
+            const auto costs = h.costsTo(to);
+            for (size_t next = 0; next <= N; ++next) bad += costs(next) != h.getCost(next, to);
+        }
+        std::fprintf(out, "costs_mismatch %zu c01 %.3f c10 %.3f\n", bad, h.costsTo(1)(0), h.costsTo(0)(1));
+    }
     std::fclose(out);
     return 0;
 }

@@ -155,6 +155,9 @@ def test_text_loaders_parse_strictly(tmp_path):
     out = run(asym, good_list)
     assert out[0] == "load 1" and out[1] == "pairs 4 views 3"
     assert out[2:6] == ["0.900 1 2", "0.600 1 0", "0.500 0 1", "0.300 0 2"]
+    # A*'s per-search costs on that asymmetric table: costsTo(to)(next) == getCost(next, to) = similarity[next][to] (the
+    # reference's heuristic, graph_traversal.h:847) -- round 4 handed out row `to` instead (0.6 where 0.5 belongs)
+    assert [l for l in out if l.startswith("costs_mismatch")] == ["costs_mismatch 0 c01 0.500 c10 0.600"]
     # image list: names without the directory prefix are kept whole; ONE record per line -- a blank line is an image of its
     # own (empty name, focal 0), because line index == view id == row of the similarity matrix (reference utils.h:136-168
     # counts and pushes every line); fields after the third are ignored like the reference does; a bad focal is refused

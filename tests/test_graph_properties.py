@@ -6,7 +6,7 @@ import os
 import subprocess
 import sys
 
-from hypothesis import given, settings, strategies as st
+from hypothesis import example, given, settings, strategies as st
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -26,8 +26,6 @@ class Model:
 
     def add_edge(self, s, d, sc):
         if s not in self.vertices or d not in self.vertices or (s, d) in self.edges:
-            return False
-        if s == d == 2 ** 32 - 1:   # the one pair whose packed key is the index's empty mark: refused (pose_graph_builder.hpp)
             return False
         self.edges[(s, d)] = sc
         self.order.append((s, d))
@@ -80,8 +78,19 @@ def script(ops):
     return "\n".join(lines) + "\n"
 
 
-@settings(max_examples=300, deadline=None)
+M32 = 2 ** 32 - 1   # (M32, M32) packs to the open-addressing table's empty mark: it must live in the hash-map side
+
+
+# derandomize: red/green must not depend on the seed (the round-4 failure was a saved example fresh seeds never drew)
+@settings(max_examples=300, deadline=None, derandomize=True, database=None)
 @given(st.lists(OP, min_size=1, max_size=60))
+@example([("B", []), ("H", M32, M32)])
+@example([("B", []), ("G", M32, M32)])
+@example([("P", 1, 2), ("E", (1, 2, 0.5)), ("H", M32, M32), ("G", M32, M32), ("N", M32)])
+@example([("P", M32, 3), ("E", (M32, M32, 0.25)), ("E", (M32, M32, 0.5)), ("H", M32, M32), ("G", M32, M32),
+          ("E", (M32, 3, 0.125)), ("E", (3, M32, 0.75)), ("G", M32, 3), ("G", 3, M32), ("H", 3, M32), ("N", M32), ("I",)])
+@example([("P", M32, 0), ("B", [(M32, M32, 0.5), (0, M32, 0.25), (M32, M32, 0.75), (M32, 0, 0.125)]), ("I",),
+          ("G", M32, M32), ("G", 0, M32), ("G", M32, 0), ("H", 0, 0)])
 def test_pose_graph_equals_the_dictionary_model(tmp_path_factory, ops):
     d = tmp_path_factory.mktemp("graphops")
     fin, fout = str(d / "ops.txt"), str(d / "out.txt")
@@ -92,3 +101,24 @@ def test_pose_graph_equals_the_dictionary_model(tmp_path_factory, ops):
     m = Model()
     want = [m.run(op) for op in ops]
     assert got == want
+
+
+def test_the_pair_that_packs_to_the_empty_mark():
+    """Round-4 crash: lookups of (2^32-1, 2^32-1) matched the table's first EMPTY slot (SIGSEGV on an empty graph, edge 0 on
+    any other).  Plain scripts, no hypothesis: empty graph, non-empty graph, and the pair as a real edge."""
+    import tempfile
+    cases = [
+        ([("B", []), ("G", M32, M32), ("H", M32, M32)], ["0", "none", "0 0"]),
+        ([("P", 1, 2), ("E", (1, 2, 0.5)), ("H", M32, M32), ("G", M32, M32)], ["2", "1", "0 0", "none"]),
+        ([("V", M32), ("E", (M32, M32, 0.5)), ("E", (M32, M32, 0.5)), ("H", M32, M32), ("G", M32, M32), ("G", M32, 1)],
+         ["1", "1", "0", "1 1", "%d %d 0.5 1" % (M32, M32), "none"]),
+    ]
+    for ops, want in cases:
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "ops.txt"), os.path.join(d, "out.txt")
+            open(fin, "w").write(script(ops))
+            r = subprocess.run([EXE, "graphops", fin, fout], capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0, (r.returncode, r.stderr)
+            assert open(fout).read().splitlines() == want
+            m = Model()
+            assert [m.run(op) for op in ops] == want
