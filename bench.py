@@ -118,14 +118,14 @@ def opencv_column(b, m, thr, cores):
 
 
 def graph_level(world, require_rccl=False):
-    """BASELINE configs 3 / 4 / 5 on the scene graphs of pyposegraphbuilder/scenes.py (v340: ~7 300 pairs / 5 M rows, v5000:
+    """BASELINE configs 3 / 4 / 5 on the scene graphs of tests/scene_drivers.py (v340: ~7 300 pairs / 5 M rows, v5000:
     ~106 000 pairs / 77 M rows -- SURVEY 8d's k ~ 40 nearest views, median ~ 600 rows per pair, cap 8000) through the C++
     driver as `world` freshly started child processes (one per GPU; never an exec after HIP initialisation).  With
     world > 1 the edge records travel through pgi_allgather_edges over RCCL (dist::attach), every rank's result file must
     equal the single-process run's byte for byte, and the line says so."""
     import hashlib
     import tempfile
-    from pyposegraphbuilder import scenes as SC
+    import scene_drivers as SC
     if not os.path.exists(SC.EXE):
         return {"skipped": "host driver %s not built" % SC.EXE}
     graphs = {}
@@ -655,7 +655,7 @@ def main():
         # as a child process, its own wall clock and stage clocks, warm repetition; global rotation error after gauge
         # alignment, AUC@5 of the estimated edges
         out["graphs"] = graph_level(1)
-        from pyposegraphbuilder import scenes as SC
+        import scene_drivers as SC
         # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
         # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
         # -> createCorrespondenceMatrix -> A* guesses -> estimatePose -> guided matching -> tracklets in HBM -- as a child

@@ -323,7 +323,10 @@ __device__ constexpr int kCI[10][4] = {{0, 2, 4, 5},     {2, 3, 8, 9},     {4, 8
                                        {12, 15, 18, 19}};
 // phase-1 quads: Q0..Q5 = (E E^T)_{00,01,02,11,12,22}; Q6..Q8 = the 2x2 minors of rows 1,2.
 // packed per term: entryA | entryB<<4 | sign<<8 (sign 1:+, 2:-, 0:unused)
-__constant__ uint16_t kQT[9][3] = {
+// Looked up per LANE (index = sub-lane): a table in memory would be a vector-memory round trip in the middle of every
+// pass (round 5: three dependent global_load + s_waitcnt vmcnt(0) for kQT, three more for kLAM, per pass), so the tables are
+// packed into 64-bit immediates at compile time -- nibble s of kQTA[t] / kQTB[t] / kQTS[t] -- and read with a shift.
+constexpr uint16_t kQT[9][3] = {
     {0x100 | 0 | (0 << 4), 0x100 | 1 | (1 << 4), 0x100 | 2 | (2 << 4)},
     {0x100 | 0 | (3 << 4), 0x100 | 1 | (4 << 4), 0x100 | 2 | (5 << 4)},
     {0x100 | 0 | (6 << 4), 0x100 | 1 | (7 << 4), 0x100 | 2 | (8 << 4)},
@@ -334,8 +337,21 @@ __constant__ uint16_t kQT[9][3] = {
     {0x100 | 3 | (8 << 4), 0x200 | 5 | (6 << 4), 0},
     {0x100 | 3 | (7 << 4), 0x200 | 4 | (6 << 4), 0},
 };
-__constant__ uint8_t kLAM[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-__constant__ uint8_t kMN[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+constexpr uint64_t qt_pack(int t, int field) {  // field 0: entryA, 1: entryB, 2: sign
+    uint64_t v = 0;
+    for (int s = 0; s < 9; ++s) {
+        const uint32_t w = kQT[s][t];
+        const uint32_t f = field == 0 ? (w & 15u) : field == 1 ? ((w >> 4) & 15u) : (w >> 8);
+        v |= (uint64_t)f << (4 * s);
+    }
+    return v;
+}
+__device__ constexpr uint64_t kQTA[3] = {qt_pack(0, 0), qt_pack(1, 0), qt_pack(2, 0)};
+__device__ constexpr uint64_t kQTB[3] = {qt_pack(0, 1), qt_pack(1, 1), qt_pack(2, 1)};
+__device__ constexpr uint64_t kQTS[3] = {qt_pack(0, 2), qt_pack(1, 2), qt_pack(2, 2)};
+// Lambda index of (i, k): {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}, nibble 3 i + k
+constexpr uint64_t kLAMP = 0x0ull | (1ull << 4) | (2ull << 8) | (1ull << 12) | (3ull << 16) | (4ull << 20) | (2ull << 24) | (4ull << 28) | (5ull << 32);
+PGI_DEV int lam_index(int i, int k) { return (int)((kLAMP >> (4 * (3 * i + k))) & 15ull); }
 
 // ---- per-wavefront LDS scratch (doubles): [basis x4 | B(z) rows x4 | region A x4] ---------------
 // group g of the wavefront uses basis[g], brow[g], rega[g].  Region A is reused in sequence:
@@ -444,8 +460,8 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
         for (int c = 0; c < 10; ++c) q[c] = 0.0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const uint32_t w = kQT[s][t];
-            const int eA = w & 15, eB = (w >> 4) & 15, sg = w >> 8;
+            const int eA = (int)((kQTA[t] >> (4 * s)) & 15ull), eB = (int)((kQTB[t] >> (4 * s)) & 15ull),
+                      sg = (int)((kQTS[t] >> (4 * s)) & 15ull);
             if (sg) {
                 double A[4], B[4];
 #pragma unroll
@@ -482,7 +498,7 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
         const int i = (s > 0) ? (s - 1) / 3 : 0, j = (s > 0) ? (s - 1) % 3 : 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double* qsrc = (s == 0) ? gs.brow + 10 * k : gs.rega + 10 * kLAM[i][k];
+            const double* qsrc = (s == 0) ? gs.brow + 10 * k : gs.rega + 10 * lam_index(i, k);
             const int ei = (s == 0) ? k : 3 * k + j;
             const bool neg = (s == 0) && (k == 1);
             double L[4];
@@ -549,8 +565,9 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
     wave_sync();
     // ---- det B(z) = sum_i (+,-,+) bc_i * (bx_r by_q - by_r bx_q) ------------------------------
     if (s < 3) {
-        const double* br = gs.brow + 13 * kMN[s][0];
-        const double* bq = gs.brow + 13 * kMN[s][1];
+        // the other two rows of B(z): {1, 2}, {0, 2}, {0, 1}
+        const double* br = gs.brow + 13 * (s == 0 ? 1 : 0);
+        const double* bq = gs.brow + 13 * (s == 2 ? 1 : 2);
         const double* bc = gs.brow + 13 * s + 8;
         double bxr[4], byr[4], bxq[4], byq[4];
 #pragma unroll

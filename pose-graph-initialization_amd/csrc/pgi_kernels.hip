@@ -1702,11 +1702,11 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
     // (the experimental 8-wavefront build runs two workgroups per CU where the default runs four: its row caps are those of
     //  half as many workgroups, and it has no hybrid class -- 2 000 rows fit whole)
-    constexpr int kWgScale = NW / 4;
-    const uint32_t cap4 = rows_cap(std::max(1, 4 / kWgScale)), cap3 = rows_cap(std::max(1, 3 / kWgScale)),
-                   cap2 = rows_cap(std::max(1, 2 / kWgScale)), cap1 = rows_cap(1);
+    //  -DPGI_NW=2: eight / six / four / two workgroups per CU -- the same 16 / 12 / 8 / 4 wavefronts per CU as the default's levels)
+    constexpr int kLevelWgs[4] = {std::max(1, 16 / NW), std::max(1, 12 / NW), std::max(1, 8 / NW), std::max(1, 4 / NW)};
+    const uint32_t cap4 = rows_cap(kLevelWgs[0]), cap3 = rows_cap(kLevelWgs[1]), cap2 = rows_cap(kLevelWgs[2]), cap1 = rows_cap(kLevelWgs[3]);
     bool hybrid = false;
-    int class_wgs = 4;        // workgroups per CU of the class being launched (sizes a persistent grid)
+    int class_wgs = kLevelWgs[0];  // workgroups per CU of the class being launched (sizes a persistent grid)
     hipStream_t ls = stream;  // the stream the next launch goes to (a class's side stream when classes overlap)
     // grid of a launch: one workgroup per pair, or -- persistent class launch -- as many as stay resident at once
     auto grid_of = [&]() {
@@ -1787,7 +1787,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
 #else
             a.pair_head = ctx->k1_persistent && !guesses ? heads + k : nullptr;  // (the guess variants have no loop)
 #endif
-            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? 4 / kWgScale : k == 1 && ctx->hybrid_rows && NW == 4 ? 4 : std::max(1, (4 - k) / kWgScale);
+            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows && NW == 4 ? 4 : kLevelWgs[k];
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
             if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;

@@ -1,7 +1,8 @@
 import os, sys, subprocess, tempfile, numpy as np
 ROOT = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.environ.get("GRAFT_REPO_ROOT", ".")
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
 with tempfile.TemporaryDirectory() as d:
     fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")

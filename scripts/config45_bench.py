@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs 4 and 5 end to end on ONE GPU (world 1), through the C++ host layer (tests/cpp/test_distributed.cpp):
   config45_bench.py [scene] [modes] [world]      scene: v5000 (default; SURVEY 8d's density: ~106 000 pairs, ~77 M rows),
-                                                 v340, v5000_ring, v340_thin (pyposegraphbuilder/scenes.py SCENES)
+                                                 v340, v5000_ring, v340_thin (tests/scene_drivers.py SCENES)
   shard         estimate all pairs + gather + L1/IRLS rotation averaging            (config 4)
   waves         A*-scheduled waves, reference-style pose guesses                    (config 5, reference guesses)
   waves_guided  the same with rotation-guided re-estimation                         (config 5 as BASELINE names it)
@@ -11,7 +11,8 @@ import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
 import numpy as np
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 name = sys.argv[1] if len(sys.argv) > 1 else "v5000"
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["shard", "waves", "waves_guided"]
 world = int(sys.argv[3]) if len(sys.argv) > 3 else 1

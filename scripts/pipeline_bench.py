@@ -6,7 +6,8 @@ import os, struct, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 full = len(sys.argv) > 1 and sys.argv[1] == "config3"
 wave = int(sys.argv[2]) if len(sys.argv) > 2 else (512 if full else 128)
 if full:

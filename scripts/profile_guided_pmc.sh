@@ -6,7 +6,8 @@ cd $R
 python3 - <<'PY'
 import sys
 sys.path.insert(0, "pose-graph-initialization_amd")
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
 SC.write_feature_scene("/tmp/config3_features.bin", views, cam, sim, pairs, 512)
 PY

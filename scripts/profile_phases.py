@@ -17,10 +17,25 @@ NAMES = {0: "stage rows -> LDS", 1: "sample + gather", 2: "nullspace 5x9 + MGS",
          18: "LO refine", 19: "LO E from root", 20: "LO wait for wave 0", 21: "LO score+combine",
          22: "round barrier wait", 23: "merge/termination", 24: "epilogue (mask+decompose)"}
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-fb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+N = sys.argv[2] if len(sys.argv) > 2 else "2000"   # a row count, or a scene name (v5000: the dense scene's own rows, first P pairs;
+fb = int(sys.argv[3]) if len(sys.argv) > 3 else 0   #  "v5000:1344" keeps only pairs of at most 1344 rows -- one size class)
 eng = Engine(fixed_budget=fb)
-b = S.make_batch(np.arange(P), N)
+if N[0] == "v":
+    import scene_drivers as SC
+    name, _, cap = N.partition(":")
+    g, _w = SC.make_scene(name)
+    bb = g["batch"]
+    off = np.asarray(bb["offsets"], np.int64)
+    n_all = np.diff(off)
+    keep = np.nonzero(n_all <= int(cap))[0][:P] if cap else np.arange(min(P, len(n_all)))
+    P = len(keep)
+    idx = np.concatenate([np.arange(off[k], off[k + 1]) for k in keep])
+    b = {k: bb[k][idx] for k in ("x1", "y1", "x2", "y2")}
+    b["offsets"] = np.concatenate([[0], np.cumsum(n_all[keep])]).astype(np.uint64)
+    print("rows of scene %s: %d pairs, median %d rows" % (N, P, np.median(n_all[keep])))
+else:
+    N = int(N)
+    b = S.make_batch(np.arange(P), N)
 db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=1)
 buf = torch.zeros(32, dtype=torch.int64, device=eng.device)
 eng.estimate_pose_batch(db); torch.cuda.synchronize()
@@ -31,7 +46,7 @@ a.record(); e, m = eng.estimate_pose_batch(db); z.record(); torch.cuda.synchroni
 acc = buf.cpu().numpy().astype(np.float64)
 tot = acc.sum()
 got = eng.edges_to_numpy(e)
-print("P=%d N=%d budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over %d waves)" % (
+print("P=%d N=%s budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over %d waves)" % (
     P, N, fb, a.elapsed_time(z), got["iters"].mean(), got["lo_runs"].mean(), 4 * P))
 for i in range(25):
     print("%2d %-28s %14.0f  %6.2f%%  %10.0f ticks/wave" % (i, NAMES.get(i, ""), acc[i], 100 * acc[i] / tot, acc[i] / (4 * P)))

@@ -11,7 +11,8 @@ for d in ("pose-graph-initialization_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import oracle_lib as O
 import pipeline_oracle as PO
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_pipeline")
 t_start = time.time()

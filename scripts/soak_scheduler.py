@@ -10,7 +10,8 @@ for d in ("pose-graph-initialization_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import oracle_lib as O
 import scheduler_oracle as SO
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 KEYS = ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses", "waves", "graph_edges",
         "quirk_only_guesses")

@@ -214,7 +214,8 @@ def test_host_scheduler_entry_validates_caller_data(capfd):
     """pgih_run_pairs (include/pgi_host.h) sizes host tables from the caller's view ids: ids beyond n_views (or, with n_views = 0,
     beyond PGIH_MAX_VIEWS), decreasing offsets and null rows are refused with a message, before anything is allocated from
     them; a well-formed call still works afterwards, takes a seed, and says so when most accepted guesses are quirk-only."""
-    from pyposegraphbuilder import PoseGraphBuilder, scenes as SC
+    from pyposegraphbuilder import PoseGraphBuilder
+    import scene_drivers as SC
     b = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", True, True, True)
     try:
         lib, h = b._host()

@@ -92,10 +92,8 @@ def test_cpp_shard_bounds_equal_python(tmp_path):
             assert got == [(int(a), int(b)) for a, b in D.shard_bounds(sizes, world)], (case, world)
 
 
-def test_cpp_hostcomm_world3(tmp_path):
-    """The TCP star that ships the RCCL unique id and carries the host-side exchanges: broadcast, uneven all-gather
-    (one empty block), fixed-size all-gather, barrier -- three processes, identical results on every rank."""
-    world, port = 3, _free_port()
+def _cpp_hostcomm(tmp_path, world):
+    port = _free_port()
     prefix = str(tmp_path / "hc")
     procs = []
     for r in range(world):
@@ -104,13 +102,24 @@ def test_cpp_hostcomm_world3(tmp_path):
     for p in procs:
         assert p.wait(timeout=120) == 0, p.stderr.read()
     blobs = [open("%s.%d" % (prefix, r), "rb").read() for r in range(world)]
-    assert blobs[0] == blobs[1] == blobs[2]
+    assert all(bl == blobs[0] for bl in blobs)
     b = np.frombuffer(blobs[0], np.uint8)
     assert np.array_equal(b[:128], (np.arange(128) * 7 + 3).astype(np.uint8))
-    sizes = [1013, 0, 3013]
+    sizes = [0 if r == 1 else 1000 * (r + 1) + 13 for r in range(world)]   # tests/cpp/test_astar.cpp hostcomm: rank 1 sends nothing
     pos = 128
     for r, n in enumerate(sizes):
         assert np.array_equal(b[pos:pos + n], (r * 31 + np.arange(n)).astype(np.uint8))
         pos += n
     recs = np.frombuffer(blobs[0][pos:], np.uint32).reshape(world, 2)
-    assert np.array_equal(recs, [[0, 0], [1, 1], [2, 4]])
+    assert np.array_equal(recs, [[r, r * r] for r in range(world)])
+
+
+def test_cpp_hostcomm_world3(tmp_path):
+    """The TCP star that ships the RCCL unique id and carries the host-side exchanges: broadcast, uneven all-gather
+    (one empty block), fixed-size all-gather, barrier -- three processes, identical results on every rank."""
+    _cpp_hostcomm(tmp_path, 3)
+
+
+def test_cpp_hostcomm_world8(tmp_path):
+    """The same protocol at the width BASELINE's configs 4/5 name (8 ranks of one node)."""
+    _cpp_hostcomm(tmp_path, 8)

@@ -25,8 +25,8 @@ EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_distributed")
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-from pyposegraphbuilder import scenes as SC
-from pyposegraphbuilder.scenes import write_scene, run_ranks, SCENES  # noqa: E402  (scene format, launcher: shared with bench.py)
+import scene_drivers as SC
+from scene_drivers import write_scene, run_ranks, SCENES  # noqa: E402  (scene format, launcher: shared with bench.py)
 
 
 # v340 / v5000: SURVEY 8d's density (k ~ 40 nearest views, median ~ 600 rows per pair, cap 8000: ~7 300 / ~106 000 pairs,

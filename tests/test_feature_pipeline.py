@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from pyposegraphbuilder import scenes as SC
+import scene_drivers as SC
 from pyposegraphbuilder import synthetic as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -39,6 +39,45 @@ def test_oracle_disconnected_components_and_gauge():
             np.testing.assert_allclose(Rgt[k] @ G, R[k], atol=1e-8)
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v4_rotavg.npz")
+GOLDEN_GRAPHS = ("exact", "noisy_outliers", "three_components", "sparse_ring")
+
+
+def _golden(name):
+    g = np.load(GOLDEN)
+    return {k: g[name + "/" + k] for k in ("V", "src", "dst", "Rrel", "weight", "R_gt", "R", "iters")}
+
+
+def _angles(Ra, Rb):
+    d = np.einsum("kij,kmj->kim", Ra, Rb)
+    return np.arccos(np.clip((np.trace(d, axis1=1, axis2=2) - 1) / 2, -1, 1))
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_oracle_reproduces_the_committed_rotation_averaging_fixture(name):
+    """four small graphs with their expected absolute rotations as committed data
+    (tests/golden/make_golden_rotavg.py).  The oracle of today must still produce them."""
+    g = _golden(name)
+    assert list(np.load(GOLDEN)["names"]) == list(GOLDEN_GRAPHS)
+    R, iters = RO.rotation_average(int(g["V"]), g["src"], g["dst"], g["Rrel"], g["weight"])
+    assert iters == int(g["iters"])
+    assert np.abs(R - g["R"]).max() < 1e-10   # (element-wise: arccos resolves nothing below 3e-8 rad near the identity)
+    if name == "exact":   # and the fixture itself is right where the answer is known in closed form
+        assert RO.align_error_deg(g["R"], g["R_gt"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_hip_rotation_averaging_matches_the_committed_fixture(name):
+    from pyposegraphbuilder import Engine
+    eng = Engine()
+    g = _golden(name)
+    R, iters = eng.rotation_average(g["src"], g["dst"], g["Rrel"], g["weight"], int(g["V"]))
+    assert _angles(R, g["R"]).max() < 1e-5, (name, _angles(R, g["R"]).max())   # rad: PCG vs sparse direct solve
+    assert abs(iters - int(g["iters"])) <= 1
+    eng.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("V,k,noise,outl,comps", [(40, 5, 0.0, 0.0, 1), (50, 6, 1.0, 0.15, 1), (340, 20, 1.0, 0.2, 1),
                                                   (30, 4, 0.5, 0.1, 3), (1500, 12, 2.0, 0.25, 1)])

@@ -1,10 +1,11 @@
 """The scene-graph surrogates of BASELINE configs 3/4/5 at SURVEY 8d's density (pyposegraphbuilder/synthetic.py
-make_scene_graph_dense, pyposegraphbuilder/scenes.py): generator properties, the bulk scene file, the stage-line parsers.  CPU."""
+make_scene_graph_dense, tests/scene_drivers.py): generator properties, the bulk scene file, the stage-line parsers.  CPU."""
 import struct
 
 import numpy as np
 
-from pyposegraphbuilder import scenes as SC, synthetic as S
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
 
 
 def small():

@@ -80,7 +80,7 @@ def test_wave_scheduler_equals_the_cpu_restatement(tmp_path, mode):
     device and oracle by <= 1e-13, which the chained guesses inherit)."""
     import oracle_lib as O
     import scheduler_oracle as SO
-    from pyposegraphbuilder import scenes as SC
+    import scene_drivers as SC
     V, wave = 80, 64
     g = S.make_scene_graph(V, k=8, seed=5, outlier_pair_frac=0.03)
     path = str(tmp_path / "scene.bin")
