@@ -23,6 +23,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_F32_PEAK_TF = 157.3    # vector fp32 peak
@@ -51,33 +52,194 @@ def replay_profile(kind, P, N, L):
         tj = json.load(open(f))
     except Exception as ex:  # noqa: BLE001
         return None, name, "unreadable: %s" % ex
-    if tj.get("pairs") != P or tj.get("corrs") != N:
+    if P is not None and (tj.get("pairs") != P or tj.get("corrs") != N):
         return None, name, "profiled on another workload (%s x %s)" % (tj.get("pairs"), tj.get("corrs"))
     sha = tj.get("source_sha256")
     if not sha:
         return None, name, "profile carries no source hash (taken before round 3)"
-    if sha != L.kernel_source_sha256():
+    if sha != (L.kernel_source_sha256() if kind in ("k1", "k2") else L.kernel_source_sha256(tuple(tj.get("source_files") or ("csrc/pgi_match.hip",)))):
         return None, name, "kernel sources changed since the profile was taken (hash mismatch): re-run scripts/profile_k1.sh"
     return tj, name, None
 
 
-def gpu_state():
-    """Best effort, no tool needed: the current shader clock (the starred line of pp_dpm_sclk) and the average socket power
-    from sysfs of the first amdgpu card that exposes them -- logged around legs whose rate depends on the granted clock."""
-    import glob
-    out = {}
-    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-        try:
-            for ln in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines():
-                if ln.strip().endswith("*"):
-                    out["sclk_mhz"] = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
-            for pw in glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_average")):
-                out["power_w"] = round(int(open(pw).read()) / 1e6, 1)
-            if out:
-                break
-        except Exception:  # noqa: BLE001
-            continue
-    return out or None
+class ClockSampler:
+    """The shader clock WHILE a leg runs (a reading before / after the leg is an idle reading): a side thread
+    polls the starred line of pp_dpm_sclk every ~2 ms between __enter__ and __exit__; .result() -> {samples, min, median, max}."""
+
+    def __init__(self, period_s=0.002):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.period, self.vals, self._stop, self._th = period_s, [], False, None
+
+    def _read(self):
+        for pth in self.paths:
+            try:
+                for ln in open(pth).read().splitlines():
+                    if ln.strip().endswith("*"):
+                        return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+            except Exception:  # noqa: BLE001
+                continue
+        return None
+
+    def _loop(self):
+        while not self._stop:
+            v = self._read()
+            if v:
+                self.vals.append(v)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        import threading
+        if self.paths:
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=1.0)
+
+    def result(self):
+        if not self.vals:
+            return None
+        v = np.array(self.vals)
+        return {"samples": int(len(v)), "min_mhz": int(v.min()), "median_mhz": int(np.median(v)), "max_mhz": int(v.max()),
+                "source": "pp_dpm_sclk polled by a side thread during the timed calls"}
+
+
+def pcie_h2d_peak_gbs(torch, device, mb=256, reps=4):
+    """The link's own rate for one large page-locked host -> device copy (what scripts/probes/first_copy_probe.hip measures):
+    the yardstick of the graph legs' `convert + upload` stage."""
+    h = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    d = torch.empty(mb << 20, dtype=torch.uint8, device=device)
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        d.copy_(h, non_blocking=True)
+        z.record()
+        torch.cuda.synchronize()
+        best = max(best, (mb << 20) / (a.elapsed_time(z) * 1e-3) / 1e9)
+    return best
+
+
+def amdahl(total_s, replicated_s):
+    """speed-up ceilings of a leg whose `replicated_s` seconds every rank repeats while the rest shards perfectly"""
+    total_s = max(total_s, 1e-9)
+    rep = min(max(replicated_s, 0.0), total_s)
+    return {"n%d" % n: round(total_s / (rep + (total_s - rep) / n), 2) for n in (2, 4, 8)}
+
+
+REPLICATED_STAGES = ("[Scheduler] candidate order", "[Scheduler] wave formation", "[Pose estimation] pose graph insertion",
+                     "[Pose estimation] per-pair arrays (host)", "[Visibility update]")
+
+
+def graph_companions(g, blob, m, mode, eng, torch, pcie_peak):
+    """SURVEY 8d's companions of a graph-level leg: K1's roofline on the leg's own rows (one resident call,
+    HIP events), the PCIe share of the upload stage, the stages every rank repeats with the Amdahl ceiling they imply, and --
+    config 4 only -- the CPU restatement over the SAME pairs, seeds and mode with every edge compared."""
+    from pyposegraphbuilder import synthetic as S
+    b = g["batch"]
+    P, rows = len(g["pairs"]), int(b["offsets"][-1])
+    st = m["stages_s"]
+    comp = {}
+    if mode == "shard":
+        db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=7)
+        e_dev, m_dev = eng.estimate_pose_batch(db)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            e_dev, m_dev = eng.estimate_pose_batch(db, e_dev, m_dev)
+            z.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(z))
+        k1_ms = float(np.median(ts))
+        k1_bytes = 17 * rows + EDGE_RECORD_BYTES * P
+        gbs = k1_bytes / (k1_ms * 1e-3) / 1e9
+        comp["roofline"] = {"bound": "hbm", "kernel": "estimate_pose_kernel (all size classes of one call, rows resident)",
+                            "kernel_ms": round(k1_ms, 3), "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes": k1_bytes,
+                            "rows_per_s": round(rows / (k1_ms * 1e-3), 1), "share_of_leg": round(k1_ms * 1e-3 / m["seconds"], 3),
+                            "traffic": None, "note": "17 B x rows + 200 B x pairs over this run's HIP-event time; K1 is VALU-issue bound by design (DESIGN.md)"}
+        res_edges = eng.edges_to_numpy(e_dev)
+        del db, e_dev, m_dev
+        # CPU restatement over the same pairs, same seed (7, as tests/cpp/test_distributed.cpp), adaptive mode, every host core
+        import oracle_lib as O
+        cores = int(O.lib().pgo_num_threads())
+        t0 = time.perf_counter()
+        e_cpu, _mk = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(), 7, threads=cores)
+        t_cpu = time.perf_counter() - t0
+        import scene_drivers as SC
+        _hdr, ed = SC.read_shard(blob, P)
+        same_leg = bool(np.array_equal(ed["E"], e_cpu["E"]) and np.array_equal(ed["status"], e_cpu["status"]) and np.array_equal(ed["n_inl"], e_cpu["n_inl"]))
+        same_res = bool(np.array_equal(res_edges["E"], e_cpu["E"]) and np.array_equal(res_edges["n_inl"], e_cpu["n_inl"]))
+        comp["cpu_baseline"] = {"value": round(P / t_cpu, 1), "unit": "pairs/s", "cores": cores, "kind": "port", "seconds": round(t_cpu, 2),
+                                "sample": "all %d pairs / %d rows of the leg (pose estimation only: no gather, no averaging); build CPU restatement, not OpenCV" % (P, rows),
+                                "gpu_matches_on_sample": same_leg and same_res, "pairs_compared": P, "cpu_model": cpu_model()}
+    up_key = "[Pose estimation] convert + upload + launch (chunks)"
+    if up_key in st and st[up_key] > 0:
+        up_bytes = 16 * rows + 17 * P
+        gbs = up_bytes / st[up_key] / 1e9
+        comp["pcie"] = {"stage": up_key, "seconds": st[up_key], "bytes": up_bytes, "achieved_GBs": round(gbs, 1),
+                        "link_peak_GBs_measured": round(pcie_peak, 1), "frac_of_link": round(gbs / pcie_peak, 3) if pcie_peak else None,
+                        "note": "f32 SoA rows + per-pair arrays over the stage's wall clock (conversion and kernel launches share that clock)"}
+    rep = sum(st.get(k, 0.0) for k in REPLICATED_STAGES) + m.get("seconds_rotation_averaging", 0.0)
+    comp["replicated_host_s"] = round(rep, 4)
+    comp["replicated_stages"] = {k: st[k] for k in REPLICATED_STAGES if k in st}
+    comp["replicated_stages"]["rotation averaging (replicas only, SURVEY 8e)"] = m.get("seconds_rotation_averaging", 0.0)
+    comp["amdahl_speedup_ceiling"] = amdahl(m["seconds"], rep)
+    return comp
+
+
+def compact_summary(out):
+    """The claims a reader of the driver's truncated record must be able to check, as one flat object."""
+    def dig(*keys):
+        v = out
+        for k in keys:
+            if not isinstance(v, dict) or k not in v:
+                return None
+            v = v[k]
+        return v
+    def r(v, n=4):
+        return round(v, n) if isinstance(v, float) else v
+    s = {"k1_edges_per_s": out.get("value"), "k1_ms": dig("roofline", "kernel_ms"), "k1_frac_hbm": dig("roofline", "frac"),
+         "k1_traffic_ratio": dig("roofline", "traffic_over_algorithmic"),
+         "k2_frac_hbm": dig("score_pose_k2", "frac_hbm"), "k2_traffic_ratio": dig("score_pose_k2", "traffic_over_algorithmic"),
+         "match_exact_frac_mfma": dig("match_descriptors", "roofline", "frac"),
+         "match_exact_ms_min_med_max": [dig("match_descriptors", "min_ms"), dig("match_descriptors", "ms"), dig("match_descriptors", "max_ms")],
+         "match_first_call_ms": dig("match_descriptors", "first_call_ms"),
+         "match_sclk_mhz_median": dig("match_descriptors", "sclk_during_timed_calls", "median_mhz"),
+         "match_screened_ms": dig("match_descriptors", "screened", "ms"),
+         "cpu_edges_per_s": dig("cpu_baseline", "value"), "cpu_cores": dig("cpu_baseline", "cores"), "cpu_parity": dig("cpu_baseline", "gpu_matches_on_sample")}
+    f = out.get("config3_from_features") or {}
+    c3 = [f.get(k, {}) for k in ("plain_every_pair_descriptor_matched", "astar_hashing_reference_guesses", "astar_hashing_rotation_guided")]
+    s["config3_s"] = [c.get("features_to_graph_s") for c in c3]
+    v5 = dig("graphs", "v5000") or {}
+    c4 = v5.get("config4_shard_estimate_gather_average", {})
+    c5 = v5.get("config5_astar_waves_rotation_guided", {})
+    s.update(config4_s=c4.get("seconds"), config4_k1_ms=dig("graphs", "v5000", "config4_shard_estimate_gather_average", "roofline", "kernel_ms"),
+             config4_cpu_pairs_per_s=dig("graphs", "v5000", "config4_shard_estimate_gather_average", "cpu_baseline", "value"),
+             config4_cpu_parity=dig("graphs", "v5000", "config4_shard_estimate_gather_average", "cpu_baseline", "gpu_matches_on_sample"),
+             config4_replicated_host_s=c4.get("replicated_host_s"), config4_amdahl_n8=(c4.get("amdahl_speedup_ceiling") or {}).get("n8"),
+             config5_guided_s=c5.get("seconds"), config5_replicated_host_s=c5.get("replicated_host_s"),
+             config5_amdahl_n8=(c5.get("amdahl_speedup_ceiling") or {}).get("n8"),
+             config5_reference_guess_s=v5.get("config5_astar_waves_reference_guesses", {}).get("seconds"))
+    worst = 0.0
+    for reps in [c.get("all_repetitions_s") for c in c3] + [v.get("all_repetitions_s") for v in v5.values() if isinstance(v, dict)]:
+        warm = (reps or [])[1:]
+        if len(warm) >= 2:
+            worst = max(worst, max(warm) / float(np.median(warm)))
+    s["worst_over_median_repetition"] = round(worst, 3) if worst else None
+    if out.get("n_gpus", 1) > 1:
+        s["exchange_verified"] = out.get("exchange_verified")
+        s["allgather_ms"] = dig("exchange", "allgather_ms")
+        s["multi_rank_identical"] = [v.get("identical_to_single_process") for v in v5.values() if isinstance(v, dict) and "identical_to_single_process" in v] or None
+    return {k: r(v) for k, v in s.items()}
 
 
 def cpu_model():
@@ -117,7 +279,7 @@ def opencv_column(b, m, thr, cores):
     return res
 
 
-def graph_level(world, require_rccl=False):
+def graph_level(world, require_rccl=False, eng=None, torch=None):
     """BASELINE configs 3 / 4 / 5 on the scene graphs of tests/scene_drivers.py (v340: ~7 300 pairs / 5 M rows, v5000:
     ~106 000 pairs / 77 M rows -- SURVEY 8d's k ~ 40 nearest views, median ~ 600 rows per pair, cap 8000) through the C++
     driver as `world` freshly started child processes (one per GPU; never an exec after HIP initialisation).  With
@@ -129,6 +291,7 @@ def graph_level(world, require_rccl=False):
     if not os.path.exists(SC.EXE):
         return {"skipped": "host driver %s not built" % SC.EXE}
     graphs = {}
+    pcie_peak = pcie_h2d_peak_gbs(torch, eng.device) if (eng is not None and world == 1) else None
     labels = {"shard": "config4_shard_estimate_gather_average", "waves": "config5_astar_waves_reference_guesses",
               "waves_guided": "config5_astar_waves_rotation_guided"}
     with tempfile.TemporaryDirectory() as tmpd:
@@ -148,6 +311,9 @@ def graph_level(world, require_rccl=False):
                 blob = open(single + ".0", "rb").read()
                 m = SC.graph_mode_metrics(g, blob, mode, *SC.seconds_of(so), SC.stages_of(so))
                 m["all_repetitions_s"] = SC.all_seconds_of(so)
+                m["all_repetitions_stage_s"] = SC.all_stages_of(so)
+                if eng is not None and world == 1 and name == "v5000":
+                    m.update(graph_companions(g, blob, m, mode, eng, torch, pcie_peak))
                 if world > 1:
                     multi = os.path.join(tmpd, "%s_%s_w%d" % (name, mode, world))
                     env = {"PGI_DRIVER_REPS": "4", "PGI_QUIET": "1"}
@@ -491,20 +657,22 @@ def main():
             imgs = [eng.prepare_descriptors(d, screen=screen) for d in descs]
             torch.cuda.synchronize()
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(13)]
-            state0 = gpu_state()
             res = None
-            for k, (e0, e1) in enumerate(evs):
+            for k, (e0, e1) in enumerate(evs[:3]):
                 e0.record()
                 res = eng.match_descriptors_batch(imgs, sel, raw=True)
                 e1.record()
-                if k < 3:
-                    torch.cuda.synchronize()
-            torch.cuda.synchronize()
-            state1 = gpu_state()
+                torch.cuda.synchronize()
+            with ClockSampler() as clk:   # the clock the box grants WHILE the ten timed calls run
+                for e0, e1 in evs[3:]:
+                    e0.record()
+                    res = eng.match_descriptors_batch(imgs, sel, raw=True)
+                    e1.record()
+                torch.cuda.synchronize()
             t = [e0.elapsed_time(e1) for e0, e1 in evs]
             timed = np.array(t[3:])
             return {"ms": float(np.median(timed)), "min_ms": float(timed.min()), "max_ms": float(timed.max()), "first_call_ms": float(t[0]),
-                    "calls": len(timed), "gpu_before": state0, "gpu_after": state1}, [x.cpu() for x in res]
+                    "calls": len(timed), "sclk": clk.result()}, [x.cpu() for x in res]
         tm, ref = time_match(False)
         tm_s, got_s = time_match(True)
         ms, ms_s = tm["ms"], tm_s["ms"]
@@ -515,11 +683,11 @@ def main():
         out["match_descriptors"] = {"pairs": len(sel), "keypoints": K, "ms": round(ms, 3), "min_ms": round(tm["min_ms"], 3),
                                     "max_ms": round(tm["max_ms"], 3), "first_call_ms": round(tm["first_call_ms"], 3), "timed_calls": tm["calls"],
                                     "pairs_per_s": round(len(sel) / (ms * 1e-3), 1),
-                                    "gpu_state_before": tm["gpu_before"], "gpu_state_after": tm["gpu_after"],
+                                    "sclk_during_timed_calls": tm["sclk"],
                                     "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
                                                  "frac": round(tf / 157.3, 4), "frac_best_call": round(tf_best / 157.3, 4),
                                                  "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
-                                                 "note": "median of the timed calls; the kernel draws the chip's full power, so the rate follows the clock the box grants (gpu_state_*)"},
+                                                 "note": "median of the timed calls; the kernel draws the chip's full power, so the rate follows the clock the box grants (sclk_during_timed_calls)"},
                                     "screened": {"ms": round(ms_s, 3), "min_ms": round(tm_s["min_ms"], 3), "max_ms": round(tm_s["max_ms"], 3),
                                                  "first_call_ms": round(tm_s["first_call_ms"], 3),
                                                  "pairs_per_s": round(len(sel) / (ms_s * 1e-3), 1),
@@ -654,7 +822,7 @@ def main():
         # the C++ host layer (tests/cpp/test_distributed.cpp: PoseGraphBuilder::estimateAndAverage / run + averageRotations)
         # as a child process, its own wall clock and stage clocks, warm repetition; global rotation error after gauge
         # alignment, AUC@5 of the estimated edges
-        out["graphs"] = graph_level(1)
+        out["graphs"] = graph_level(1, eng=eng, torch=torch)
         import scene_drivers as SC
         # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
         # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
@@ -684,6 +852,7 @@ def main():
                         errf = np.array([S.rot_err_deg(ef[key][1], fposes[key[1]][0] @ fposes[key[0]][0].T) for key in ef])
                         feat[label] = {"features_to_graph_s": tim[mode]["seconds"], "all_repetitions_s": tim[mode]["all_seconds"],
                                        "repetition_reported": tim[mode]["repetition"],  # the median of the warm repetitions
+                                       "all_repetitions_stage_s": tim[mode]["all_stages"],
                                        "stages_s": tim[mode]["stages"],
                                        "pairs_per_s": round(len(fpairs) / tim[mode]["seconds"], 1), "edges": len(ef),
                                        "descriptor_matching_runs": kf["matching_runs"], "tracklet_quick_matching_runs": kf["quick_matching_runs"],
@@ -691,6 +860,13 @@ def main():
                                        "poses_from_guess": kf["poses_from_guess"], "quirk_only_guesses": kf["quirk_only_guesses"],
                                        "edge_rot_err_auc_at_5deg": round(S.auc_at(np.concatenate([errf, np.full(len(fpairs) - len(ef), np.inf)]), 5.0), 4),
                                        "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
+                    gj, gname, gwhy = replay_profile("guided", None, None, L)
+                    feat["dominant_kernel"] = dict(
+                        {"kernel": "guided_scan_tile_kernel", "bound": "hbm (L2-resident gate records + descriptor rows)"},
+                        **({k: gj.get(k) for k in ("kernel_us_trace_avg", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
+                                                    "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "lane_utilisation", "vgprs", "spilled_vgprs")}
+                           if gj else {}),
+                        source=("replayed from %s; source hash matches the loaded build" % gname) if gj else "none: %s" % gwhy)
                     if slow:  # the upload stage reports itself when it is far slower than PCIe allows (a shared box now and then)
                         feat["slow_uploads"] = slow[:6]
                 else:
@@ -760,6 +936,7 @@ def main():
                     raise
         dist.barrier()
     if rank == 0:
+        out["summary"] = compact_summary(out)   # LAST key, < 1 KB: what the driver's 8 KB tail of this line must still show
         print(json.dumps(out))
     if comm is not None:
         comm.close()

@@ -575,13 +575,15 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     auto local_optimise = [&]() {
         if constexpr (!GUESS) return;  // only the guess variants call it (keeps the plain kernel's code unchanged)
         int ni_first = -1;
-        if (prm.lo_iters) {
-            float bE0[9];
+        if constexpr (NW > 1) {  // (a one-wavefront workgroup builds every normal matrix inside refit_wave0)
+            if (prm.lo_iters) {
+                float bE0[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
-            int td = tid;
-            asm volatile("" : "+v"(td));
-            ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ, wscr_all + W_DOUBLES, sh, td);
+                for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
+                int td = tid;
+                asm volatile("" : "+v"(td));
+                ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ, wscr_all + W_DOUBLES, sh, td);
+            }
         }
         if (w == 0) {
             for (uint32_t it = 0; it < prm.lo_iters; ++it) {
@@ -619,8 +621,9 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
         const uint64_t rng_g = mix64(a.seed ^ mix64(a.pair_id_base + pair));
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const bool mine = ln < 8;
-        const uint32_t h = (uint32_t)(w * 8 + (mine ? ln : 0));
+        constexpr int kPerWave = 32 / NW;  // 32 two-point hypotheses, shared evenly by the workgroup's wavefronts
+        const bool mine = ln < kPerWave;
+        const uint32_t h = (uint32_t)(w * kPerWave + (mine ? ln : 0));
         const uint32_t i0 = draw_index(rng_g, 0x40000000u + h, 0u, n);
         uint32_t i1 = i0;
         for (uint32_t k = 1; k < 64u && i1 == i0; ++k) i1 = draw_index(rng_g, 0x40000000u + h, k, n);
@@ -906,7 +909,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 // (same steps as local_optimise() above, spelled out: inside the round loop the compiler schedules the
                 // inline form measurably better than the shared lambda -- 2 % on BASELINE config 2)
                 int ni_first = -1;
-                if (prm.lo_iters) {  // every wavefront is here anyway: build the first refit's normal matrix together
+                if (NW > 1 && prm.lo_iters) {  // every wavefront is here anyway: build the first refit's normal matrix together
                     float bE0[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
@@ -945,7 +948,11 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                     }
                     __builtin_amdgcn_s_setprio(0);
                 }
-                deferred = true;
+                if constexpr (NW == 1) {  // nobody solved a speculative round meanwhile: the sequential order itself
+                    if (terminated(hyps)) break;
+                } else {
+                    deferred = true;
+                }
             } else if (terminated(hyps)) {
                 break;
             }
@@ -979,11 +986,11 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     // Wave 0 decomposes the model (3x3 SVD spread over three lanes, pgi_device.hpp) while waves 1..3 write the inlier
     // mask; the cheirality vote needs both and follows the barrier.
     uint32_t mc = 0;
-    if (ew == 0) {
-        decompose_wave(finalE, sh->Rt, elane);
-    } else {
-        for (uint32_t base = 0; base < npad; base += NT - 64) {
-            const uint32_t i = base + (uint32_t)(etid - 64);
+    if (ew == 0) decompose_wave(finalE, sh->Rt, elane);
+    if (NW == 1 || ew != 0) {  // (a one-wavefront workgroup does both, one after the other)
+        constexpr uint32_t kMaskLanes = NW == 1 ? 64u : (uint32_t)(NT - 64);
+        for (uint32_t base = 0; base < npad; base += kMaskLanes) {
+            const uint32_t i = base + (uint32_t)(NW == 1 ? etid : etid - 64);
             const float nanv = __builtin_nanf("");
             const float4 p = (i < npad) ? rows.get(i) : make_float4(nanv, nanv, nanv, nanv);
             float r2, den;
@@ -1704,7 +1711,10 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     //  half as many workgroups, and it has no hybrid class -- 2 000 rows fit whole)
     //  -DPGI_NW=2: eight / six / four / two workgroups per CU -- the same 16 / 12 / 8 / 4 wavefronts per CU as the default's levels)
     constexpr int kLevelWgs[4] = {std::max(1, 16 / NW), std::max(1, 12 / NW), std::max(1, 8 / NW), std::max(1, 4 / NW)};
-    const uint32_t cap4 = rows_cap(kLevelWgs[0]), cap3 = rows_cap(kLevelWgs[1]), cap2 = rows_cap(kLevelWgs[2]), cap1 = rows_cap(kLevelWgs[3]);
+    // (NW < 4: two classes only -- rows whole in LDS at the top occupancy, and everything larger HYBRID at the same occupancy)
+    const uint32_t cap4 = rows_cap(kLevelWgs[0]);
+    const uint32_t cap3 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[1]), cap2 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[2]),
+                   cap1 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[3]);
     bool hybrid = false;
     int class_wgs = kLevelWgs[0];  // workgroups per CU of the class being launched (sizes a persistent grid)
     hipStream_t ls = stream;  // the stream the next launch goes to (a class's side stream when classes overlap)
@@ -1737,7 +1747,11 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     // PGI_LDS_MIN_WGS overrides the default for experiments.
     const uint32_t lds_cap = ctx->lds_min_wgs >= 4 ? cap4 : ctx->lds_min_wgs == 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
     if (cap <= cap4 || b->n_pairs < 64) {  // every pair already gets the top occupancy (or the batch is tiny): one launch
-        if (cap <= lds_cap) launch_lds(cap); else launch_global();
+        if (NW < 4 && cap > cap4) {  // (a tiny batch of large pairs in the builds that know two classes: the hybrid one)
+            hybrid = true;
+            launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));
+            hybrid = false;
+        } else if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // bucket by row count on the device, one launch per occupancy class
         if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
         const size_t need = ((size_t)5 * b->n_pairs + 16) * sizeof(uint32_t);  // counts[8] | heads[8] | five lists
@@ -1787,14 +1801,14 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
 #else
             a.pair_head = ctx->k1_persistent && !guesses ? heads + k : nullptr;  // (the guess variants have no loop)
 #endif
-            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows && NW == 4 ? 4 : kLevelWgs[k];
+            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows && NW <= 4 ? kLevelWgs[0] : kLevelWgs[k];
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
             if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
-            hybrid = k == 1 && ctx->hybrid_rows && NW == 4;
-            if (hybrid) launch_lds(rows_cap_of(4, fixed_stash));  // 1280 rows in LDS next to the sample stash
+            hybrid = k == 1 && ctx->hybrid_rows && NW <= 4;
+            if (hybrid) launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));  // 1280 rows in LDS next to the sample stash (NW = 4)
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;
             keep(hipGetLastError());

@@ -288,7 +288,26 @@ struct PoseGraphBuilder::Staging {
     hipEvent_t smallUp = nullptr;
     std::unique_ptr<HostPool> pool;
     std::mutex busy;  // one estimatePoses at a time per process
+    // processFeatures (round 5): the feature arena (every view's keypoints, descriptors and prepared copies: 3.5 GB at config
+    // 3's size) and the waves' device pool are LENT to one run at a time and never released -- a fresh hipMalloc of the arena
+    // per call took 0.3-0.45 s in one repetition out of four on the driver's box (0.003 s in the others), which was the whole
+    // of the "slow repetitions" of VERDICT r4 (bench.py: all_repetitions_stage_s).  A second builder running at the same time
+    // finds the lock taken and allocates privately, as before.
+    std::mutex featBusy;
+    void* featArena = nullptr;
+    size_t featArenaBytes = 0;
+    DevPool featPool;
+    char* lendArena(size_t bytes) {  // featBusy held by the caller
+        if (bytes > featArenaBytes) {
+            if (featArena) (void)hipFree(featArena);
+            featArena = nullptr; featArenaBytes = 0;
+            if (hipMalloc(&featArena, bytes + bytes / 8) != hipSuccess) throw PgiError("hipMalloc failed");
+            featArenaBytes = bytes + bytes / 8;
+        }
+        return (char*)featArena;
+    }
     ~Staging() {
+        if (featArena) (void)hipFree(featArena);
         if (dev) (void)hipFree(dev);
         if (small) (void)hipHostFree(small);
         for (void* r : ring) if (r) (void)hipHostFree(r);
@@ -399,7 +418,8 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     const size_t o_x1 = 0, o_y1 = o_x1 + up(rows * 4), o_x2 = o_y1 + up(rows * 4), o_y2 = o_x2 + up(rows * 4),
                  o_off = o_y2 + up(rows * 4), o_thr = o_off + up((L + 1) * 8), o_guess = o_thr + up(L * 8),
                  o_has = o_guess + up(L * 96), o_Eg = o_has + up(L), o_tau = o_Eg + up(L * 72), o_small_end = o_tau + up(L * 8),
-                 o_cnt = o_small_end, o_masks = o_cnt + up(L * 4), dev_total = o_masks + up(rows);
+                 o_cnt = o_small_end, o_masks = o_cnt + up(L * 4), o_all = o_masks + up(rows),
+                 dev_total = o_all + (d_edges_out ? 0 : up(P * sizeof(pgi_edge)));  // the gathered table, unless the caller brings one
     if (!staging) staging = Staging::shared(engineDevice(engine->get()));
     std::lock_guard<std::mutex> stagingBusy(staging->busy);
     HIP_OK(hipSetDevice(engineDevice(engine->get())));  // this thread's allocations, stream and events belong to the engine's device
@@ -445,12 +465,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         }
     };
     // the gathered table (P records); this rank's block is written in place at [lo, hi)
-    std::unique_ptr<DevBuf> own_all;
-    pgi_edge* d_all = d_edges_out;
-    if (!d_all) {
-        own_all.reset(new DevBuf(P * sizeof(pgi_edge)));
-        d_all = own_all->as<pgi_edge>();
-    }
+    pgi_edge* const d_all = d_edges_out ? d_edges_out : (pgi_edge*)(db + o_all);  // (in the grow-only block: no hipMalloc per wave)
     mark("per-pair arrays (host)");
     double convertSeconds = 0, searchSeconds = 0;
     if (L) {
@@ -892,8 +907,18 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         lay[v].f16 = take((size_t)n_pad * PGI_DESC_DIM * 2);
     }
     const std::chrono::steady_clock::time_point uploadStart = std::chrono::steady_clock::now();
-    DevBuf arena(std::max<size_t>(arenaBytes, 256));
-    char* const ab = arena.as<char>();
+    if (!staging) staging = Staging::shared(engineDevice(engine->get()));
+    HIP_OK(hipSetDevice(engineDevice(engine->get())));
+    // the process-wide arena and wave pool if nobody else is using them (Staging::featBusy), private memory otherwise; the
+    // device is idle on them before the loan ends (every exit path, also an exception's)
+    struct Loan {
+        std::unique_lock<std::mutex> lock;
+        pgi_ctx* ctx;
+        ~Loan() { if (lock.owns_lock()) (void)pgi_synchronize(ctx); }
+    } loan{std::unique_lock<std::mutex>(staging->featBusy, std::try_to_lock), ctx};
+    std::unique_ptr<DevBuf> ownArena;
+    if (!loan.lock.owns_lock()) ownArena.reset(new DevBuf(std::max<size_t>(arenaBytes, 256)));
+    char* const ab = loan.lock.owns_lock() ? staging->lendArena(std::max<size_t>(arenaBytes, 256)) : ownArena->as<char>();
     if (std::getenv("PGI_PIPELINE_TIMING"))
         std::fprintf(stderr, "[processFeatures] arena of %.2f GB allocated in %.3f s\n", arenaBytes / 1e9,
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - uploadStart).count());
@@ -916,9 +941,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
         // buffer travels as one asynchronous copy on the copy stream, the per-view preparation kernels of the run wait for
         // it on the engine's stream -- while the team already fills the next buffer.  A view whose arrays are page-locked
         // already (hipHostMalloc / hipHostRegister / pgi_host_register) is copied from where it lies.
-        if (!staging) staging = Staging::shared(engineDevice(engine->get()));
         std::lock_guard<std::mutex> stagingBusy(staging->busy);
-        HIP_OK(hipSetDevice(engineDevice(engine->get())));
         staging->init(kCoreNumber ? kCoreNumber : 1);
         auto pageLocked = [](const void* p) {
             hipPointerAttribute_t at{};
@@ -1021,7 +1044,8 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
 
     typedef std::chrono::steady_clock Clock;
     auto since = [](Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); };
-    DevPool pool;
+    DevPool ownPool;
+    DevPool& pool = loan.lock.owns_lock() ? staging->featPool : ownPool;
     // The path searches of the NEXT wave run on the host while this wave's guided matching occupies the GPU: they read the
     // pose graph and the visibility as this wave's commit leaves them -- exactly what they would see at the start of the
     // next wave -- so the guesses, the counters and the graph are the same as without the overlap.

@@ -1,6 +1,7 @@
 import os, sys, subprocess, tempfile, numpy as np
 ROOT = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.environ.get("GRAFT_REPO_ROOT", ".")
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pyposegraphbuilder import synthetic as S
 import scene_drivers as SC
 views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)

@@ -10,6 +10,7 @@ phases of every estimatePoses call on stderr."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from pyposegraphbuilder import synthetic as S
 import scene_drivers as SC

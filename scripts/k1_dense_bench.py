@@ -10,6 +10,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from pyposegraphbuilder import _lib as L, synthetic as S
 import scene_drivers as SC

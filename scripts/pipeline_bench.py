@@ -6,6 +6,7 @@ import os, struct, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pyposegraphbuilder import synthetic as S
 import scene_drivers as SC
 full = len(sys.argv) > 1 and sys.argv[1] == "config3"

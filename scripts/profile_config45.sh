@@ -7,6 +7,7 @@ cd $R
 python3 - <<'PY'
 import sys
 sys.path.insert(0, "pose-graph-initialization_amd")
+sys.path.insert(0, "tests")
 import scene_drivers as SC
 g, wave = SC.make_scene("v5000")
 SC.write_scene_bulk("/tmp/config45_scene.bin", g, wave, sim_kind=2)

@@ -5,6 +5,7 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pyposegraphbuilder import _lib as L
 L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi_prof.so")
 import torch

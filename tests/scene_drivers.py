@@ -193,6 +193,14 @@ def stages_of(stdout):
     return {k2.strip(): float(v) for k2, v in re.findall(r"([^=;]+)=([0-9.]+);", line[len("stages:"):])}
 
 
+def all_stages_of(stdout):
+    """the `stages:` line of EVERY repetition, in order: [{RunningStatistics time key: seconds}] (a slow
+    repetition must show which stage carried the excess, not only the reported one)"""
+    import re
+    return [{k2.strip(): round(float(v), 4) for k2, v in re.findall(r"([^=;]+)=([0-9.]+);", ln[len("stages:"):])}
+            for ln in stdout.splitlines() if ln.startswith("stages:")]
+
+
 # ---- feature-level scenes (tests/cpp/test_pipeline.cpp: PoseGraphBuilder::processFeatures) -------------------------------------
 PIPELINE_EXE = os.path.join(PKG, "test_pipeline")
 PIPELINE_KEYS = ("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess", "hypotheses",
@@ -251,7 +259,7 @@ def pipeline_timings(stdout):
     for mode, rs in reps.items():
         warm = list(range(1, len(rs))) if len(rs) > 1 else [0]
         k = sorted(warm, key=lambda i: rs[i]["seconds"])[(len(warm) - 1) // 2]
-        out[mode] = dict(rs[k], all_seconds=[r["seconds"] for r in rs], repetition=k)
+        out[mode] = dict(rs[k], all_seconds=[r["seconds"] for r in rs], all_stages=[r["stages"] for r in rs], repetition=k)
     return out
 
 

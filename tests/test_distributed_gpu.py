@@ -239,3 +239,70 @@ def test_python_builder_run_is_the_cpp_scheduler(tmp_path):
             assert builder.statistics["paths_found"] > 0 and builder.statistics["poses_from_guess"] > 0
     finally:
         builder.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["shard", "waves_guided"])
+def test_eight_ranks_over_the_host_transport_match_single_process(scene, mode):
+    """The width BASELINE's configs 4/5 name: EIGHT ranks (processes) of the C++ driver sharing the one GPU of the box, edge
+    records over the host transport (RCCL refuses ranks that share a device): the shard / gather / commit protocol at world 8
+    reproduces the single-process result byte for byte on every rank.  (Round 4 never ran it wider than 3.)"""
+    if scene["name"] != "v340":
+        pytest.skip("eight processes on one GPU: the V = 340 scene")
+    d = scene["dir"]
+    run_ranks([EXE, scene["path"], str(d / ("w1_" + mode)), mode], 1)
+    o8 = run_ranks([EXE, scene["path"], str(d / ("w8_" + mode)), mode], 8)
+    assert len(o8) == 8 and all("transport host" in o and "/8 " in o for o in o8)
+    single = open(str(d / ("w1_" + mode)) + ".0", "rb").read()
+    for r in range(8):
+        assert open(str(d / ("w8_" + mode)) + ".%d" % r, "rb").read() == single, r
+    # eight uneven, row-balanced, non-empty blocks really happened
+    from pyposegraphbuilder import distributed as D
+    lo_hi = D.shard_bounds(np.diff(scene["g"]["batch"]["offsets"].astype(np.int64)), 8)
+    assert len({hi - lo for lo, hi in lo_hi}) > 1 and all(hi > lo for lo, hi in lo_hi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("guided", [False, True])
+def test_c_abi_run_pairs_is_the_driver_on_the_dense_scene(scene, guided):
+    """pgih_run_pairs of libpgi_host.so (include/pgi_host.h) -- the installed entry point a non-C++ caller binds -- on the
+    DENSE V = 5000 scene (106 151 pairs, 76.6 M rows handed over as ONE flat N x 4 CV_64F block): the pose graph it returns is
+    the one tests/cpp/test_distributed.cpp's scheduled run writes, edge for edge in insertion order, bit for bit, with the same
+    scheduler counters.  (Round 4 compared the two on the thin V = 340 scene only; bench.py's graph legs time the driver.)"""
+    import ctypes as C
+    from pyposegraphbuilder import PoseGraphBuilder
+    if scene["name"] != "v5000":
+        pytest.skip("the dense V = 5000 scene")
+    g, d, V, wave = scene["g"], scene["dir"], scene["V"], scene["wave"]
+    mode = "waves_guided" if guided else "waves"
+    out = str(d / ("abi_" + mode))
+    run_ranks([EXE, scene["path"], out, mode], 1)
+    stats, edges = SC.read_waves(open(out + ".0", "rb").read())
+    b = g["batch"]
+    P = len(g["pairs"])
+    corr = np.empty((int(b["offsets"][-1]), 4), np.float64)
+    for c, k in enumerate(("x1", "y1", "x2", "y2")):
+        corr[:, c] = b[k]
+    src, dst = np.ascontiguousarray(g["pairs"][:, 0], np.uint32), np.ascontiguousarray(g["pairs"][:, 1], np.uint32)
+    sim, thr = np.ascontiguousarray(SC.pair_similarity(g), np.float64), np.full(P, 7.5e-4)
+    off = np.ascontiguousarray(b["offsets"], np.uint64)
+    rec = np.zeros(P, [("src", "<u4"), ("dst", "<u4"), ("score", "<f8"), ("R", "<f8", 9), ("t", "<f8", 3)])
+    n_edges, st = C.c_uint32(0), np.zeros(16, np.uint64)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    builder = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", True, True, True)
+    try:
+        lib, h = builder._host()
+        assert lib.pgih_set_rotation_guided(h, int(guided)) >= 0
+        rc = lib.pgih_run_pairs(h, V, P, ptr(src), ptr(dst), ptr(sim), ptr(thr), ptr(off), ptr(corr), wave, 0, ptr(rec), P,
+                                C.byref(n_edges), ptr(st))
+        assert rc >= 0, lib.pgih_last_error()
+    finally:
+        builder.close()
+    assert n_edges.value == len(edges) == stats["graph_edges"] > 0.9 * int((~g["wrong"]).sum())
+    got = rec[:n_edges.value]
+    for key in ("src", "dst", "score", "R", "t"):
+        assert np.array_equal(got[key], edges[key]), key
+    for k, key in enumerate(("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes", "poses_from_guess",
+                             "hypotheses", "waves", "graph_edges", "quirk_only_guesses")):
+        want = stats["quirk_only_guesses"] if key == "quirk_only_guesses" else stats[key]
+        assert int(st[k]) == want, (key, int(st[k]), want)
