@@ -84,5 +84,6 @@ struct pgi_ctx {
     hipStream_t class_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t class_fork = nullptr, class_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int class_overlap = 1;  // env PGI_CLASS_OVERLAP=0: one class after the other on the caller's stream
+    int k1_nw = 0;          // wavefronts per pair of K1: 0 = by batch size (launch_estimate), 1 / 2 / 4 forced (env PGI_K1_NW)
     int k1_persistent = 1;  // size-class launches as persistent grids (resident workgroups pull pairs); env PGI_K1_PERSISTENT=0: grid = pairs
 };

@@ -28,14 +28,18 @@
 
 namespace pgi {
 
-#ifndef PGI_NW
-#define PGI_NW 4               // (-DPGI_NW=8: the experimental 8-wavefront build, `make libpgi_nw8.so`; DESIGN.md section 7 "Round 4")
-#endif
-constexpr int NW = PGI_NW;     // wavefronts per workgroup
-constexpr int NT = NW * 64;    // threads per workgroup
+// Wavefronts per workgroup (= per image pair) are a TEMPLATE parameter of K1 since round 5: one, two or four.  A pair's fit
+// is the same instruction stream whatever the number (hypotheses, scores and merges are order-free), so every choice gives
+// the same bits; what changes is how the work of MANY pairs packs onto the chip.  With one wavefront per pair nothing waits at
+// a round barrier and no wavefront idles beside wave 0's refits -- 14 % more pairs per second on the dense V = 5000 scene's
+// 106 000 pairs -- but a pair then takes four times as long, and so does the wind-down of a launch: small batches stay with
+// four (launch_estimate picks; PGI_K1_NW overrides).
+constexpr int kMaxNW = 4;
+constexpr uint32_t kNw1Pairs = 98304, kNw2Pairs = 12288;  // launch_estimate's rule (batch sizes from which 1 / 2 wavefronts per pair pay)
 constexpr int QCAP = 40;       // models per wavefront pass (4 hypotheses x 10 roots)
 constexpr double QMAGIC = 393216.0;  // 1.5 * 2^18: summands rounded to multiples of 2^-34
 
+template <int NW>
 struct WgShared {
     float bestE[9];
     int best_score;  // -1: none
@@ -83,6 +87,10 @@ struct K1Args {
     const float* src_y1;
     const float* src_x2;
     const float* src_y2;
+    // Streamed batches (pgi_estimate_pose_batch_streamed): *ready = how many leading pairs of the batch are resident (rows,
+    // thresholds, guesses); the caller's copy stream raises it behind every chunk it uploads WHILE this launch already works on
+    // the earlier ones.  nullptr: everything was resident before the launch.
+    const uint32_t* ready;
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -280,9 +288,10 @@ PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, co
 
 // Workgroup-cooperative variant (all NW wavefronts; two barriers): used for the FIRST refit after a
 // merge, where every wavefront is synchronised anyway.  partial: NW*45 doubles of dead scratch.
-template <int LDS_PTS>
+template <int LDS_PTS, int NW>
 PGI_DEV uint32_t normal_matrix_wg(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
-                                  double* loA, double* partial, WgShared* sh, int tid) {
+                                  double* loA, double* partial, WgShared<NW>* sh, int tid) {
+    constexpr int NT = NW * 64;
     const int lane = tid & 63, w = tid >> 6;
     uint32_t cnt = 0;
 #pragma unroll
@@ -422,7 +431,7 @@ PGI_DEV void jacobi9_wave(double* A, double* V, double* basis0, int lane) {
 // LDS: A, V and the triangle scratch alias wave 0's unused solver groups; the queue is wave 0's.
 template <int LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
-                             float thr2, double* wscr0, WgShared* sh, int lane, int floor_score, uint32_t n_bar,
+                             float thr2, double* wscr0, uint32_t* qhyp0, int lane, int floor_score, uint32_t n_bar,
                              int& r_score, uint32_t& r_ninl, int& r_idx, Prof& prof, int ni_pre = -1,
                              uint32_t lin_pct = 0u) {
     double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
@@ -455,13 +464,13 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
 #pragma unroll
         for (int c = 0; c < 9; ++c) E32[c] = (float)(__shfl(ev, c) * inv);
         wave_sync();
-        cnt = enqueue_models(lane == 0 && (n2 > 0.0), E32, 0u, queue0, sh->q_hyp[0], lane);
+        cnt = enqueue_models(lane == 0 && (n2 > 0.0), E32, 0u, queue0, qhyp0, lane);
     } else {
         const int g = lane >> 4, s = lane & 15;  // only group 0 holds the refit; groups 1..3 idle along
         const bool valid = backend_group<false, 14, false>(group_scratch(wscr0, g), s, g * 16,
                                                             [](int) { return make_float4(0.f, 0.f, 0.f, 0.f); }, E32, nullptr, prof);
         wave_sync();
-        cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, sh->q_hyp[0], lane);
+        cnt = enqueue_models(valid && g == 0, E32, 0u, queue0, qhyp0, lane);
     }
     wave_sync();
     prof.mark<20>();
@@ -473,8 +482,9 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     return ni;
 }
 
-template <int LDS_PTS, bool GUESS>
+template <int LDS_PTS, bool GUESS, int NW>
 __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pair, char* smem) {
+    constexpr int NT = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index: uniform, lives in an SGPR
     const uint64_t o = a.off[pair];
@@ -483,9 +493,9 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
 
     float4* pts = reinterpret_cast<float4*>(smem);
     double* wscr_all = reinterpret_cast<double*>(smem + (size_t)a.pts_cap * 16);  // NW * W_DOUBLES
-    WgShared* sh = reinterpret_cast<WgShared*>(wscr_all + NW * W_DOUBLES);
+    WgShared<NW>* sh = reinterpret_cast<WgShared<NW>*>(wscr_all + NW * W_DOUBLES);
     // sample stash of the variants whose rows may live in HBM/L2 (NW * 4 groups * 5 rows), behind the shared state
-    float4* smp_stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(sh) + ((sizeof(WgShared) + 15) & ~(size_t)15));
+    float4* smp_stash = reinterpret_cast<float4*>(reinterpret_cast<char*>(sh) + ((sizeof(WgShared<NW>) + 15) & ~(size_t)15));
     (void)smp_stash;
     double* wscr = wscr_all + w * W_DOUBLES;
     float* queue = reinterpret_cast<float*>(wscr + W_REGA);  // overlays region A after each solve
@@ -582,7 +592,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
                 int td = tid;
                 asm volatile("" : "+v"(td));
-                ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ, wscr_all + W_DOUBLES, sh, td);
+                ni_first = (int)normal_matrix_wg<LDS_PTS, NW>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ, wscr_all + W_DOUBLES, sh, td);
             }
         }
         if (w == 0) {
@@ -596,7 +606,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 uint32_t r_ninl;
                 int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                 asm volatile("" : "+v"(ln));
-                const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best, cur_ninl,
+                const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best, cur_ninl,
                                                                 r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct);
                 if (ni < 5) break;
                 if (lane == 0) sh->lo_runs += 1;
@@ -742,7 +752,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
             __builtin_amdgcn_s_setprio(3);  // (the workgroup's critical path, as in the round loop)
             int rs0, ri0;
             uint32_t rn0;
-            const uint32_t ni0 = refit_wave0<LDS_PTS>(rows, n, npad, Ef, tau2, thr2, wscr_all, sh, lane, -1, 0u, rs0, rn0, ri0, prof);
+            const uint32_t ni0 = refit_wave0<LDS_PTS>(rows, n, npad, Ef, tau2, thr2, wscr_all, sh->q_hyp[0], lane, -1, 0u, rs0, rn0, ri0, prof);
             if (lane == 0) {
                 sh->lo_ni = ni0;
                 sh->lo_score = rs0;
@@ -916,7 +926,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                     // thread id rebuilt from the wave index (uniform) and a fresh lane count: no VGPR carried -- and
                     // spilled -- across the round loop for this once-per-improvement step
                     const int td = (w << 6) + fresh_lane_id();
-                    ni_first = (int)normal_matrix_wg<LDS_PTS>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ,
+                    ni_first = (int)normal_matrix_wg<LDS_PTS, NW>(rows, npad, bE0, thr2, wscr_all + W_REGA + G_REGA_SZ,
                                                               wscr_all + W_DOUBLES, sh, td);
                 }
                 if (w == 0) {  // n-point refits while they improve (only wave 0 touches the best from here to A)
@@ -933,7 +943,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                         uint32_t r_ninl;
                         int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                         asm volatile("" : "+v"(ln));
-                        const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh, ln, cur_best,
+                        const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best,
                                                                        cur_ninl, r_score, r_ninl, r_idx, prof,
                                                                        it == 0 ? ni_first : -1, prm.lo_linear_pct);
                         if (ni < 5) break;
@@ -1078,6 +1088,16 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     prof.flush(a.prof, lane);
 }
 
+// Streamed batches: a workgroup that took pair `pair` waits until the caller's copy stream has announced it.  Thread 0 polls
+// with a SYSTEM-scope acquire load (the writer is the copy engine; the acquire also drops whatever stale lines this CU / XCD
+// holds of the just-written rows -- a cache line can straddle two chunks), the workgroup barrier passes the order on.
+PGI_DEV void wait_until_resident(const uint32_t* ready, uint32_t pair) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= pair) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+}
+
 // The kernel: one pair per workgroup (grid = pairs), or -- a size-bucket launch -- workgroups that take entries of the
 // bucket's list: entry blockIdx.x when the grid covers the whole list, or (round 4, the default for the variants WITHOUT the
 // guess path) as a PERSISTENT grid of as many workgroups as the chip keeps resident, each taking whatever entry the shared
@@ -1087,8 +1107,8 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
 // registers -- 2 / 26 / 4 spilled VGPRs in the three variants, none of them inside the hypothesis passes (same time as the
 // loop-free build at every N when the grid covers the list) -- but 64-164 in the guess variants, which therefore keep the
 // one-pair form (-DPGI_K1_LOOP_GUESS builds them with the loop for experiments).
-template <int LDS_PTS, bool GUESS>
-__global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
+template <int LDS_PTS, bool GUESS, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PGI_K1_LOOP_GUESS
     constexpr bool kLoop = true;
@@ -1111,7 +1131,8 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
                 if (slot >= *a.pair_count) return;
                 pair = a.pair_list[slot];
             }
-            estimate_pair<LDS_PTS, GUESS>(a, pair, smem);
+            if (a.ready) wait_until_resident(a.ready, pair);
+            estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
             if (!persistent) return;
             __syncthreads();  // the pair's results are written, its LDS state is dead
         }
@@ -1121,7 +1142,8 @@ __global__ __launch_bounds__(NT, 4) void estimate_pose_kernel(const K1Args a) {
             if (blockIdx.x >= *a.pair_count) return;
             pair = a.pair_list[blockIdx.x];
         }
-        estimate_pair<LDS_PTS, GUESS>(a, pair, smem);
+        if (a.ready) wait_until_resident(a.ready, pair);
+        estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
     }
 }
 
@@ -1492,8 +1514,32 @@ std::string& last_error_ref() {
 }
 }  // namespace pgi
 
-constexpr size_t kStashBytes = (size_t)NW * 4 * 5 * sizeof(float4);  // 1280 B, variants 0 and 2 only
-static size_t k1_fixed_lds(bool stash) { return (size_t)NW * W_DOUBLES * 8 + sizeof(WgShared) + 64 + (stash ? kStashBytes : 0); }
+// LDS of a K1 workgroup of `nw` wavefronts besides its staged rows; the sample stash (nw x 4 groups x 5 rows; 1280 B at four
+// wavefronts) belongs to the variants whose rows may lie outside LDS (0 and 2)
+static size_t k1_fixed_lds(int nw, bool stash) {
+    const size_t shared = nw == 1 ? sizeof(WgShared<1>) : nw == 2 ? sizeof(WgShared<2>) : sizeof(WgShared<4>);
+    return (size_t)nw * W_DOUBLES * 8 + shared + 64 + (stash ? (size_t)nw * 4 * 5 * sizeof(float4) : 0);
+}
+// the kernel instance for (rows variant, guess path, wavefronts per pair)
+template <int NWv>
+static void launch_k1(int lds_pts, bool guesses, dim3 grid, size_t lds, hipStream_t s, const K1Args& a) {
+    const dim3 block(NWv * 64);
+    if (lds_pts == 2) {
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true, NWv>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<2, false, NWv>), grid, block, lds, s, a);
+    } else if (lds_pts == 1) {
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true, NWv>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<1, false, NWv>), grid, block, lds, s, a);
+    } else if constexpr (NWv == kMaxNW) {  // rows from HBM/L2 only: pairs beyond every LDS class, which exist at four wavefronts only
+        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true, NWv>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((estimate_pose_kernel<0, false, NWv>), grid, block, lds, s, a);
+    }
+}
+static void launch_k1(int nw, int lds_pts, bool guesses, dim3 grid, size_t lds, hipStream_t s, const K1Args& a) {
+    if (nw == 1) launch_k1<1>(lds_pts, guesses, grid, lds, s, a);
+    else if (nw == 2) launch_k1<2>(lds_pts, guesses, grid, lds, s, a);
+    else launch_k1<4>(lds_pts, guesses, grid, lds, s, a);
+}
 
 extern "C" {
 
@@ -1549,10 +1595,11 @@ pgi_ctx* pgi_create(int device, const pgi_params* params) {
     if (cus > 0) c->resident_wgs = 3 * cus;
     c->n_cus = cus > 0 ? cus : 256;
     // K1 may use the whole LDS of a CU for staged rows
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void*)estimate_pose_kernel<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    if (const char* e = getenv("PGI_K1_NW")) c->k1_nw = atoi(e);
     if (const char* e = getenv("PGI_LDS_MIN_WGS")) c->lds_min_wgs = atoi(e);
     if (const char* e = getenv("PGI_HYBRID_ROWS")) c->hybrid_rows = atoi(e);
     if (const char* e = getenv("PGI_CLASS_OVERLAP")) c->class_overlap = atoi(e);
@@ -1686,7 +1733,8 @@ static uint32_t k1_rows_cap(const pgi_ctx* ctx, int wgs_per_cu, size_t fixed_byt
 // `src`: four page-locked host arrays (device-visible addresses) the rows are consumed from in place; b->d_x1..d_y2 are
 // then the device mirror for rows that do not fit in LDS.
 static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks,
-                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr) {
+                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr,
+                           const uint32_t* d_ready = nullptr) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1702,19 +1750,23 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.pair_head = nullptr;
     a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
     a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
+    a.ready = d_ready;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t fixed = k1_fixed_lds(false), fixed_stash = k1_fixed_lds(true);
+    // Wavefronts per pair for this call (see kMaxNW above).  Measured on the dense V = 5000 scene's rows (scripts/k1_dense_bench.py,
+    // K1D_MAXPAIRS): two wavefronts per pair tie with four at 12 000 pairs and win above (-11 % at 24 000, -14 % at 48 000), one wins from about 10^5 pairs on (its
+    // steady rate is 32 % above four's, but a launch winds down for 9 ms: the pairs that run to max_iters are one wavefront's work).
+    int nw = ctx->k1_nw == 1 || ctx->k1_nw == 2 || ctx->k1_nw == 4 ? ctx->k1_nw : b->n_pairs >= kNw1Pairs ? 1 : b->n_pairs >= kNw2Pairs ? 2 : 4;
+    const size_t fixed = k1_fixed_lds(nw, false), fixed_stash = k1_fixed_lds(nw, true);
     const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
     auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) { return k1_rows_cap(ctx, wgs_per_cu, fixed_bytes); };
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
-    // (the experimental 8-wavefront build runs two workgroups per CU where the default runs four: its row caps are those of
-    //  half as many workgroups, and it has no hybrid class -- 2 000 rows fit whole)
-    //  -DPGI_NW=2: eight / six / four / two workgroups per CU -- the same 16 / 12 / 8 / 4 wavefronts per CU as the default's levels)
-    constexpr int kLevelWgs[4] = {std::max(1, 16 / NW), std::max(1, 12 / NW), std::max(1, 8 / NW), std::max(1, 4 / NW)};
-    // (NW < 4: two classes only -- rows whole in LDS at the top occupancy, and everything larger HYBRID at the same occupancy)
+    // Occupancy levels: 16 / 12 / 8 / 4 wavefronts per CU = 4 / 3 / 2 / 1 workgroups of four wavefronts.  Below four wavefronts
+    // per pair there are two classes only -- rows whole in LDS at the top occupancy, and everything larger HYBRID (the first
+    // rows in LDS, the tail from HBM/L2) at the same occupancy.
+    const int kLevelWgs[4] = {16 / nw, std::max(1, 12 / nw), std::max(1, 8 / nw), std::max(1, 4 / nw)};
     const uint32_t cap4 = rows_cap(kLevelWgs[0]);
-    const uint32_t cap3 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[1]), cap2 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[2]),
-                   cap1 = NW < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[3]);
+    const uint32_t cap3 = nw < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[1]), cap2 = nw < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[2]),
+                   cap1 = nw < 4 ? 0x7FFFFFC0u : rows_cap(kLevelWgs[3]);
     bool hybrid = false;
     int class_wgs = kLevelWgs[0];  // workgroups per CU of the class being launched (sizes a persistent grid)
     hipStream_t ls = stream;  // the stream the next launch goes to (a class's side stream when classes overlap)
@@ -1726,18 +1778,11 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + (hybrid ? fixed_stash : fixed);
-        if (hybrid) {  // first cap_rows rows in LDS, the tail from HBM/L2
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<2, true>), grid_of(), dim3(NT), lds, ls, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<2, false>), grid_of(), dim3(NT), lds, ls, a);
-        } else {
-            if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<1, true>), grid_of(), dim3(NT), lds, ls, a);
-            else hipLaunchKernelGGL((estimate_pose_kernel<1, false>), grid_of(), dim3(NT), lds, ls, a);
-        }
+        launch_k1(nw, hybrid ? 2 : 1, guesses, grid_of(), lds, ls, a);  // hybrid: first cap_rows rows in LDS, the tail from HBM/L2
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        if (guesses) hipLaunchKernelGGL((estimate_pose_kernel<0, true>), grid_of(), dim3(NT), fixed_stash, ls, a);
-        else hipLaunchKernelGGL((estimate_pose_kernel<0, false>), grid_of(), dim3(NT), fixed_stash, ls, a);
+        launch_k1(nw, 0, guesses, grid_of(), fixed_stash, ls, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
@@ -1747,7 +1792,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     // PGI_LDS_MIN_WGS overrides the default for experiments.
     const uint32_t lds_cap = ctx->lds_min_wgs >= 4 ? cap4 : ctx->lds_min_wgs == 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
     if (cap <= cap4 || b->n_pairs < 64) {  // every pair already gets the top occupancy (or the batch is tiny): one launch
-        if (NW < 4 && cap > cap4) {  // (a tiny batch of large pairs in the builds that know two classes: the hybrid one)
+        if (nw < 4 && cap > cap4) {  // (a tiny batch of large pairs in the builds that know two classes: the hybrid one)
             hybrid = true;
             launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));
             hybrid = false;
@@ -1801,13 +1846,13 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
 #else
             a.pair_head = ctx->k1_persistent && !guesses ? heads + k : nullptr;  // (the guess variants have no loop)
 #endif
-            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows && NW <= 4 ? kLevelWgs[0] : kLevelWgs[k];
+            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows ? kLevelWgs[0] : kLevelWgs[k];
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
             if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
-            hybrid = k == 1 && ctx->hybrid_rows && NW <= 4;
+            hybrid = k == 1 && ctx->hybrid_rows;
             if (hybrid) launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));  // 1280 rows in LDS next to the sample stash (NW = 4)
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;
@@ -1830,6 +1875,12 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     if (!ctx) return fail(PGI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(ctx->mu);  // the size-bucket scratch belongs to the context
     return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
+}
+
+int pgi_estimate_pose_batch_streamed(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks, const uint32_t* d_ready) {
+    if (!ctx || !d_ready) return fail(PGI_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes, nullptr, d_ready);
 }
 
 // Page-locked inputs AND results: K1 works on the caller's buffers IN PLACE over PCIe.  The kernel reads every row exactly
@@ -1875,7 +1926,7 @@ static int estimate_host_direct(pgi_ctx* ctx, const float* const* src, const uin
     }
     HIP_TRY(hipMemcpyAsync(d, hs, guesses ? o_has + n_pairs : o_thr + (size_t)n_pairs * 8, hipMemcpyHostToDevice, S.stream));
     // the rows of pairs beyond the four-workgroup LDS capacity live partly (or wholly) outside LDS: device mirror
-    const bool need_mirror = ((max_corr + 63u) & ~63u) > k1_rows_cap(ctx, 4, k1_fixed_lds(false));
+    const bool need_mirror = ((max_corr + 63u) & ~63u) > k1_rows_cap(ctx, 4, k1_fixed_lds(4, false));
     const float* mirror[4] = {src[0], src[1], src[2], src[3]};
     if (need_mirror) {
         const size_t one = up((size_t)rows * 4);

@@ -2,8 +2,9 @@
 """K1 alone on the rows of the dense V = 5000 scene (BASELINE configs 4/5 at SURVEY 8d's density: ~106 000 pairs, ~77 M rows,
 median 588 rows per pair), resident in HBM, ONE estimate_pose_batch call per repetition -- the floor of config 4's
 estimation stage.  Several builds of libpgi (paths relative to the package) are timed in one process, interleaved, and
-their result bytes compared:
-    k1_dense_bench.py [libpgi.so libpgi_nw2.so ...]
+their result bytes compared -- or, "nw=1" / "nw=2" / "nw=4" / "nw=0" (the launcher's own rule), the default build with that
+many wavefronts per pair (PGI_K1_NW, read when the context is made):
+    k1_dense_bench.py [libpgi.so nw=1 nw=2 nw=4 nw=0 ...]
 Environment: K1D_SCENE (v5000), K1D_ROUNDS (5), K1D_PARAMS ("round_size=16,lo_iters=2": pgi_params overrides for every build),
 K1D_MAXPAIRS (all): keep only the first so-many pairs (profiling runs)."""
 import os, sys, time
@@ -41,7 +42,12 @@ for kv in filter(None, os.environ.get("K1D_PARAMS", "").split(",")):
 engs = []
 for path in libs:
     L._lib = None
-    L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
+    if path.startswith("nw="):
+        os.environ["PGI_K1_NW"] = path[3:]
+        L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi.so")
+    else:
+        os.environ.pop("PGI_K1_NW", None)
+        L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
     e = Engine()
     if params:
         e.set_params(**params)

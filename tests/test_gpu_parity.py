@@ -735,3 +735,44 @@ def test_config1_single_pair_of_2000_correspondences(eng):
         assert e.used_guess == (0 if g is None else 1)
         assert rot_angle(np.array(e.R), np.array(oe.R)) < R_TOL_RAD and np.array(e.t) @ np.array(oe.t) > 1 - T_COS_TOL
         assert S.rot_err_deg(np.array(e.R).reshape(3, 3), d["R"]) < (0.1 if g is None else 2.0)
+
+
+@pytest.mark.parametrize("nw", [1, 2, 4])
+def test_every_wavefront_count_per_pair_gives_the_oracles_bits(nw, monkeypatch):
+    """K1 is a template over the wavefronts per image pair (round 5: one / two / four; launch_estimate picks by batch size,
+    PGI_K1_NW forces).  A fit's hypotheses, scores and merges are order-free, so every count must give the ORACLE's bits:
+    ragged pairs across the LDS and hybrid classes of each count (320 / 640 / 1344 rows whole in LDS, the rest hybrid or --
+    four wavefronts, huge pairs -- from HBM/L2), tiny and degenerate pairs, then the same rows with pose guesses in both
+    guess modes (the rotation-guided path deals its 32 two-point hypotheses out over the wavefronts)."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_K1_NW", str(nw))
+    e = Engine()
+    try:
+        sizes = ([60, 300, 321, 640, 641, 900, 1344, 1345, 2300, 4, 5, 64] * 6)[:70] + [4100, 9000]
+        rhos = ([0.5, 0.3, 0.7, 0.5, 0.15, 0.6] * 12)[:len(sizes)]
+        ids = np.arange(23000, 23000 + len(sizes))
+        parts = [S.make_pair(int(i), n, inlier_ratio=r) for i, n, r in zip(ids, sizes, rhos)]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        cat = lambda k: np.concatenate([p[k] for p in parts])
+        x1, y1, x2, y2 = cat("x1"), cat("y1"), cat("x2"), cat("y2")
+        db = e.upload(x1, y1, x2, y2, off, 7.5e-4, seed=9, pair_id_base=23000)
+        edges, masks = e.estimate_pose_batch(db)
+        exp, em = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(), 9, pair_id_base=23000)
+        assert np.array_equal(masks.cpu().numpy(), em)
+        assert_edges_match(e.edges_to_numpy(edges), exp)
+        rng = np.random.default_rng(nw)
+        guesses = np.zeros((len(sizes), 12))
+        has = (rng.random(len(sizes)) < 0.8).astype(np.uint8)
+        for i, p in enumerate(parts):
+            Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(0.5 if i % 7 else 40.0)) @ p["R"]
+            guesses[i] = np.r_[Rg.ravel(), p["t"] if i % 3 else rng.standard_normal(3)]
+        dbg = e.upload(x1, y1, x2, y2, off, 7.5e-4, guesses=guesses, has_guess=has, seed=9, pair_id_base=23000)
+        for mode in (0, 1):
+            e.set_params(guess_mode=mode)
+            eg, mg = e.estimate_pose_batch(dbg)
+            expg, emg = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(guess_mode=mode), 9, pair_id_base=23000,
+                                              guesses=guesses, has_guess=has)
+            assert np.array_equal(mg.cpu().numpy(), emg), mode
+            assert_edges_match(e.edges_to_numpy(eg), expg)
+    finally:
+        e.close()
