@@ -41,6 +41,7 @@ typedef enum {
 #define PGI_EDGE_NAN (-1)          /* false (pose_graph_builder.h:1069-1070)             */
 #define PGI_EDGE_FEW_POINTS (-2)   /* fewer than 5 rows                                  */
 #define PGI_EDGE_TOO_MANY_ROWS (-3) /* the pair has more rows than pgi_batch.max_corr promised */
+#define PGI_EDGE_NOT_RESIDENT (-4) /* streamed batch: the pair was never announced through *d_ready (4 s watchdog) */
 
 typedef struct pgi_ctx pgi_ctx;
 

@@ -91,6 +91,7 @@ struct K1Args {
     // thresholds, guesses); the caller's copy stream raises it behind every chunk it uploads WHILE this launch already works on
     // the earlier ones.  nullptr: everything was resident before the launch.
     const uint32_t* ready;
+    uint32_t* ready_dev;  // streamed: [0] the device-side mirror of *ready the waiting workgroups poll, [1] the relay's lock
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -1091,11 +1092,55 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
 // Streamed batches: a workgroup that took pair `pair` waits until the caller's copy stream has announced it.  Thread 0 polls
 // with a SYSTEM-scope acquire load (the writer is the copy engine; the acquire also drops whatever stale lines this CU / XCD
 // holds of the just-written rows -- a cache line can straddle two chunks), the workgroup barrier passes the order on.
-PGI_DEV void wait_until_resident(const uint32_t* ready, uint32_t pair) {
+// A caller that never raises the word (a failed upload, a bug) must not hang the GPU: after 4 s of the constant 100 MHz
+// clock the wait gives up and the pair is reported as PGI_EDGE_NOT_RESIDENT.  Returns false then (workgroup-uniform).
+PGI_DEV bool wait_until_resident(const K1Args& a, uint32_t pair, char* smem) {
+    uint32_t* flag = reinterpret_cast<uint32_t*>(smem);
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <= pair) __builtin_amdgcn_s_sleep(32);
+        // *a.ready lies in the caller's page-locked HOST memory: thousands of waiting workgroups polling it over PCIe starve
+        // the very uploads they wait for (measured: a streamed config 4 took 0.16 s instead of 0.10 s).  So ONE workgroup at
+        // a time -- whoever holds the lock word -- reads the host word and republishes it in device memory; everybody else
+        // polls that mirror on chip.
+        uint32_t ok = 1;
+        uint32_t seen = __hip_atomic_load(a.ready_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen <= pair) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                if (atomicCAS(a.ready_dev + 1, 0u, 1u) == 0u) {  // the relay
+                    for (;;) {
+                        const uint32_t v = __hip_atomic_load(a.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (v > seen) {
+                            seen = v;
+                            __hip_atomic_fetch_max(a.ready_dev, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (seen > pair) break;
+                        __builtin_amdgcn_s_sleep(32);
+                        if (wall_clock64() - t0 > 400000000ull) { ok = 0; break; }
+                    }
+                    __hip_atomic_store(a.ready_dev + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127);
+                seen = __hip_atomic_load(a.ready_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen > pair) break;
+                if (wall_clock64() - t0 > 400000000ull) { ok = 0; break; }
+            }
+        }
+        *flag = ok;
     }
     __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();  // everyone has read the flag: the row area is free again
+    if (!ok) {
+        const uint64_t o = a.off[pair];
+        const uint32_t n = (uint32_t)(a.off[pair + 1] - o);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a.masks[o + i] = 0;
+        if (threadIdx.x == 0) {
+            edge_clear(a.edges + pair);
+            a.edges[pair].status = PGI_EDGE_NOT_RESIDENT;
+        }
+    }
+    return ok;
 }
 
 // The kernel: one pair per workgroup (grid = pairs), or -- a size-bucket launch -- workgroups that take entries of the
@@ -1131,8 +1176,7 @@ __global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args 
                 if (slot >= *a.pair_count) return;
                 pair = a.pair_list[slot];
             }
-            if (a.ready) wait_until_resident(a.ready, pair);
-            estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
+            if (a.ready == nullptr || wait_until_resident(a, pair, smem)) estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
             if (!persistent) return;
             __syncthreads();  // the pair's results are written, its LDS state is dead
         }
@@ -1142,8 +1186,7 @@ __global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args 
             if (blockIdx.x >= *a.pair_count) return;
             pair = a.pair_list[blockIdx.x];
         }
-        if (a.ready) wait_until_resident(a.ready, pair);
-        estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
+        if (a.ready == nullptr || wait_until_resident(a, pair, smem)) estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
     }
 }
 
@@ -1639,6 +1682,7 @@ void pgi_destroy(pgi_ctx* ctx) {
     }
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
+    if (ctx->d_relay) (void)hipFree(ctx->d_relay);
     for (int k = 0; k < 4; ++k) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
@@ -1751,7 +1795,13 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
     a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
     a.ready = d_ready;
+    a.ready_dev = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (d_ready) {  // the on-chip mirror of the caller's ready word and the relay's lock, zeroed in stream order before the kernels
+        if (!ctx->d_relay) HIP_TRY(hipMalloc((void**)&ctx->d_relay, 256));
+        HIP_TRY(hipMemsetAsync(ctx->d_relay, 0, 256, stream));
+        a.ready_dev = ctx->d_relay;
+    }
     // Wavefronts per pair for this call (see kMaxNW above).  Measured on the dense V = 5000 scene's rows (scripts/k1_dense_bench.py,
     // K1D_MAXPAIRS): two wavefronts per pair tie with four at 12 000 pairs and win above (-11 % at 24 000, -14 % at 48 000), one wins from about 10^5 pairs on (its
     // steady rate is 32 % above four's, but a launch winds down for 9 ms: the pairs that run to max_iters are one wavefront's work).
