@@ -755,13 +755,20 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     // descending similarity, ties by (src,dst): the order the reference pops its heap.  An index order is sorted, not the
     // candidate records themselves (10^5 records with their matrices' headers: a stable sort moved each a dozen times).
     const Clock::time_point tSort = Clock::now();
-    std::vector<uint32_t> order(cand.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&cand](uint32_t ia, uint32_t ib) {
-        const ViewPair &a = cand[ia], &b = cand[ib];
+    // (the keys are copied out once and sorted as one flat array: a comparator that reached into the 10^5 candidate records
+    //  through an index cost twice as much; the position in the caller's list is the last key, which makes plain std::sort stable)
+    struct OrderKey { double similarity; ViewId src, dst; uint32_t index; };
+    std::vector<OrderKey> keys(cand.size());
+    for (size_t i = 0; i < keys.size(); ++i) keys[i] = OrderKey{cand[i].similarity, cand[i].src, cand[i].dst, (uint32_t)i};
+    std::sort(keys.begin(), keys.end(), [](const OrderKey& a, const OrderKey& b) {
         if (a.similarity != b.similarity) return a.similarity > b.similarity;
-        return std::make_pair(a.src, a.dst) < std::make_pair(b.src, b.dst);
+        if (a.src != b.src) return a.src < b.src;
+        if (a.dst != b.dst) return a.dst < b.dst;
+        return a.index < b.index;
     });
+    std::vector<uint32_t> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = keys[i].index;
+    std::vector<OrderKey>().swap(keys);
     statistics.addTime("[Scheduler] candidate order", std::chrono::duration<double>(Clock::now() - tSort).count(), 1);
     ViewId maxId = 0;
     for (const ViewPair& vp : cand) maxId = std::max(maxId, std::max(vp.src, vp.dst));
@@ -858,24 +865,40 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     // and measured: the formation left the critical path, 0.008 -> 0.0025 s, but the runs were not faster, 0.155-0.18 s
     // against 0.144-0.16 s on the dense V = 5000 scene; removed.)
     size_t cursor = 0;
+    std::vector<uint32_t> pick;          // candidates of the batch being admitted (positions in `cand`)
+    std::vector<ViewId> pickSrc, pickDst;
+    std::vector<uint8_t> admit;
     auto formWave = [&]() {
-        for (; cursor < cand.size() && wave.size() < waveSize; ++cursor) {
-            if (cursor + 8 < cand.size()) __builtin_prefetch(&cand[order[cursor + 8]]);
-            ViewPair& vp = cand[order[cursor]];
-            if (vp.similarity < kSimilarityThreshold) { cursor = cand.size(); break; }  // heap holds sim >= threshold only
-            if (poseGraph_.hasEdgeBetween(vp.src, vp.dst)) continue;               // :426-431
-            if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
-            poseGraph_.addVertexPair(vp.src, vp.dst);
-            // the wave holds HEADERS over the candidates' matrices (cv::Mat semantics): the rows stay where the caller put them and
-            // are released when the caller releases its list -- a wave that owned them paid for unmapping 2.4 GB of matrices inside
-            // the run (0.09 s of a 0.25 s run at 10^5 pairs)
-            ViewPair header;
-            header.src = vp.src;
-            header.dst = vp.dst;
-            header.similarity = vp.similarity;
-            header.normalizedThreshold = vp.normalizedThreshold;
-            header.correspondences = CorrespondenceMatrix::viewOf(static_cast<const ViewPair&>(vp).correspondences.ptr(), vp.correspondences.rows);
-            wave.push_back(std::move(header));
+        // In batches of what the wave still lacks: the candidates that pass the list's own filters (similarity, row count) are
+        // checked against the graph and get their vertices under ONE lock (PoseGraph::admitPairs); the order of the reference's
+        // tests (:426-431 before :550-551) does not matter, both only skip.
+        while (cursor < cand.size() && wave.size() < waveSize) {
+            pick.clear(); pickSrc.clear(); pickDst.clear();
+            for (; cursor < cand.size() && wave.size() + pick.size() < waveSize; ++cursor) {
+                if (cursor + 8 < cand.size()) __builtin_prefetch(&cand[order[cursor + 8]]);
+                const ViewPair& vp = cand[order[cursor]];
+                if (vp.similarity < kSimilarityThreshold) { cursor = cand.size(); break; }  // heap holds sim >= threshold only
+                if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
+                pick.push_back(order[cursor]);
+                pickSrc.push_back(vp.src);
+                pickDst.push_back(vp.dst);
+            }
+            admit.assign(pick.size(), 0);
+            poseGraph_.admitPairs(pickSrc.data(), pickDst.data(), pick.size(), admit.data());   // :426-431 + addVertex x 2
+            for (size_t k = 0; k < pick.size(); ++k) {
+                if (!admit[k]) continue;
+                const ViewPair& vp = cand[pick[k]];
+                // the wave holds HEADERS over the candidates' matrices (cv::Mat semantics): the rows stay where the caller put them and
+                // are released when the caller releases its list -- a wave that owned them paid for unmapping 2.4 GB of matrices inside
+                // the run (0.09 s of a 0.25 s run at 10^5 pairs)
+                ViewPair header;
+                header.src = vp.src;
+                header.dst = vp.dst;
+                header.similarity = vp.similarity;
+                header.normalizedThreshold = vp.normalizedThreshold;
+                header.correspondences = CorrespondenceMatrix::viewOf(vp.correspondences.ptr(), vp.correspondences.rows);
+                wave.push_back(std::move(header));
+            }
         }
     };
     // room for every candidate's edge up front: committing 10^5 edges wave by wave re-housed the 208-byte records a handful of

@@ -19,7 +19,7 @@ PEAK_F32, PEAK_F64 = 157.3e12, 78.6e12
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
-def read(tag, kernel="estimate_pose_kernel<2, false>"):
+def read(tag, kernel="estimate_pose_kernel<2, false, 4>"):
     vals, avg_us, calls = {}, None, None
     for line in open(os.path.join(OUT, "%s_k1_%s_summary.txt" % (TAG, tag))):
         if kernel not in line:
@@ -56,7 +56,7 @@ def main():
     write_b = c["WRITE_SIZE"] * 1024
     wc = c["SQ_WAVE_CYCLES"]
     out = {
-        "kernel": "pgi::estimate_pose_kernel<2, false> (hybrid rows: 1280 in LDS, 720 from L2)", "pairs": 10000, "corrs": 2000,
+        "kernel": "pgi::estimate_pose_kernel<2, false, 4> (hybrid rows: 1280 in LDS, 720 from L2; four wavefronts per pair at this batch size)", "pairs": 10000, "corrs": 2000,
         "profile_tag": TAG,
         "source": "rocprofv3 --kernel-trace --pmc ... (separate passes, scripts/profile_k1.sh %s); sums / dispatches; "
                   "summaries in profiles/%s_k1_rocprofv3_summary.txt" % (TAG, TAG),

@@ -47,7 +47,7 @@ a.record(); e, m = eng.estimate_pose_batch(db); z.record(); torch.cuda.synchroni
 acc = buf.cpu().numpy().astype(np.float64)
 tot = acc.sum()
 got = eng.edges_to_numpy(e)
-print("P=%d N=%s budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over %d waves)" % (
-    P, N, fb, a.elapsed_time(z), got["iters"].mean(), got["lo_runs"].mean(), 4 * P))
+print("P=%d N=%s budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over all wavefronts; PGI_K1_NW=%s)" % (
+    P, N, fb, a.elapsed_time(z), got["iters"].mean(), got["lo_runs"].mean(), os.environ.get("PGI_K1_NW", "auto")))
 for i in range(25):
-    print("%2d %-28s %14.0f  %6.2f%%  %10.0f ticks/wave" % (i, NAMES.get(i, ""), acc[i], 100 * acc[i] / tot, acc[i] / (4 * P)))
+    print("%2d %-28s %14.0f  %6.2f%%  %10.0f ticks/pair" % (i, NAMES.get(i, ""), acc[i], 100 * acc[i] / tot, acc[i] / P))

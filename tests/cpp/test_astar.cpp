@@ -181,6 +181,14 @@ static int graphops(char** argv) {
             }
             for (size_t i = 0; i < n; ++i) { items[i].R = poses[i].R.data(); items[i].t = poses[i].t.data(); }
             out << g.addEdges(items.data(), n) << "\n";
+        } else if (op == "A") {  // admitPairs: n, then n x (src dst) -> the admit flags and the vertex count afterwards
+            size_t n; in >> n;
+            std::vector<ViewId> s(n), d(n);
+            for (size_t i = 0; i < n; ++i) in >> s[i] >> d[i];
+            std::vector<uint8_t> admit(n, 7);
+            g.admitPairs(s.data(), d.data(), n, admit.data());
+            for (size_t i = 0; i < n; ++i) out << (int)admit[i];
+            out << " " << g.numVertices() << "\n";
         } else if (op == "H") {
             ViewId s, d; in >> s >> d;
             out << (g.hasEdge(s, d) ? 1 : 0) << " " << (g.hasEdgeBetween(s, d) ? 1 : 0) << "\n";

@@ -17,7 +17,8 @@ SCORE = st.integers(1, 999).map(lambda k: k / 1000.0)
 EDGE = st.tuples(IDS, IDS, SCORE)
 OP = st.one_of(st.tuples(st.just("V"), IDS), st.tuples(st.just("P"), IDS, IDS), st.tuples(st.just("E"), EDGE),
                st.tuples(st.just("B"), st.lists(EDGE, min_size=0, max_size=12)), st.tuples(st.just("H"), IDS, IDS),
-               st.tuples(st.just("G"), IDS, IDS), st.tuples(st.just("N"), IDS), st.tuples(st.just("I")))
+               st.tuples(st.just("G"), IDS, IDS), st.tuples(st.just("N"), IDS), st.tuples(st.just("I")),
+               st.tuples(st.just("A"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)))
 
 
 class Model:
@@ -46,6 +47,14 @@ class Model:
             return "1" if self.add_edge(*op[1]) else "0"
         if k == "B":
             return str(sum(1 for e in op[1] if self.add_edge(*e)))
+        if k == "A":   # PoseGraph::admitPairs: not an edge yet in either direction -> admitted, both vertices added
+            flags = []
+            for s, d in op[1]:
+                ok = (s, d) not in self.edges and (d, s) not in self.edges
+                flags.append("1" if ok else "0")
+                if ok:
+                    self.vertices.update((s, d))
+            return "".join(flags) + " %d" % len(self.vertices)
         if k == "H":
             s, d = op[1], op[2]
             return "%d %d" % ((s, d) in self.edges, (s, d) in self.edges or (d, s) in self.edges)
@@ -73,6 +82,9 @@ def script(ops):
         elif op[0] == "B":
             lines.append("B %d" % len(op[1]))
             lines += ["%d %d %r" % e for e in op[1]]
+        elif op[0] == "A":
+            lines.append("A %d" % len(op[1]))
+            lines += ["%d %d" % e for e in op[1]]
         else:
             lines.append(" ".join(str(x) for x in op))
     return "\n".join(lines) + "\n"
