@@ -277,10 +277,20 @@ class HostPool {
 // chunk c - 1 run; ring, device block, streams and events are grow-only and shared by every builder of the process.
 struct PoseGraphBuilder::Staging {
     static constexpr int kRing = 3;
-    void* dev = nullptr;
-    size_t dev_bytes = 0;
-    void* small = nullptr;  // page-locked per-pair arrays (offsets, thresholds, guesses, screening models)
-    size_t small_bytes = 0;
+    // TWO device blocks and two page-locked mirrors of the per-pair arrays (round 5): while the kernels of one wave work on
+    // block `active`, the rows of the scheduler's NEXT wave are converted and uploaded into the other one (prefetch below)
+    void* devBlk[2] = {nullptr, nullptr};
+    size_t devBytes[2] = {0, 0};
+    void* smallBlk[2] = {nullptr, nullptr};  // page-locked per-pair arrays (offsets, thresholds, guesses, screening models)
+    size_t smallBytes[2] = {0, 0};
+    int active = 0;
+    struct Prefetched {   // the rows of `pairs[0..P)` -- this rank's block of them -- lie in block `which`; preDone marks their arrival
+        const void* first = nullptr;
+        size_t P = 0, rows = 0;
+        int which = 0;
+        bool valid = false;
+    } pre;
+    hipEvent_t preDone = nullptr;
     void* ring[kRing] = {nullptr, nullptr, nullptr};
     size_t ring_bytes = 0;  // each
     hipStream_t copy = nullptr;
@@ -314,8 +324,9 @@ struct PoseGraphBuilder::Staging {
     }
     ~Staging() {
         if (featArena) (void)hipFree(featArena);
-        if (dev) (void)hipFree(dev);
-        if (small) (void)hipHostFree(small);
+        for (void* d : devBlk) if (d) (void)hipFree(d);
+        for (void* h : smallBlk) if (h) (void)hipHostFree(h);
+        if (preDone) (void)hipEventDestroy(preDone);
         for (void* r : ring) if (r) (void)hipHostFree(r);
         for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
         if (smallUp) (void)hipEventDestroy(smallUp);
@@ -331,6 +342,7 @@ struct PoseGraphBuilder::Staging {
         for (hipEvent_t& e : up)
             if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
         if (!smallUp && hipEventCreateWithFlags(&smallUp, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
+        if (!preDone && hipEventCreateWithFlags(&preDone, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
         if (!readyWord && hipHostMalloc((void**)&readyWord, 256, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
         if (!pool || pool->size() < std::min<size_t>(threads, std::max(1u, std::thread::hardware_concurrency()))) pool.reset(new HostPool(threads));
     }
@@ -345,18 +357,18 @@ struct PoseGraphBuilder::Staging {
         const Release* r = static_cast<const Release*>(p);  // (never lowers the word: an aborted call has raised it to the top)
         if (r->value > __atomic_load_n(r->word, __ATOMIC_RELAXED)) __atomic_store_n(r->word, r->value, __ATOMIC_RELEASE);
     }
-    void reserve(size_t smallBytes, size_t ringBytes, size_t devBytes) {
-        growHost(small, small_bytes, smallBytes);
+    void reserve(int which, size_t smallWant, size_t ringBytes, size_t devWant) {
+        growHost(smallBlk[which], smallBytes[which], smallWant);
         if (ringBytes > ring_bytes) {
             size_t have = 0;
             for (void*& r : ring) { have = ring_bytes; growHost(r, have, ringBytes); }
             ring_bytes = have;
         }
-        if (devBytes > dev_bytes) {
-            if (dev) (void)hipFree(dev);
-            dev = nullptr; dev_bytes = 0;
-            if (hipMalloc(&dev, devBytes + devBytes / 4) != hipSuccess) throw PgiError("hipMalloc failed");
-            dev_bytes = devBytes + devBytes / 4;
+        if (devWant > devBytes[which]) {
+            if (devBlk[which]) (void)hipFree(devBlk[which]);
+            devBlk[which] = nullptr; devBytes[which] = 0;
+            if (hipMalloc(&devBlk[which], devWant + devWant / 4) != hipSuccess) throw PgiError("hipMalloc failed");
+            devBytes[which] = devWant + devWant / 4;
         }
     }
     // Process-wide and never released: page-locking a few hundred MB costs tens of milliseconds, and a process that builds
@@ -383,7 +395,8 @@ struct PoseGraphBuilder::Staging {
 size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseGraph& poseGraph_, uint64_t seed,
                                        std::vector<pgi_edge>* edges_out, bool screenGuesses, pgi_edge* d_edges_out,
                                        const std::function<void(size_t, size_t)>* prepareGuesses,
-                                       std::function<size_t()>* deferredInsertion) {
+                                       std::function<size_t()>* deferredInsertion,
+                                       const std::function<const std::vector<ViewPair>*()>* nextWave, bool rowsOnly) {
     const size_t P = pairs.size();
     if (deferredInsertion) *deferredInsertion = nullptr;
     if (!P) return 0;
@@ -392,6 +405,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     Clock::time_point tp = t0;
     const bool timing = std::getenv("PGI_HOST_TIMING") != nullptr;  // stderr: wall clock per phase of this function
     auto mark = [&](const char* what) {  // phase clocks: RunningStatistics "[Pose estimation] <phase>" (+ stderr on request)
+        if (rowsOnly) return;  // (a prefetch runs on a helper thread: the statistics belong to the calling one)
         const Clock::time_point now = Clock::now();
         const double sec = std::chrono::duration<double>(now - tp).count();
         statistics.addTime(std::string("[Pose estimation] ") + what, sec, 1);
@@ -441,22 +455,35 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
                  o_cnt = o_small_end, o_masks = o_cnt + up(L * 4), o_all = o_masks + up(rows),
                  dev_total = o_all + (d_edges_out ? 0 : up(P * sizeof(pgi_edge)));  // the gathered table, unless the caller brings one
     if (!staging) staging = Staging::shared(engineDevice(engine->get()));
-    std::lock_guard<std::mutex> stagingBusy(staging->busy);
+    // (rowsOnly: the PREFETCH of the scheduler's next wave, called from inside the running wave's call, which holds the lock)
+    std::unique_lock<std::mutex> stagingBusy(staging->busy, std::defer_lock);
+    if (!rowsOnly) stagingBusy.lock();
     HIP_OK(hipSetDevice(engineDevice(engine->get())));  // this thread's allocations, stream and events belong to the engine's device
     staging->init(kCoreNumber ? kCoreNumber : 1);
-    staging->reserve(o_small_end - o_off, maxChunkRows * 16, dev_total);
-    char* const hs = (char*)staging->small - o_off;  // so that hs + o_* addresses the page-locked mirror
-    char* const db = (char*)staging->dev;
+    // Which of the two blocks: a prefetch fills the one the running wave does not use; a wave whose rows were prefetched
+    // works where they lie; every other call on the active one.
+    const bool prefetched = !rowsOnly && staging->pre.valid && staging->pre.first == (const void*)pairs.data() && staging->pre.P == P &&
+                            staging->pre.rows == rows;
+    if (!rowsOnly) {
+        if (prefetched) staging->active = staging->pre.which;
+        staging->pre.valid = false;  // consumed, or stale: either way nobody else may take it
+    }
+    const int which = rowsOnly ? 1 - staging->active : staging->active;
+    staging->reserve(which, o_small_end - o_off, maxChunkRows * 16, dev_total);
+    char* const hs = (char*)staging->smallBlk[which] - o_off;  // so that hs + o_* addresses the page-locked mirror
+    char* const db = (char*)staging->devBlk[which];
     double *thr = (double*)(hs + o_thr), *guess = (double*)(hs + o_guess), *Eg = (double*)(hs + o_Eg), *tau2 = (double*)(hs + o_tau);
     uint8_t* has = (uint8_t*)(hs + o_has);
-    memcpy(hs + o_off, off.data(), (L + 1) * 8);
-    for (size_t k = 0; k < L; ++k) thr[k] = pairs[lo + k].normalizedThreshold;  // every pair, also those without rows
+    if (!prefetched) {
+        memcpy(hs + o_off, off.data(), (L + 1) * 8);
+        for (size_t k = 0; k < L; ++k) thr[k] = pairs[lo + k].normalizedThreshold;  // every pair, also those without rows
+    }
     // Pose guesses: known up front (the caller filled poseGuesses), or produced per launch group by `prepareGuesses` -- the
     // scheduler's A* searches for the pairs [first, last) of `pairs` -- right before the group's rows are converted, so
     // that the host searches for group g + 1 while the device estimates group g.  Either way the guess arrays of a group
     // are filled and uploaded with the group.
     bool may_guess = prepareGuesses != nullptr;
-    for (size_t k = 0; k < L && !may_guess; ++k) may_guess = !pairs[lo + k].poseGuesses.empty();
+    for (size_t k = 0; k < L && !may_guess && !rowsOnly; ++k) may_guess = !pairs[lo + k].poseGuesses.empty();
     const bool screen = may_guess && screenGuesses;
     std::vector<uint8_t> screened(screen ? L : 0, 0);  // this block's pairs that carried a chained pose into the screening launch
     std::vector<uint32_t> guessInliers;                // their inlier counts under the SQUARED bound (1.5 thr)^2
@@ -490,9 +517,15 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     double convertSeconds = 0, searchSeconds = 0;
     if (L) {
         hipStream_t copy = staging->copy;
-        HIP_OK(hipMemcpyAsync(db + o_off, hs + o_off, o_guess - o_off, hipMemcpyHostToDevice, copy));  // offsets, thresholds
-        HIP_OK(hipEventRecord(staging->smallUp, copy));
-        HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->smallUp, 0));  // the stream the engine enqueues on
+        if (prefetched) {  // offsets, thresholds and every row are in the block already: the engine's stream waits for their arrival
+            HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->preDone, 0));
+        } else {
+            HIP_OK(hipMemcpyAsync(db + o_off, hs + o_off, o_guess - o_off, hipMemcpyHostToDevice, copy));  // offsets, thresholds
+            if (!rowsOnly) {
+                HIP_OK(hipEventRecord(staging->smallUp, copy));
+                HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->smallUp, 0));  // the stream the engine enqueues on
+            }
+        }
         float* const dcol[4] = {(float*)(db + o_x1), (float*)(db + o_y1), (float*)(db + o_x2), (float*)(db + o_y2)};
         size_t groupK0 = 0, groupChunks = 0, groupTarget = 1;
         uint32_t groupMaxCorr = 0;
@@ -507,7 +540,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         // (GPU_MAX_HW_QUEUES), so a marker of the copy stream can sit behind a waiting kernel.  Off by default for that reason.
         // Not with the reference's guess screening: its scoring launches would have to run beside the resident kernels.
         static const bool streamedOn = [] { const char* e = std::getenv("PGI_K1_STREAMED"); return e && e[0] == '1'; }();
-        const bool streamed = streamedOn && !screen && chunks.size() > 1;
+        const bool streamed = streamedOn && !screen && chunks.size() > 1 && !prefetched && !rowsOnly;
         if (streamed) {
             uint32_t blockMaxCorr = 0;
             for (const Chunk& ch : chunks) blockMaxCorr = std::max(blockMaxCorr, ch.maxCorr);
@@ -531,7 +564,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         } releaseAll{streamed ? staging->readyWord : nullptr};
         for (size_t c = 0; c < chunks.size(); ++c) {
             const Chunk& ch = chunks[c];
-            if (groupChunks == 0 && may_guess) {  // a new launch group starts here: its guesses first (A* on the host team)
+            if (groupChunks == 0 && may_guess && !rowsOnly) {  // a new launch group starts here: its guesses first (A* on the host team)
                 const size_t last = std::min(chunks.size(), c + groupTarget) - 1;
                 const size_t g0 = ch.k0, g1 = chunks[last].k1;
                 const Clock::time_point ts = Clock::now();
@@ -541,10 +574,10 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             }
             const int slot = (int)(c % Staging::kRing);
             const size_t r0 = off[ch.k0], cr = off[ch.k1] - r0;
-            if (c >= (size_t)Staging::kRing) HIP_OK(hipEventSynchronize(staging->up[slot]));  // its previous upload has left the buffer
+            if (!prefetched) HIP_OK(hipEventSynchronize(staging->up[slot]));  // its previous upload (of this call or an earlier one) has left the buffer
             float* const hb = (float*)staging->ring[slot];
             const Clock::time_point tc = Clock::now();
-            if (cr) {
+            if (cr && !prefetched) {
                 // the team converts contiguous row ranges of the chunk; a range starts inside the pair holding its first row
                 const size_t parts = std::min<size_t>(staging->pool->size(), cr / 16384 + 1);
                 staging->pool->run(parts, [&](size_t t) {
@@ -564,8 +597,9 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
                     HIP_OK(hipMemcpyAsync(dcol[a] + r0, hb + (size_t)a * cr, cr * 4, hipMemcpyHostToDevice, copy));
             }
             convertSeconds += std::chrono::duration<double>(Clock::now() - tc).count();
-            HIP_OK(hipEventRecord(staging->up[slot], copy));
-            HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->up[slot], 0));
+            if (!prefetched) HIP_OK(hipEventRecord(staging->up[slot], copy));
+            if (rowsOnly) continue;  // a prefetch uploads and nothing else
+            if (!prefetched) HIP_OK(hipStreamWaitEvent(engineStream(engine->get()), staging->up[slot], 0));
             // Kernels are launched per GROUP of uploaded chunks -- 1, 2, then 4 chunks: a launch pays a fixed wind-down while its
             // last workgroups finish (0.9 ms, DESIGN.md section 7 "The drain"), so the first launch comes early and the later
             // ones are large.
@@ -611,6 +645,16 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             groupTarget = std::min<size_t>(groupTarget * 2, 4);
         }
         releaseAll.word = nullptr;  // every release is queued: the last one announces the whole block
+        if (rowsOnly) {  // the descriptor the next wave's own call recognises its rows by
+            HIP_OK(hipEventRecord(staging->preDone, copy));
+            staging->pre.first = (const void*)pairs.data();
+            staging->pre.P = P;
+            staging->pre.rows = rows;
+            staging->pre.which = which;
+            staging->pre.valid = true;
+            if (rowsOnlyConvertSeconds) *rowsOnlyConvertSeconds = convertSeconds;  // (RunningStatistics belongs to the calling thread)
+            return 0;
+        }
         mark("convert + upload + launch (chunks)");
         statistics.addTime("[Pose estimation] of which row conversion (host team)", convertSeconds, 1);
         if (prepareGuesses) statistics.addTime("[Pose estimation] of which path searches (host team)", searchSeconds, 1);
@@ -618,6 +662,33 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     // the path's one exchange step (no-op copy in a single process)
     std::vector<uint32_t> counts(world);
     for (uint32_t r = 0; r < world; ++r) counts[r] = (uint32_t)(blocks[r].second - blocks[r].first);
+    // The scheduler's NEXT wave (round 5): formed now and its rows converted and uploaded into the other block WHILE this wave's
+    // kernels run -- the host used to sit in the wait below and then spent 6-7 ms per wave on exactly that before the first
+    // launch of the next wave.  What needs this wave's commit -- the A* guesses -- is still computed after it.
+    // The upload runs on a helper thread (it drives the host team, which nothing else needs until the next wave's A*) while THIS
+    // thread waits for the kernels, gathers, downloads and inserts -- joined before this call returns (it works on the staging
+    // this call has locked).
+    std::thread prefetcher;
+    std::exception_ptr prefetchError;
+    double prefetchConvertSeconds = 0;
+    struct JoinPrefetcher {
+        std::thread& t;
+        ~JoinPrefetcher() { if (t.joinable()) t.join(); }
+    } joinPrefetcher{prefetcher};
+    if (nextWave && !rowsOnly && L) {
+        if (const std::vector<ViewPair>* nw = (*nextWave)()) {
+            if (!nw->empty())
+                prefetcher = std::thread([this, nw, &poseGraph_, &prefetchError, &prefetchConvertSeconds]() {
+                    try {
+                        rowsOnlyConvertSeconds = &prefetchConvertSeconds;
+                        estimatePoses(*nw, poseGraph_, 0, nullptr, false, nullptr, nullptr, nullptr, nullptr, /*rowsOnly*/ true);
+                    } catch (...) {
+                        prefetchError = std::current_exception();
+                    }
+                });
+        }
+        mark("next wave: formation (its rows upload behind this wave's kernels, download and insertion)");
+    }
     Engine::check(pgi_synchronize(engine->get()));
     mark("wait for the kernels");
     Engine::check(pgi_allgather_edges(engine->get(), d_all + lo, counts.data(), d_all));
@@ -652,6 +723,15 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         added = insertAll(edges);
     }
     mark("pose graph insertion");
+    if (prefetcher.joinable()) {
+        prefetcher.join();
+        statistics.addTime("[Pose estimation] of which row conversion of the NEXT wave (host team, on the helper thread)", prefetchConvertSeconds, 1);
+        mark("next wave: rest of its row upload (exposed)");
+        if (prefetchError) {
+            staging->pre.valid = false;
+            std::rethrow_exception(prefetchError);
+        }
+    }
     // Guard for the reference-faithful guess path (guess_quirk = 1, graph_traversal.h:149,164): a chained pose passes the
     // 5-inlier tester, then getInliers compares SQUARED residuals with the UN-squared bound and almost any pose collects
     // kMinimumInlierNumber rows.  Count the accepted guesses that would have failed under the squared bound: those edges
@@ -776,8 +856,11 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     for (const EdgeId& id : poseGraph_.getEdgeIds()) visibilityTable.addLink(id.first, id.second);
     const bool pathFinding = kUsePathFinding && similarityTable != nullptr;
     const uint32_t world = worldSize(), rank = worldRank();
-    std::vector<ViewPair> wave;
+    std::vector<ViewPair> wave, nextWave;
     uint64_t seed = seedBase;
+    // called by estimatePoses while the wave's kernels run: forms the NEXT wave (speculatively, see the loop below) so that its
+    // rows can be uploaded meanwhile; assigned once formWave exists
+    std::function<const std::vector<ViewPair>*()> formNextWhileEstimating = []() -> const std::vector<ViewPair>* { return nullptr; };
     auto flush = [&]() {
         if (wave.empty()) return;
         // findPath (:785-862) on the graph committed by the previous waves.  The searches of a wave are independent (the graph
@@ -823,7 +906,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         }
         std::vector<pgi_edge> edges;
         const size_t added = estimatePoses(wave, poseGraph_, seed++, &edges, /*screenGuesses*/ pathFinding && !rotationGuidedGuesses, nullptr,
-                                           pathFinding ? &searchRange : nullptr);
+                                           pathFinding ? &searchRange : nullptr, nullptr, &formNextWhileEstimating);
         if (pathFinding) {
             struct Tally { uint64_t searched = 0, touched = 0, found = 0; } tally;
             for (size_t i = 0; i < wave.size(); ++i) {  // per-pair tallies summed in pair order
@@ -868,7 +951,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     std::vector<uint32_t> pick;          // candidates of the batch being admitted (positions in `cand`)
     std::vector<ViewId> pickSrc, pickDst;
     std::vector<uint8_t> admit;
-    auto formWave = [&]() {
+    auto formWave = [&](std::vector<ViewPair>& wave) {
         // In batches of what the wave still lacks: the candidates that pass the list's own filters (similarity, row count) are
         // checked against the graph and get their vertices under ONE lock (PoseGraph::admitPairs); the order of the reference's
         // tests (:426-431 before :550-551) does not matter, both only skip.
@@ -905,9 +988,45 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
     // times (a third of the insertion's cost)
     poseGraph_.reserveEdges(cand.size());
     double formSeconds = 0, flushSeconds = 0;
+    // The NEXT wave is formed while this wave's kernels run, i.e. BEFORE this wave's edges are in the graph.  Formation asks the
+    // graph one thing -- "is this candidate an edge already, in either direction?" -- so the early answer is wrong only for a
+    // candidate that the list names twice with the first instance in the running wave.  That is checked after the commit
+    // (PoseGraph::anyEdgeBetween over the speculative wave): if it ever happens the speculative wave and its uploaded rows are
+    // dropped and the wave is formed again the sequential way, so the result is the sequential one in every case.  (Vertices
+    // added by the early formation are those the later formation adds: an excluded candidate's vertices exist -- it is an edge.)
+    size_t cursorBeforeNext = 0;
+    bool speculated = false;
+    static const bool prefetchOn = [] { const char* e = std::getenv("PGI_WAVE_PREFETCH"); return !e || e[0] != '0'; }();
+    formNextWhileEstimating = [&]() -> const std::vector<ViewPair>* {
+        if (!prefetchOn) return nullptr;
+        const Clock::time_point tf = Clock::now();
+        cursorBeforeNext = cursor;
+        nextWave.clear();
+        formWave(nextWave);
+        speculated = true;
+        formSeconds += std::chrono::duration<double>(Clock::now() - tf).count();
+        return &nextWave;
+    };
+    std::vector<ViewId> chkSrc, chkDst;
     for (;;) {
         const Clock::time_point tf = Clock::now();
-        formWave();
+        if (speculated) {
+            speculated = false;
+            chkSrc.resize(nextWave.size());
+            chkDst.resize(nextWave.size());
+            for (size_t i = 0; i < nextWave.size(); ++i) { chkSrc[i] = nextWave[i].src; chkDst[i] = nextWave[i].dst; }
+            if (poseGraph_.anyEdgeBetween(chkSrc.data(), chkDst.data(), chkSrc.size())) {
+                cursor = cursorBeforeNext;  // a candidate listed twice: redo the formation against the committed graph
+                nextWave.clear();
+                if (staging) staging->pre.valid = false;
+                formWave(wave);
+            } else {
+                wave.swap(nextWave);    // (the vector's buffer travels: the prefetch is recognised by it)
+                nextWave.clear();
+            }
+        } else {
+            formWave(wave);
+        }
         const Clock::time_point tw = Clock::now();
         formSeconds += std::chrono::duration<double>(tw - tf).count();
         if (wave.empty()) break;
@@ -1048,7 +1167,7 @@ PoseGraphBuilder::FeatureRunStatistics PoseGraphBuilder::processFeatures(const s
             largestRun = std::max(largestRun, endOf(v1 - 1) - begin);
             v = v1;
         }
-        staging->reserve(0, largestRun, 0);
+        staging->reserve(staging->active, 0, largestRun, 0);
         hipStream_t copy = staging->copy;
         // (where the host's time goes: printed with PGI_PIPELINE_TIMING, and whenever the stage is far slower than PCIe allows)
         auto nowS = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -232,6 +232,13 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
             }
         }
     }
+    // is ANY of the n pairs an edge, in either direction? (one lock; the scheduler's check of a speculatively formed wave)
+    bool anyEdgeBetween(const ViewId* s, const ViewId* d, size_t n) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        for (size_t i = 0; i < n; ++i)
+            if (edge_index.count({s[i], d[i]}) != 0 || edge_index.count({d[i], s[i]}) != 0) return true;
+        return false;
+    }
     // both endpoints of a candidate pair (pose_graph.h addVertex twice), one lock
     void addVertexPair(ViewId a, ViewId b) {
         std::unique_lock<std::shared_mutex> l(mu);
@@ -637,7 +644,11 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
                          std::vector<pgi_edge>* edges_out = nullptr, bool screenGuesses = false,
                          pgi_edge* d_edges_out = nullptr,
                          const std::function<void(size_t, size_t)>* prepareGuesses = nullptr,
-                         std::function<size_t()>* deferredInsertion = nullptr);
+                         std::function<size_t()>* deferredInsertion = nullptr,
+                         const std::function<const std::vector<ViewPair>*()>* nextWave = nullptr, bool rowsOnly = false);
+    // nextWave (optional; the scheduler's): called once while this call's kernels run; returns the pairs of the NEXT call (or
+    // nullptr) -- their rows are converted and uploaded into the second staging block meanwhile, and the call that later brings
+    // exactly that vector finds them resident.  rowsOnly: that prefetch itself (internal).
 
     // BASELINE config 4: shard -> estimate -> gather -> replicated L1/IRLS rotation averaging; the gathered records
     // stay in HBM between the exchange and the solve.  R_i are world->camera, one per view id < numViews.
@@ -768,6 +779,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     // (defined in the implementation file: HIP stays out of this header)
     struct Staging;
     std::shared_ptr<Staging> staging;
+    double* rowsOnlyConvertSeconds = nullptr;  // where a prefetch (helper thread) leaves its conversion time for the calling thread
     uint64_t lastQuirkOnlyGuesses = 0;  // of the last estimatePoses call (all ranks)
 };
 

@@ -189,6 +189,11 @@ static int graphops(char** argv) {
             g.admitPairs(s.data(), d.data(), n, admit.data());
             for (size_t i = 0; i < n; ++i) out << (int)admit[i];
             out << " " << g.numVertices() << "\n";
+        } else if (op == "Y") {  // anyEdgeBetween: n, then n x (src dst)
+            size_t n; in >> n;
+            std::vector<ViewId> s(n), d(n);
+            for (size_t i = 0; i < n; ++i) in >> s[i] >> d[i];
+            out << (g.anyEdgeBetween(s.data(), d.data(), n) ? 1 : 0) << "\n";
         } else if (op == "H") {
             ViewId s, d; in >> s >> d;
             out << (g.hasEdge(s, d) ? 1 : 0) << " " << (g.hasEdgeBetween(s, d) ? 1 : 0) << "\n";

@@ -56,11 +56,11 @@ def pair_similarity(g):
     return np.round(0.3 + 0.6 * ratio + 0.05 * ((i * 7 + j) % 3), 3)
 
 
-def write_scene(path, g, wave, sim_kind):
+def write_scene(path, g, wave, sim_kind, sim=None):
     """u32 V, P, wave, simKind | [V x V f64 similarity if simKind == 1] | per pair: u32 src, dst, n; f64 thr, similarity;
     n x 4 f64 rows (cv::Mat N x 4 CV_64F, the reference's correspondence matrix)."""
     b, V = g["batch"], len(g["R_gt"])
-    sim = pair_similarity(g)
+    sim = pair_similarity(g) if sim is None else np.asarray(sim, np.float64)   # (sim: a caller's own per-pair values)
     with open(path, "wb") as f:
         f.write(struct.pack("<IIII", V, len(g["pairs"]), wave, sim_kind))
         if sim_kind == 1:

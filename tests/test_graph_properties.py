@@ -18,7 +18,8 @@ EDGE = st.tuples(IDS, IDS, SCORE)
 OP = st.one_of(st.tuples(st.just("V"), IDS), st.tuples(st.just("P"), IDS, IDS), st.tuples(st.just("E"), EDGE),
                st.tuples(st.just("B"), st.lists(EDGE, min_size=0, max_size=12)), st.tuples(st.just("H"), IDS, IDS),
                st.tuples(st.just("G"), IDS, IDS), st.tuples(st.just("N"), IDS), st.tuples(st.just("I")),
-               st.tuples(st.just("A"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)))
+               st.tuples(st.just("A"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)),
+               st.tuples(st.just("Y"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)))
 
 
 class Model:
@@ -55,6 +56,8 @@ class Model:
                 if ok:
                     self.vertices.update((s, d))
             return "".join(flags) + " %d" % len(self.vertices)
+        if k == "Y":   # PoseGraph::anyEdgeBetween
+            return "1" if any((s, d) in self.edges or (d, s) in self.edges for s, d in op[1]) else "0"
         if k == "H":
             s, d = op[1], op[2]
             return "%d %d" % ((s, d) in self.edges, (s, d) in self.edges or (d, s) in self.edges)
@@ -82,8 +85,8 @@ def script(ops):
         elif op[0] == "B":
             lines.append("B %d" % len(op[1]))
             lines += ["%d %d %r" % e for e in op[1]]
-        elif op[0] == "A":
-            lines.append("A %d" % len(op[1]))
+        elif op[0] in ("A", "Y"):
+            lines.append("%s %d" % (op[0], len(op[1])))
             lines += ["%d %d" % e for e in op[1]]
         else:
             lines.append(" ".join(str(x) for x in op))

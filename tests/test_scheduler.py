@@ -105,3 +105,42 @@ def test_wave_scheduler_equals_the_cpu_restatement(tmp_path, mode):
     for got, (s_, d_, score, R, t) in zip(edges, ref):
         assert (int(got["src"]), int(got["dst"])) == (s_, d_) and got["score"] == score
         assert np.abs(got["R"].reshape(3, 3) - R).max() < 1e-9 and np.abs(got["t"] - t).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["waves", "waves_guided"])
+def test_next_wave_prefetch_equals_the_sequential_scheduler(tmp_path, mode):
+    """Round 5: while a wave's kernels run, the scheduler forms the NEXT wave and uploads its rows into a second staging block
+    (PoseGraphBuilder::run / estimatePoses `nextWave`).  The early formation sees the graph BEFORE the running wave's commit,
+    which is wrong exactly for a candidate the list names twice (or once per direction) with the first instance in the
+    running wave; the run detects that after the commit and forms the wave again.  Both cases against PGI_WAVE_PREFETCH=0,
+    byte for byte: a plain scene (every wave prefetched) and the same scene with 24 candidates listed a second time --
+    half of them reversed -- at similarities that put them one or two waves later."""
+    import scene_drivers as SC
+    V, wave = 80, 48
+    g = S.make_scene_graph(V, k=8, seed=9, outlier_pair_frac=0.03)
+    sim = SC.pair_similarity(g)
+    b = g["batch"]
+    off = b["offsets"].astype(np.int64)
+    order = np.argsort(-sim, kind="stable")
+    dup = order[np.arange(0, 24) * 3]                       # candidates of the first two waves
+    pairs2 = g["pairs"][dup].copy()
+    pairs2[::2] = pairs2[::2, ::-1]                         # every other one in the other direction
+    rows = np.concatenate([np.arange(off[e], off[e + 1]) for e in dup])
+    g2 = dict(g, pairs=np.concatenate([g["pairs"], pairs2]))
+    g2["batch"] = {k: np.concatenate([b[k], b[k][rows]]) for k in ("x1", "y1", "x2", "y2", "inlier")}
+    g2["batch"]["offsets"] = np.concatenate([off, off[-1] + np.cumsum(np.diff(off)[dup])]).astype(np.uint64)
+    sim2 = np.concatenate([sim, np.round(sim[dup] - 0.004 * (1 + np.arange(24) % 3) - 0.1, 3)])
+    for name, scene, sims in (("plain", g, None), ("twice", g2, sim2)):
+        path = str(tmp_path / (name + ".bin"))
+        SC.write_scene(path, scene, wave, sim_kind=2, sim=sims)
+        SC.run_ranks([SC.EXE, path, str(tmp_path / (name + "_on")), mode], 1, extra_env={"PGI_QUIET": "1"})
+        SC.run_ranks([SC.EXE, path, str(tmp_path / (name + "_off")), mode], 1, extra_env={"PGI_QUIET": "1", "PGI_WAVE_PREFETCH": "0"})
+        on, offb = open(str(tmp_path / (name + "_on")) + ".0", "rb").read(), open(str(tmp_path / (name + "_off")) + ".0", "rb").read()
+        assert on == offb, name
+        stats, edges = SC.read_waves(on)
+        assert stats["waves"] >= 4 and stats["paths_found"] > 0
+        if name == "twice":   # the second listing of a pair that became an edge is skipped (pose_graph_builder.h:426-431)
+            assert stats["pairs_processed"] < len(g2["pairs"]) and stats["pairs_processed"] >= len(g["pairs"]) - 2
+            keys = {(int(e["src"]), int(e["dst"])) for e in edges}
+            assert not any((int(d), int(s_)) in keys and (int(s_), int(d)) in keys for s_, d in g["pairs"][dup])
