@@ -18,4 +18,5 @@ PY
 PGI_DRIVER_REPS=2 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_config3_trace -o $T -- pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out $M > gpurun_out/${T}_config3_trace.log 2>&1
 python3 scripts/rocpd_summary.py $(find gpurun_out/${T}_config3_trace -name "*.db" | head -1) > gpurun_out/${T}_config3_trace_summary.txt 2>&1
 head -40 gpurun_out/${T}_config3_trace_summary.txt | cut -c1-150; cat gpurun_out/${T}_config3_trace.log | tail -5
+rm -rf gpurun_out/${T}_config3_trace
 rm -f /tmp/config3_features.bin /tmp/config3_features.out

@@ -20,5 +20,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${T}_k1_fetch -o $T -- p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${T}_k1_write -o $T -- python3 $ARGS > gpurun_out/${T}_k1_write.log 2>&1
 for d in trace flops mix wait lds fetch write; do
   python3 scripts/rocpd_summary.py $(find gpurun_out/${T}_k1_$d -name "*.db" | head -1) > gpurun_out/${T}_k1_${d}_summary.txt 2>&1
+  rm -rf gpurun_out/${T}_k1_$d   # (tens of MB each; gpurun brings back at most 64 MiB)
 done
 cat gpurun_out/${T}_k1_*_summary.txt | grep -v "^==" | grep -i "estimate_pose\|bucket\|kernel " | cut -c1-200

@@ -13,5 +13,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${T}_k2_fetch -o $T -- p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${T}_k2_write -o $T -- python3 scripts/k2_bench.py > gpurun_out/${T}_k2_write.log 2>&1
 for d in trace fetch write; do
   python3 scripts/rocpd_summary.py $(find gpurun_out/${T}_k2_$d -name "*.db" | head -1) > gpurun_out/${T}_k2_${d}_summary.txt 2>&1
+  rm -rf gpurun_out/${T}_k2_$d   # (tens of MB each; gpurun brings back at most 64 MiB)
 done
 cat gpurun_out/${T}_k2_bench.log; cat gpurun_out/${T}_k2_*_summary.txt | grep -v "^==" | grep -i "score_pose\|kernel " | cut -c1-200
