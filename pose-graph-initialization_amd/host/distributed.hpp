@@ -174,7 +174,16 @@ inline HostComm::HostComm(const LaunchEnv& env_, int portOffset, double timeoutS
         int fd = -1;
         for (;;) {  // rank 0 may not be listening yet
             fd = ::socket(AF_INET, SOCK_STREAM, 0);
-            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+                // A connect() to a local port nobody listens on yet can succeed against ITSELF when the kernel hands out that
+                // very port as the source (TCP simultaneous open; the port then is taken and rank 0 cannot listen on it --
+                // seen once in the suite with eight ranks retrying): such a socket is dropped and the attempt repeated.
+                sockaddr_in me{}, peer{};
+                socklen_t lm = sizeof me, lp = sizeof peer;
+                const bool self = ::getsockname(fd, (sockaddr*)&me, &lm) == 0 && ::getpeername(fd, (sockaddr*)&peer, &lp) == 0 &&
+                                  me.sin_port == peer.sin_port && me.sin_addr.s_addr == peer.sin_addr.s_addr;
+                if (!self) break;
+            }
             if (fd >= 0) ::close(fd);
             fd = -1;
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) break;

@@ -38,11 +38,20 @@ def make_scene(name, seed=11):
 
 
 def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """A rendezvous port BELOW the kernel's ephemeral range (32768+ on Linux): the ranks' clients retry connect() until rank 0
+    listens, and a port inside that range can be handed to one of them as its own source port in the meantime."""
+    import random
+    for _ in range(200):
+        port = random.randint(20000, 29999)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    raise RuntimeError("no free port in 20000-29999")
 
 
 def pair_similarity(g):

@@ -47,10 +47,7 @@ def _worker(rank, world, port, sizes, q):
 
 
 def test_allgather_edges_gloo_world2():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = _free_port()
     sizes = [100, 3000, 50, 50, 700, 2000, 64, 900, 1200]  # uneven shards (5 vs 4 pairs)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -73,11 +70,20 @@ ASTAR_EXE = os.path.join(ROOT, "pose-graph-initialization_amd", "test_astar")
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """A rendezvous port BELOW the kernel's ephemeral range (32768+ on Linux): the ranks' clients retry connect() until rank 0
+    listens, and a port inside that range can be handed to one of them as its own source port in the meantime."""
+    import random
+    for _ in range(200):
+        port = random.randint(20000, 29999)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    raise RuntimeError("no free port in 20000-29999")
 
 
 def test_cpp_shard_bounds_equal_python(tmp_path):
