@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""K1 on uniform batches (BASELINE config 2's shape: P pairs x N rows, inlier ratio 0.5) with one / two / four wavefronts per
+pair: time per call at several P -> steady rate and wind-down of each count.  usage: k1_nw_uniform.py [N=2000] [P1,P2,...]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pose-graph-initialization_amd"))
+import torch
+from pyposegraphbuilder import synthetic as S
+from pyposegraphbuilder.engine import Engine
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+Ps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [5000, 10000, 20000, 40000]
+engs = {}
+for nw in (4, 2, 1):
+    os.environ["PGI_K1_NW"] = str(nw)
+    engs[nw] = Engine()
+b = S.make_batch(np.arange(max(Ps)), N)
+for P in Ps:
+    off = b["offsets"][:P + 1]
+    r = int(off[-1])
+    line = "P %6d N %4d:" % (P, N)
+    ref = None
+    for nw, e in engs.items():
+        db = e.upload(b["x1"][:r], b["y1"][:r], b["x2"][:r], b["y2"][:r], off, 7.5e-4, seed=0xB0BA)
+        ts = []
+        for rep in range(4):
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); ed, m = e.estimate_pose_batch(db); z.record(); torch.cuda.synchronize()
+            if rep: ts.append(a.elapsed_time(z))
+        by = ed.cpu().numpy().tobytes()
+        ref = ref or by
+        line += "  NW=%d %.3f ms (%.2f M/s)%s" % (nw, np.median(ts), P / np.median(ts) / 1e3, "" if by == ref else " DIFFERENT")
+        del db
+    print(line, flush=True)
