@@ -123,6 +123,7 @@ def load():
     lib.pgi_guided_match_batch.argtypes = [C.c_void_p, C.POINTER(FeatureView), C.POINTER(FeatureView), C.c_uint32, C.c_void_p,
                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
+    lib.pgi_estimate_pose_batch_streamed.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch_host.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]

@@ -776,3 +776,43 @@ def test_every_wavefront_count_per_pair_gives_the_oracles_bits(nw, monkeypatch):
             assert_edges_match(e.edges_to_numpy(eg), expg)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("nw", [0, 1])
+def test_streamed_batch_equals_the_resident_batch(nw, monkeypatch):
+    """pgi_estimate_pose_batch_streamed (include/pgi.h, round 5): the launch is issued while the caller is still "uploading" -- a
+    workgroup that takes pair k waits until the caller's ready word exceeds k (one relay workgroup reads the page-locked word,
+    the others poll its on-chip mirror).  Here the rows are resident from the start and the HOST THREAD raises the word in
+    steps with pauses in between (no stream operation stands between the waiting kernels and their release): same bytes as the
+    plain call; then once more with everything announced up front.  A pair that is never announced would come back as
+    PGI_EDGE_NOT_RESIDENT after the 4 s watchdog instead of hanging the GPU."""
+    import time
+    import torch
+    from pyposegraphbuilder import Engine
+    if nw:
+        monkeypatch.setenv("PGI_K1_NW", str(nw))
+    e = Engine()
+    try:
+        sizes = ([60, 300, 700, 1400, 2300, 500, 90, 1000] * 400)[:3000]
+        ids = np.arange(31000, 31000 + len(sizes))
+        b = S.make_batch(ids, sizes)
+        db = e.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=12, pair_id_base=31000)
+        ref_e, ref_m = e.estimate_pose_batch(db)
+        torch.cuda.synchronize()
+        ref = (ref_e.cpu().numpy().tobytes(), ref_m.cpu().numpy().tobytes())
+        ready = torch.zeros(1, dtype=torch.int32).pin_memory()
+        word = ready.numpy()
+        for steps in ((700, 1500, 2999, 3000), (3000,)):
+            word[0] = 0
+            ed, mk = e.estimate_pose_batch_streamed(db, ready)
+            for v in steps:
+                time.sleep(0.003)
+                word[0] = v
+            t0 = time.time()
+            torch.cuda.synchronize()
+            assert time.time() - t0 < 2.0          # (nothing ran into the watchdog)
+            got = e.edges_to_numpy(ed)
+            assert not np.any(got["status"] == -4)  # PGI_EDGE_NOT_RESIDENT
+            assert (ed.cpu().numpy().tobytes(), mk.cpu().numpy().tobytes()) == ref, steps
+    finally:
+        e.close()
