@@ -725,6 +725,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     mark("pose graph insertion");
     if (prefetcher.joinable()) {
         prefetcher.join();
+        rowsOnlyConvertSeconds = nullptr;
         statistics.addTime("[Pose estimation] of which row conversion of the NEXT wave (host team, on the helper thread)", prefetchConvertSeconds, 1);
         mark("next wave: rest of its row upload (exposed)");
         if (prefetchError) {
@@ -832,6 +833,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
                                                       const SimilarityTable* similarityTable, uint64_t seedBase) {
     RunStatistics st;
     typedef std::chrono::steady_clock Clock;
+    if (staging) staging->pre.valid = false;  // (rows a run that ended by an exception may have left uploaded belong to nobody)
     // descending similarity, ties by (src,dst): the order the reference pops its heap.  An index order is sorted, not the
     // candidate records themselves (10^5 records with their matrices' headers: a stable sort moved each a dozen times).
     const Clock::time_point tSort = Clock::now();
