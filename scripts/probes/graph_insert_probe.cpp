@@ -1,0 +1,28 @@
+// Host-only probe: PoseGraph::addEdges of 10^5 edges in seven batches (what the scheduler commits on the dense V = 5000 scene): ns per edge,
+// first repetitions on fresh memory.  g++ -O2 -std=c++17 -Ipose-graph-initialization_amd/host -Iinclude scripts/probes/graph_insert_probe.cpp -lpthread
+#include <chrono>
+#include <cstdio>
+#include <random>
+#include "pose_graph_builder.hpp"
+using namespace reconstruction;
+int main() {
+    const size_t V = 5000, E = 103000, W = 7;
+    std::mt19937 rng(1);
+    std::vector<PoseGraph::NewEdge> items(E);
+    std::vector<std::array<double, 12>> Rt(E);
+    for (size_t i = 0; i < E; ++i) {
+        ViewId a = rng() % V, b = (a + 1 + rng() % 40) % V;
+        for (int c = 0; c < 12; ++c) Rt[i][c] = c * 0.1 + i * 1e-6;
+        items[i] = PoseGraph::NewEdge{a, b, 0.5, Rt[i].data(), Rt[i].data() + 9};
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        PoseGraph g;
+        for (size_t v = 0; v < V; ++v) g.addVertex(v);
+        g.reserveEdges(E);
+        auto t0 = std::chrono::steady_clock::now();
+        size_t added = 0;
+        for (size_t w = 0; w < W; ++w) added += g.addEdges(items.data() + w * (E / W), E / W);
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("rep %d: %zu edges in %.4f s = %.0f ns per edge\n", rep, added, s, 1e9 * s / added);
+    }
+}

@@ -97,3 +97,46 @@ def test_driver_output_parsers():
     t = SC.pipeline_timings(pipe)[4]
     assert t["seconds"] == 0.175 and t["repetition"] == 3 and t["stages"]["upload + prepare"] == 0.029
     assert t["all_seconds"] == [0.3, 0.171, 0.491, 0.175]
+
+
+def test_every_repetitions_stage_clocks_are_parsed():
+    """bench.py puts the stage clocks of EVERY repetition into its line (round 5: a slow repetition must name its stage)."""
+    out = ("rank 0/1 transport none mode shard edges 5 rotavg iters 8 | seconds: estimate + gather + average 0.2000, rotation averaging 0.0000\n"
+           "stages: [Pose estimation]=0.1500; [Pose estimation] download=0.0010; [Rotation averaging]=0.0160;\n"
+           "rank 0/1 transport none mode shard edges 5 rotavg iters 8 | seconds: estimate + gather + average 0.1000, rotation averaging 0.0000\n"
+           "stages: [Pose estimation]=0.0800; [Pose estimation] download=0.0009; [Rotation averaging]=0.0150;\n"
+           "rank 0/1 transport none mode shard edges 5 rotavg iters 8 | seconds: estimate + gather + average 0.1100, rotation averaging 0.0000\n"
+           "stages: [Pose estimation]=0.0900; [Pose estimation] download=0.0011; [Rotation averaging]=0.0155;\n")
+    assert SC.all_seconds_of(out) == [0.2, 0.1, 0.11]
+    st = SC.all_stages_of(out)
+    assert len(st) == 3 and st[1] == {"[Pose estimation]": 0.08, "[Pose estimation] download": 0.0009, "[Rotation averaging]": 0.015}
+    assert SC.seconds_of(out) == (0.1, 0.0)                              # the median of the warm repetitions (here: the lower of two)
+    assert SC.stages_of(out)["[Pose estimation]"] == 0.08                # ... and its own stage line
+    pipe = ("mode 2: 10 pairs -> 9 edges in 0.300 s (33.3 pairs/s; 1 matched, 2 quick, 3 guided runs)\n"
+            "        seconds: upload + prepare 0.200, quick matching 0.004, matching 0.030, correspondences 0.001, A* 0.004, pose estimation 0.017, guided 0.048, commit + tracklets 0.030\n"
+            "mode 2: 10 pairs -> 9 edges in 0.170 s (58.8 pairs/s; 1 matched, 2 quick, 3 guided runs)\n"
+            "        seconds: upload + prepare 0.027, quick matching 0.004, matching 0.030, correspondences 0.001, A* 0.004, pose estimation 0.017, guided 0.048, commit + tracklets 0.030\n")
+    t = SC.pipeline_timings(pipe)[2]
+    assert t["all_seconds"] == [0.3, 0.17] and t["seconds"] == 0.17
+    assert [s["upload + prepare"] for s in t["all_stages"]] == [0.2, 0.027]
+
+
+def test_bench_summary_and_amdahl_helpers():
+    """bench.py's last key (`summary`, < 1 KB: what the driver's truncated record must still show) and the Amdahl ceilings of a
+    leg whose replicated host seconds every rank repeats."""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(SC.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.amdahl(0.12, 0.03)
+    assert a == {"n2": round(0.12 / (0.03 + 0.045), 2), "n4": round(0.12 / (0.03 + 0.0225), 2), "n8": round(0.12 / (0.03 + 0.01125), 2)}
+    assert bench.amdahl(0.1, 0.0)["n8"] == 8.0 and bench.amdahl(0.1, 0.2)["n8"] == 1.0
+    line = json.load(open(os.path.join(SC.ROOT, "profiles", "r05_bench.json")))
+    s = bench.compact_summary({k: v for k, v in line.items() if k != "summary"})
+    assert s == line["summary"] and len(json.dumps(s)) < 1024
+    assert list(line)[-1] == "summary"                                   # the last key of the line
+    for key in ("k1_edges_per_s", "k1_frac_hbm", "k2_frac_hbm", "match_exact_frac_mfma", "config3_s", "config4_s", "config4_cpu_parity",
+                "config5_guided_s", "worst_over_median_repetition"):
+        assert s[key] is not None, key
