@@ -91,7 +91,7 @@ struct K1Args {
     // thresholds, guesses); the caller's copy stream raises it behind every chunk it uploads WHILE this launch already works on
     // the earlier ones.  nullptr: everything was resident before the launch.
     const uint32_t* ready;
-    uint32_t* ready_dev;  // streamed: [0] the device-side mirror of *ready the waiting workgroups poll, [1] the relay's lock
+    uint32_t* ready_dev;  // streamed: [0] the device-side mirror of *ready the waiting workgroups poll, [1] the relay's lock, [2] "the caller is gone"
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -1101,11 +1101,14 @@ PGI_DEV bool wait_until_resident(const K1Args& a, uint32_t pair, char* smem) {
         // the very uploads they wait for (measured: a streamed config 4 took 0.16 s instead of 0.10 s).  So ONE workgroup at
         // a time -- whoever holds the lock word -- reads the host word and republishes it in device memory; everybody else
         // polls that mirror on chip.
+        // (ready_dev[2]: the first workgroup whose watchdog fires raises it, and nobody waits after that -- a launch whose caller
+        //  has gone away ends in 4 s, not in 4 s per resident workgroup and list entry)
         uint32_t ok = 1;
         uint32_t seen = __hip_atomic_load(a.ready_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (seen <= pair) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
+                if (__hip_atomic_load(a.ready_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
                 if (atomicCAS(a.ready_dev + 1, 0u, 1u) == 0u) {  // the relay
                     for (;;) {
                         const uint32_t v = __hip_atomic_load(a.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1115,7 +1118,10 @@ PGI_DEV bool wait_until_resident(const K1Args& a, uint32_t pair, char* smem) {
                         }
                         if (seen > pair) break;
                         __builtin_amdgcn_s_sleep(32);
-                        if (wall_clock64() - t0 > 400000000ull) { ok = 0; break; }
+                        if (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(a.ready_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            ok = 0;
+                            break;
+                        }
                     }
                     __hip_atomic_store(a.ready_dev + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -1125,6 +1131,7 @@ PGI_DEV bool wait_until_resident(const K1Args& a, uint32_t pair, char* smem) {
                 if (seen > pair) break;
                 if (wall_clock64() - t0 > 400000000ull) { ok = 0; break; }
             }
+            if (!ok) __hip_atomic_store(a.ready_dev + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         *flag = ok;
     }

@@ -816,3 +816,37 @@ def test_streamed_batch_equals_the_resident_batch(nw, monkeypatch):
             assert (ed.cpu().numpy().tobytes(), mk.cpu().numpy().tobytes()) == ref, steps
     finally:
         e.close()
+
+
+def test_streamed_batch_whose_caller_goes_away_ends_by_itself():
+    """The watchdog of the streamed launch: the ready word stops half way (a caller that died, a failed upload).  After 4 s the
+    first waiting workgroup gives up and tells the others; the pairs that were announced carry their normal results, the rest
+    PGI_EDGE_NOT_RESIDENT (-4) with cleared masks, the launch ends, and the context works afterwards."""
+    import time
+    import torch
+    from pyposegraphbuilder import Engine
+    e = Engine()
+    try:
+        sizes = ([60, 300, 700, 1400, 500, 90] * 400)[:2000]
+        b = S.make_batch(np.arange(52000, 52000 + len(sizes)), sizes)
+        db = e.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=3, pair_id_base=52000)
+        ref_e, ref_m = e.estimate_pose_batch(db)
+        ref = e.edges_to_numpy(ref_e)
+        ref_masks = ref_m.cpu().numpy()
+        ready = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ready.numpy()[0] = 1200
+        t0 = time.time()
+        ed, mk = e.estimate_pose_batch_streamed(db, ready)
+        torch.cuda.synchronize()
+        waited = time.time() - t0
+        assert 3.0 < waited < 12.0, waited
+        got, gm = e.edges_to_numpy(ed), mk.cpu().numpy()
+        off = b["offsets"].astype(np.int64)
+        assert np.array_equal(got["status"][1200:], np.full(800, -4)) and not gm[off[1200]:].any()
+        for key in ("E", "status", "n_inl", "iters", "R"):
+            assert np.array_equal(got[key][:1200], ref[key][:1200]), key
+        assert np.array_equal(gm[:off[1200]], ref_masks[:off[1200]])
+        again_e, again_m = e.estimate_pose_batch(db)                      # the context is as good as before
+        assert torch.equal(again_e, ref_e) and torch.equal(again_m, ref_m)
+    finally:
+        e.close()
