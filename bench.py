@@ -104,8 +104,11 @@ class ClockSampler:
         if not self.vals:
             return None
         v = np.array(self.vals)
-        return {"samples": int(len(v)), "min_mhz": int(v.min()), "median_mhz": int(np.median(v)), "max_mhz": int(v.max()),
-                "source": "pp_dpm_sclk polled by a side thread during the timed calls"}
+        med = int(np.median(v))
+        return {"samples": int(len(v)), "min_mhz": int(v.min()), "median_mhz": med, "max_mhz": int(v.max()),
+                "source": "pp_dpm_sclk polled by a side thread during the timed calls",
+                # (some leases' sysfs keeps showing the idle state -- ~100 MHz -- under full load: such a reading says nothing)
+                "plausible": bool(med >= 500)}
 
 
 def pcie_h2d_peak_gbs(torch, device, mb=256, reps=4):
@@ -213,7 +216,7 @@ def compact_summary(out):
          "match_exact_frac_mfma": dig("match_descriptors", "roofline", "frac"),
          "match_exact_ms_min_med_max": [dig("match_descriptors", "min_ms"), dig("match_descriptors", "ms"), dig("match_descriptors", "max_ms")],
          "match_first_call_ms": dig("match_descriptors", "first_call_ms"),
-         "match_sclk_mhz_median": dig("match_descriptors", "sclk_during_timed_calls", "median_mhz"),
+         "match_sclk_mhz_median": dig("match_descriptors", "sclk_during_timed_calls", "median_mhz") if dig("match_descriptors", "sclk_during_timed_calls", "plausible") else None,
          "match_screened_ms": dig("match_descriptors", "screened", "ms"),
          "cpu_edges_per_s": dig("cpu_baseline", "value"), "cpu_cores": dig("cpu_baseline", "cores"), "cpu_parity": dig("cpu_baseline", "gpu_matches_on_sample")}
     f = out.get("config3_from_features") or {}
