@@ -33,6 +33,14 @@
 #include <vector>
 
 namespace pgi {
+// Inner solves of the rotation averaging stop at |r|_M <= 1e-4 |r0|_M (round 5; 1e-10 before).  The outer IRLS loop is a fixed-point
+// iteration whose steps shrink 3-5x each, and the preconditioned systems have an effective condition of ~40 (75 iterations for ten
+// orders of magnitude), so a relative residual of 1e-4 leaves ~6e-4 of a step as error -- two orders below the next step.  Measured
+// (scripts/rotavg_bench.py + soak_rotavg.py, 120 random graphs x 2 solver settings): 1e-10 / 1e-6 / 1e-4 / 1e-3 -> V = 5000: 12.2 / 11.0 /
+// 9.2 / 8.0 ms, band graph (config 4's shape) 19.7 / 14.6 / 12.1 / 11.1 ms; outer iteration counts and the worst difference from the
+// oracle's direct solves (3.4e-7 rad) are THE SAME down to 1e-4; at 1e-3 the first iteration counts move by one.
+constexpr double kInnerTolerance = 1e-4;
+
 
 #define RDEV __device__ __forceinline__
 constexpr uint32_t kSingleWgViews = 64;  // at or below (16 lanes per view in one pass): one-workgroup PCG in a single launch
@@ -1698,6 +1706,9 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                     (int)inv_lds));
         return 0;
     };
+    // relative tolerance of every inner solve (kInnerTolerance above; PGI_ROTAVG_CG_TOL overrides)
+    double cg_tol = kInnerTolerance;
+    if (const char* e = std::getenv("PGI_ROTAVG_CG_TOL")) cg_tol = std::min(1e-2, std::max(1e-14, std::atof(e)));
     double two_iters = 0;  // iterations of the last two-level solve (trace)
     std::vector<double> norm_host;  // block partials of the step norm (multi-workgroup, tree and two-level paths)
     // one two-level solve of the current outer step, applied to the rotations, norm_host filled; 1 when the coarse matrix could
@@ -1734,7 +1745,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
             const int prev = (int)((launch + 1) & 1u), next = (int)(launch & 1u);
             hipLaunchKernelGGL(cg2_iteration_kernel, dim3(mode == 2 ? 1u : NB), dim3(kCgBlock), 0, st, N, ptr2, edge2, other2, agg2, root2,
                                (const double*)(d + o_w), (const double*)diag2, x2, p2, (const double*)rbuf[cur], rbuf[cur ^ 1],
-                               (const double*)qbuf[cur], qbuf[cur ^ 1], (const double*)sbuf[cur], sbuf[cur ^ 1], mode, launch == 1 ? 1 : 0, 1e-10,
+                               (const double*)qbuf[cur], qbuf[cur ^ 1], (const double*)sbuf[cur], sbuf[cur ^ 1], mode, launch == 1 ? 1 : 0, cg_tol,
                                (const double*)pbuf[prev], pbuf[next], NB, (const CgState*)(cst + prev), mode == 2 ? record : cst + next, NA,
                                (const uint32_t*)(d2 + t_ablk2), (const uint8_t*)(d2 + t_aob2), (const double*)(d2 + t_Ainv2),
                                (const double*)(d2 + t_rpart2), (const double*)csbuf[prev], csbuf[next]);
@@ -1799,7 +1810,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                (const uint32_t*)(d + o_tedge), (const uint32_t*)(d + o_tother), (const int8_t*)(d + o_tsign),
                                (const uint32_t*)(d + o_tpe), (const uint32_t*)(d + o_tsz), (const uint32_t*)(d + o_ten),
                                (const uint32_t*)(d + o_tex), (const uint32_t*)(d + o_tn2o), (const double*)(d + o_omega),
-                               (const double*)(d + o_w), std::max<uint32_t>(prm.cg_iters, 1000u), 1e-10, (TreeIncidence*)(d + o_aw),
+                               (const double*)(d + o_w), std::max<uint32_t>(prm.cg_iters, 1000u), cg_tol, (TreeIncidence*)(d + o_aw),
                                (double*)(d + o_x), (double*)(d + o_its));
         };
         // multi-workgroup Jacobi PCG: 1 = converged (and applied: finish_views ran on the record), 0 = not, < 0 on an error
@@ -1824,7 +1835,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
                                    (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const uint8_t*)(d + o_root),
                                    (const double*)(d + o_w), (const double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_p),
                                    (const double*)rbuf[cur], rbuf[cur ^ 1], (const double*)qbuf[cur], qbuf[cur ^ 1],
-                                   (const double*)sbuf[cur], sbuf[cur ^ 1], mode, launch == 1 ? 1 : 0, 1e-10, (const double*)pbuf[prev],
+                                   (const double*)sbuf[cur], sbuf[cur ^ 1], mode, launch == 1 ? 1 : 0, cg_tol, (const double*)pbuf[prev],
                                    pbuf[next], nbp, (const CgState*)(cst + prev), mode == 2 ? record : cst + next);
                 if (mode != 2) {
                     cur ^= 1;
@@ -1851,7 +1862,7 @@ static int rotavg_solve(pgi_ctx* ctx, const pgi_rotavg_params& prm_in, uint32_t 
             hipLaunchKernelGGL(rot_solve_kernel, dim3(1), dim3(1024), 0, st, n_views, (const uint32_t*)(d + o_ptr),
                                (const uint32_t*)(d + o_aedge), (const uint32_t*)(d + o_aother), (const int8_t*)(d + o_asign),
                                (const uint8_t*)(d + o_root), (const double*)(d + o_omega), (const double*)(d + o_w),
-                               prm.cg_iters, 1e-10, row_lanes, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
+                               prm.cg_iters, cg_tol, row_lanes, (double*)(d + o_diag), (double*)(d + o_x), (double*)(d + o_r),
                                (double*)(d + o_p), (double*)(d + o_Ap), (double*)(d + o_stats));
             single_now = true;
             if (tree_ok) {  // a solve that ran into the cap sends this graph to the tree path (see the multi-workgroup branch)

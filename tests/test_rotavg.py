@@ -197,9 +197,11 @@ def test_two_level_solver_forced_on_well_conditioned_graphs(V, k, noise, outl, c
 @pytest.mark.gpu
 def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch):
     """5000 views x ~21 edges per view: the first L1 solve runs into the 200-iteration cap, but the spanning forest is a
-    far worse preconditioner there (1 380 iterations against 19) -- the solver must not switch."""
+    far worse preconditioner there (1 380 iterations against 19) -- the solver must not switch.  (Inner tolerance pinned to the
+    1e-10 of rounds 1-4: at the default 1e-4 that first solve stops before the cap and the rule is not exercised.)"""
     from pyposegraphbuilder import Engine
     monkeypatch.setenv("PGI_ROTAVG_TRACE", "1")
+    monkeypatch.setenv("PGI_ROTAVG_CG_TOL", "1e-10")
     eng = Engine()
     src, dst, Rrel, w, Rgt, _ = RO.make_graph(5000, 20, noise_deg=1.0, outlier_frac=0.15, seed=2)
     R, iters = eng.rotation_average(src, dst, Rrel, w, 5000)
@@ -207,6 +209,29 @@ def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch
     assert "(L1): 200 PCG" in trace and "): -" not in trace and "two-level" not in trace
     assert iters <= 12 and RO.align_error_deg(R, Rgt).mean() < 0.5
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["random", "band", "sequence"])
+def test_inner_tolerance_does_not_move_the_fixed_point(kind, monkeypatch):
+    """The inner solves stop at a relative 1e-4 by default (PGI_ROTAVG_CG_TOL overrides): the same outer iteration count and
+    the same rotations as with solves to 1e-10, to well under the distance either keeps from the oracle's direct solves."""
+    from pyposegraphbuilder import Engine
+    if kind == "random":
+        V = 1500
+        src, dst, Rrel, w, _, _ = RO.make_graph(V, 12, noise_deg=2.0, outlier_frac=0.25, seed=5)
+    else:
+        V = 3000
+        src, dst, Rrel, w, _ = sequence_graph(V, 12 if kind == "band" else 4, 1.0, 0.05, seed=19)
+    got = {}
+    for tol in ("", "1e-10"):
+        if tol:
+            monkeypatch.setenv("PGI_ROTAVG_CG_TOL", tol)
+        eng = Engine()
+        got[tol] = eng.rotation_average(src, dst, Rrel, w, V)
+        eng.close()
+    assert got[""][1] == got["1e-10"][1], (got[""][1], got["1e-10"][1])
+    assert np.abs(got[""][0] - got["1e-10"][0]).max() < 1e-6
 
 
 @pytest.mark.gpu
