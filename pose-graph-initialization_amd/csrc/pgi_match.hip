@@ -1503,6 +1503,377 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     ratio_out[P.off + i] = ratio;
 }
 
+constexpr int kGfCap = 20;  // candidates a source lists per round in guided_scan_flat_kernel (16: 7 workgroups per CU but more second
+                            // rounds, 24: 5 workgroups; measured 3.04 / 3.03 / 3.33 ms per 510 pairs)
+// The same scan with the descriptor sums taken off the source's own lane (round 5).  In the tile kernel above a lane sums only
+// its own source's candidates among the sixteen staged rows -- one or two, while the wavefront waits for the lane that has
+// five (28 % of the lanes' additions were useful).  Here, grid (8 x ceil(blocks / 8)), ONE wavefront per workgroup, one lane
+// per source (64 neighbours in window order):
+//   (1) every lane fetches its source's descriptor into 128 registers itself (32 loads of 16 bytes; the 64 lines a load touches
+//       serve the next seven), in flight during the window arithmetic;
+//   (2) as above, but a lane keeps its gate-passing destinations in its column of `list` ordered by RECORD POSITION (they are
+//       met nearly in that order: an insertion that rarely moves anything); a source with more than C of them keeps the C
+//       smallest destination indices and takes another round;
+//   (3) per sixteen staged rows the lanes pool their candidates: (source lane, candidate a, candidate b) items -- two
+//       candidates of one source, so that its descriptor travels once for two sums -- are dealt 64 at a time, one per lane,
+//       whichever lane the source lives in: the source's descriptor comes through ds_bpermute, the two rows from LDS, and the
+//       two sums run as independent chains, sequentially in double as above.  A lane's candidates inside a tile are a run of
+//       its ordered list: sixteen entries are read at once, the run's length, the items and the position the lane waits for
+//       next come from them without a loop; offsets and the next tile come over the DPP network;
+//   (4) as above, without relying on the lists' order: best = the smallest (distance, index), second = the smallest distance
+//       among smaller indices.
+// Blocks are renumbered so that each XCD takes a contiguous run of them: neighbours in window order want the same records and
+// rows, and now find them in their own L2.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {  // every lane active; the result is wavefront-uniform
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror: every lane holds its row's
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {  // every lane active
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1 (a lane without a source adds 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// PGI_GUIDED_PHASES=1 (diagnostics): PH counts the clock ticks a wavefront spends per phase into g_guided_phase
+__device__ unsigned long long g_guided_phase[8];
+template <int C, bool PH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_scan_flat_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
+    const double* __restrict__ spans, const uint32_t* __restrict__ order, int32_t* __restrict__ best_out, double* __restrict__ ratio_out,
+    uint32_t blocks_per_pair, uint32_t n_blocks) {
+    static_assert(C >= 2 && C <= 32, "a candidate's place in the list is five bits of an item");
+    static_assert(kGtRows == 16, "sixteen rows in flight per pass; a row number is four bits of an item");
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    constexpr int D = 1;  // steps the sums' operands travel ahead (2 and 3 measured equal)
+    __shared__ uint32_t list[C][64];  // (destination index << 16 | record position), ascending record position
+    __shared__ double dist[64][C | 1];  // per source (an odd stride: the lanes that sum one source's candidates write different banks)
+    __shared__ uint32_t batch[64 * kGtRows / 2];  // items: lane | a << 6 | row a << 11 | b << 15 | row b << 20
+    __shared__ __attribute__((aligned(16))) float tile[kGtRows][kGtStride];
+    const uint32_t per_xcd = (n_blocks + 7u) / 8u;
+    const uint32_t logical = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    if (logical >= n_blocks) return;
+    const uint32_t pair_id = logical / blocks_per_pair, bx = logical % blocks_per_pair;
+    const GuidedPair P = pairs[pair_id];
+    const uint32_t lane = threadIdx.x;
+    if (bx * 64u >= P.n1) return;      // (wavefront-uniform; in a live wavefront every lane stays for the shared steps)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ph = PH ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto tick = [&](int k) {
+        if (PH) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph[k] += now - t_ph; t_ph = now; }
+    };
+    const bool active = bx * 64u + lane < P.n1;
+    const uint32_t i = active ? order[P.off + bx * 64u + lane] : 0u;
+    // (1)
+    float a[kD];
+    {
+        const float4* row = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
+#pragma unroll
+        for (int q = 0; q < kD / 4; ++q) {
+            const float4 t = row[q];
+            a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+        }
+    }
+    const double x1 = (double)P.kp1[2 * (size_t)i], y1 = (double)P.kp1[2 * (size_t)i + 1];
+    const double rx = (P.F[0] * x1 + P.F[1] * y1) + P.F[2];
+    const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
+    const double b1 = rx * rx + ry * ry;
+    const double vx = x1 - P.ep0, vy = y1 - P.ep1;
+    const int32_t my_bin = epipolar_bin(vx, -vy, P.min_angle, P.range, P.bins);
+    const uint32_t* st = starts + (size_t)pair_id * (kGaBuckets + 2);
+    const double amin = spans[2 * (size_t)pair_id], amax = spans[2 * (size_t)pair_id + 1];
+    // the fine buckets of this source's bin and of its gate window, as in guided_scan_tile_kernel
+    int f0 = 0, f1 = kGaBuckets - 1;
+    if (P.bins > 1 && P.range == P.range && P.range != 0.0) {
+        const double step = P.range / (double)(P.bins - 1);
+        const double ea = P.min_angle + ((double)my_bin - 0.5) * step, eb = P.min_angle + ((double)my_bin + 0.5) * step;
+        const bool open_lo = my_bin == 0, open_hi = my_bin == P.bins - 1;
+        double lo_ang = fmin(ea, eb), hi_ang = fmax(ea, eb);
+        if ((open_lo && step > 0.0) || (open_hi && step < 0.0)) lo_ang = -1.0e300;
+        if ((open_hi && step > 0.0) || (open_lo && step < 0.0)) hi_ang = 1.0e300;
+        f0 = max(0, ga_fine(lo_ang, amin, amax) - 1);
+        f1 = min(kGaBuckets - 1, ga_fine(hi_ang, amin, amax) + 1);
+    }
+    int g0[2] = {0, 0}, g1[2] = {kGaBuckets - 1, -1};
+    const double d2 = vx * vx + vy * vy;
+    if (d2 > 4.0 && d2 < 1.0e300 && b1 > 0.0 && b1 < 1.0e300) {
+        const double c = ga_source_centre(vx, vy);
+        const double half = kRadianToDegree * asin(0.75 / sqrt(d2)) * 1.0001 + 1.0e-5;
+        if (2.0 * half < 179.0) {
+            double lo[2] = {c - half, 0.0}, hi[2] = {c + half, -1.0};
+            if (lo[0] <= 0.0) { lo[1] = lo[0] + 180.0; hi[1] = 180.0; lo[0] = 0.0; }
+            else if (hi[0] > 180.0) { lo[1] = 0.0; hi[1] = hi[0] - 180.0; hi[0] = 180.0; }
+            for (int k = 0; k < 2; ++k) {
+                if (hi[k] < lo[k]) { g0[k] = 0; g1[k] = -1; continue; }
+                const int fa = ga_fine(lo[k], amin, amax), fb = ga_fine(hi[k], amin, amax);
+                if (fa < 0 || fb < 0) { g0[k] = 0; g1[k] = kGaBuckets - 1; continue; }
+                g0[k] = max(0, fa - 1);
+                g1[k] = min(kGaBuckets - 1, fb + 1);
+            }
+        }
+    }
+    int v0[2], v1[2];
+    for (int k = 0; k < 2; ++k) { v0[k] = max(g0[k], f0); v1[k] = min(g1[k], f1); }
+    if (v1[0] >= v0[0] && v1[1] >= v0[1] && v0[1] <= v1[0] + 1 && v0[0] <= v1[1] + 1) {
+        v0[0] = min(v0[0], v0[1]);
+        v1[0] = max(v1[0], v1[1]);
+        v1[1] = v0[1] - 1;
+    }
+    uint32_t re0[3] = {0u, 0u, st[kGaBuckets]}, re1[3] = {0u, 0u, st[kGaBuckets + 1]};
+    for (int k = 0; k < 2; ++k)
+        if (v1[k] >= v0[k]) { re0[k] = st[v0[k]]; re1[k] = st[v1[k] + 1]; }
+    if (!active) re1[0] = re0[0] = re1[1] = re0[1] = re1[2] = re0[2] = 0u;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    tick(0);
+    static_assert(sizeof(GaEntry) == 48 && kGtRecs * sizeof(GaEntry) <= sizeof(float) * kGtRows * kGtStride, "records are staged in the tile");
+    GaEntry* recs = reinterpret_cast<GaEntry*>(&tile[0][0]);
+    // (2) this lane's gate-passing destinations with index > after, the C smallest indices of them in `list`; returns how many in all
+    auto collect = [&](int64_t after, bool idle) -> uint32_t {  // idle: a source that is done only helps with the staging
+        uint32_t total = 0;
+        uint32_t c0[3] = {idle ? re1[0] : re0[0], idle ? re1[1] : re0[1], idle ? re1[2] : re0[2]};  // cursors
+        while (true) {
+            uint32_t need = kNone;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (c0[k] < re1[k]) need = min(need, c0[k]);
+            need = wave_min_u32(need);
+            if (need == kNone) break;
+            const uint32_t E = need, nrec = min((uint32_t)kGtRecs, P.n2 - E);
+            wave_sync();
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(entries + P.off2 + E);
+                uint4* dst = reinterpret_cast<uint4*>(recs);
+                for (uint32_t q = lane; q < nrec * 3u; q += 64u) dst[q] = src[q];
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t lo = max(c0[k], E), hi = min(re1[k], E + nrec);
+                // two records per step: their reads travel together and the two gates are independent chains (the reference's tests,
+                // matcher.h:340-351, evaluated without branches; only the rare value between "surely near" and "surely far" divides)
+                auto gate = [&](const GaEntry& en) -> bool {
+                    const bool mine = (en.bin == my_bin) & ((int64_t)en.j > after);
+                    const double r = (x1 * en.rxc + y1 * en.ryc) + en.rwc;
+                    const double num = (r * r) * (en.a1 + b1), den = en.a1 * b1;
+                    const bool far = (den > 0.0) & (num >= 0.57 * den), near = (den > 0.0) & (num <= 0.56 * den);
+                    bool pass = mine & !far;
+                    if (pass && !near) pass = !(num / den >= 0.75 * 0.75);  // the reference's quotient decides
+                    return pass;
+                };
+                auto append = [&](uint32_t j, uint32_t e) {
+                    const uint32_t key = (j << 16) | e;
+                    uint32_t pos = min(total, (uint32_t)C);  // where the listed ones end
+                    bool put = true;
+                    if (total >= (uint32_t)C) {  // full: the largest listed index makes room if this one is smaller (rare)
+                        uint32_t mx = 0, mp = 0;
+                        for (uint32_t p2 = 0; p2 < (uint32_t)C; ++p2) {
+                            const uint32_t v = list[p2][lane];
+                            if (v > mx) { mx = v; mp = p2; }
+                        }
+                        put = key < mx;
+                        if (put) {
+                            for (uint32_t p2 = mp; p2 + 1u < (uint32_t)C; ++p2) list[p2][lane] = list[p2 + 1u][lane];
+                            pos = (uint32_t)C - 1u;
+                        }
+                    }
+                    if (put) {  // into its place by record position (usually the end: records are met in ascending position per range)
+                        while (pos > 0u) {
+                            const uint32_t prev = list[pos - 1u][lane];
+                            if ((prev & 0xFFFFu) <= e) break;
+                            list[pos][lane] = prev;
+                            --pos;
+                        }
+                        list[pos][lane] = key;
+                    }
+                    ++total;
+                };
+                for (uint32_t e = lo; e < hi; e += 2u) {
+                    const bool two = e + 1u < hi;
+                    const GaEntry en0 = recs[e - E], en1 = recs[(two ? e + 1u : e) - E];
+                    const bool p0 = gate(en0), p1 = gate(en1) & two;
+                    if (p0) append(en0.j, e);
+                    if (p1) append(en1.j, e + 1u);
+                }
+                if (hi > c0[k]) c0[k] = hi;
+            }
+        }
+        return total;
+    };
+    double best = DBL_MAX, second = DBL_MAX;
+    int32_t best_index = -1;
+    uint32_t count = 0;
+    int64_t after = -1;
+    bool more = true;
+    while (__any(more)) {
+        const uint32_t total = collect(after, !more);
+        tick(2);
+        const uint32_t nlist = min(total, (uint32_t)C);
+        uint32_t jcap = kNone;  // a source with more than it lists: this round covers the indices up to its largest listed one
+        if (total > (uint32_t)C) {
+            jcap = 0u;
+            for (uint32_t c = 0; c < (uint32_t)C; ++c) jcap = max(jcap, list[c][lane] >> 16);
+        }
+        // (3) the tiles of sixteen records that hold listed candidates, ascending
+        wave_sync();  // (the lists are complete; the tile is free)
+        uint32_t cur = 0;  // this lane's first candidate not yet dealt
+        uint32_t E0 = wave_min_u32(nlist ? (list[0][lane] & 0xFFFFu) : kNone);
+        auto tile_index = [&](uint32_t E) -> uint32_t {  // destination indices of the records E .. E + 15, one per lane
+            return (E != kNone && lane < min((uint32_t)kGtRows, P.n2 - E)) ? entries[P.off2 + E + lane].j : 0u;
+        };
+        float2 bv[16];  // a tile's rows travel while the tile before it is summed
+        auto fetch_rows = [&](uint32_t E, uint32_t rj) {
+            const uint32_t nr = min((uint32_t)kGtRows, P.n2 - E);
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rj, (int)u);
+                if (u < nr) bv[u] = reinterpret_cast<const float2*>(P.d2 + (size_t)j * kD)[lane];
+            }
+        };
+        // the wavefront's first listed record position at or after `from` (kNone: none).  A lane looks at the next sixteen of its
+        // ordered list; one that finds them all below `from` with more behind answers `from` itself: a valid bound, never past an entry
+        auto tile_after = [&](uint32_t from) -> uint32_t {
+            uint32_t m = kNone;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t e = list[min(cur + k, (uint32_t)C - 1u)][lane] & 0xFFFFu;
+                if (cur + k < nlist && e >= from) m = min(m, e);
+            }
+            if (m == kNone && cur + 16u < nlist) m = from;
+            return wave_min_u32(m);
+        };
+        // tiles E0 (dealt and summed now), E1 (its rows travel meanwhile) and E2 (its destination indices travel): each start is
+        // fixed two tiles ahead, so no load waits for the one before it
+        uint32_t E1 = E0 == kNone ? kNone : tile_after(E0 + (uint32_t)kGtRows);
+        uint32_t rj1 = tile_index(E1);
+        if (E0 != kNone) fetch_rows(E0, tile_index(E0));
+        while (E0 != kNone) {
+            const uint32_t nrow = min((uint32_t)kGtRows, P.n2 - E0);
+            // the next sixteen of this lane's ordered list: those inside the tile are a run from `cur` (positions are distinct:
+            // at most sixteen)
+            uint32_t rel[16];
+            uint32_t n_mine = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t e = list[min(cur + k, (uint32_t)C - 1u)][lane] & 0xFFFFu;
+                rel[k] = e - E0;
+                n_mine += (cur + k < nlist && e - E0 < nrow) ? 1u : 0u;
+            }
+            const uint32_t n_items = (n_mine + 1u) / 2u;
+            const uint32_t incl = wave_inclusive_sum(n_items);
+            const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            {
+                const uint32_t o = incl - n_items;
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k += 2u)
+                    if (k < n_mine) {
+                        const bool two = k + 1u < n_mine;
+                        const uint32_t ca = cur + k, cb = two ? ca + 1u : ca, ra = rel[k], rb = two ? rel[k + 1u] : ra;
+                        batch[o + k / 2u] = lane | (ca << 6) | (ra << 11) | (cb << 15) | (rb << 20);
+                    }
+            }
+            cur += n_mine;
+            const uint32_t E2 = E1 == kNone ? kNone : tile_after(E1 + (uint32_t)kGtRows);
+            const uint32_t rj2 = tile_index(E2);
+            tick(3);
+            wave_sync();  // (the previous tile's sums are done)
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u)
+                if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+            if (E1 != kNone) fetch_rows(E1, rj1);
+            wave_sync();
+            tick(4);
+            for (uint32_t base = 0; base < B; base += 64u) {
+                const bool valid = base + lane < B;
+                const uint32_t item = valid ? batch[base + lane] : lane;  // (a lane without an item sums row 0 against itself and drops it:
+                const uint32_t owner = item & 63u;                         //  every lane stays in, its registers are read by others)
+                const uint32_t ca = (item >> 6) & 31u, cb = (item >> 15) & 31u;
+                const float4* ta = reinterpret_cast<const float4*>(&tile[(item >> 11) & 15u][0]);
+                const float4* tb = reinterpret_cast<const float4*>(&tile[(item >> 20) & 15u][0]);
+                const int from = (int)(owner << 2);
+                double da = 0.0, db = 0.0;
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                auto pull = [&](float s) { return __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(s))); };
+                // D steps ahead: the operands of elements 4 (q + D) .. travel while 4 q .. 4 q + 3 are summed.  The empty asm
+                // ties the two chains to their step: without it instruction selection hoists all 64 row reads and 128 pulls above
+                // the arithmetic and the descriptor is spilled (measured: 900 dwords of scratch).
+                float4 U[D + 1], V[D + 1];
+                float S[D + 1][4];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    U[d] = ta[d]; V[d] = tb[d];
+                    S[d][0] = pull(a[4 * d]); S[d][1] = pull(a[4 * d + 1]); S[d][2] = pull(a[4 * d + 2]); S[d][3] = pull(a[4 * d + 3]);
+                }
+#pragma unroll
+                for (int q = 0; q < kD / 4; ++q) {
+                    if (q + D < kD / 4) {
+                        const int n = (q + D) % (D + 1), e = 4 * (q + D);
+                        U[n] = ta[q + D]; V[n] = tb[q + D];
+                        S[n][0] = pull(a[e]); S[n][1] = pull(a[e + 1]); S[n][2] = pull(a[e + 2]); S[n][3] = pull(a[e + 3]);
+                    }
+                    const int c = q % (D + 1);
+                    const float4 u = U[c], v = V[c];
+                    const pk2 a01 = {S[c][0], S[c][1]}, a23 = {S[c][2], S[c][3]};
+                    const pk2 du01 = a01 - pk2{u.x, u.y}, du23 = a23 - pk2{u.z, u.w}, dv01 = a01 - pk2{v.x, v.y}, dv23 = a23 - pk2{v.z, v.w};
+                    const double u0 = (double)du01.x, u1 = (double)du01.y, u2 = (double)du23.x, u3 = (double)du23.y;
+                    const double w0 = (double)dv01.x, w1 = (double)dv01.y, w2 = (double)dv23.x, w3 = (double)dv23.y;
+                    da = fma(u0, u0, da); db = fma(w0, w0, db);
+                    da = fma(u1, u1, da); db = fma(w1, w1, db);
+                    da = fma(u2, u2, da); db = fma(w2, w2, db);
+                    da = fma(u3, u3, da); db = fma(w3, w3, db);
+                    asm volatile("" : "+v"(da), "+v"(db));
+                }
+                if (valid) {
+                    dist[owner][ca] = da;
+                    dist[owner][cb] = db;
+                }
+            }
+            tick(5);
+            E0 = E1; E1 = E2; rj1 = rj2;
+        }
+        wave_sync();
+        // (4) the round's smallest (distance, index), then the smallest distance among smaller indices
+        double m_d = DBL_MAX;
+        uint32_t m_j = kNone;
+        for (uint32_t c = 0; c < nlist; ++c) {
+            const double dc = dist[lane][c];
+            const uint32_t jc = list[c][lane] >> 16;
+            if (dc < m_d || (dc == m_d && jc < m_j)) { m_d = dc; m_j = jc; }
+        }
+        double s_d = DBL_MAX;
+        for (uint32_t c = 0; c < nlist; ++c)
+            if ((list[c][lane] >> 16) < m_j) s_d = fmin(s_d, dist[lane][c]);
+        count += nlist;
+        if (m_d < best) {  // the earlier rounds held smaller indices: their best is a predecessor of this round's first minimum
+            second = fmin(best, s_d);
+            best = m_d;
+            best_index = (int32_t)m_j;
+        }
+        more = more && jcap != kNone;
+        if (more) after = (int64_t)jcap;
+        tick(6);
+    }
+    if (PH && lane == 0u)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_guided_phase[k], ph[k]);
+    if (!active) return;
+    double corr = 1.0;
+    if (count < 20u) corr = 0.65 * 0.65;
+    if (count < 10u) corr = 0.6 * 0.6;
+    if (count < 5u) corr = 0.5 * 0.5;
+    if (count < 3u) corr = 0.25 * 0.25;
+    const double ratio = (best / second) / corr;
+    const bool keep = !(ratio < 0.00001) && best_index > -1 && (ratio < 0.8 * 0.8 || count == 1u);
+    best_out[P.off + i] = keep ? best_index : -1;
+    ratio_out[P.off + i] = ratio;
+}
+
 __global__ __launch_bounds__(1024) void guided_select_kernel(const GuidedPair* __restrict__ pairs, const int32_t* __restrict__ best_in,
                                                              const double* __restrict__ ratio_in, uint32_t* __restrict__ ci,
                                                              uint32_t* __restrict__ cj, double* __restrict__ cr, uint32_t max_n,
@@ -2128,8 +2499,9 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     }
     // bucketed scan (the hashing saves the work) where the bins fit its counters; otherwise the tiled scan over everything
     const bool bucketed = n_bins > 0 && n_bins <= (uint32_t)kGmMaxBuckets && max_kp <= (uint32_t)PGI_DESC_MAX;
-    // default for the binned mode: the fine angular index + tile scan (guided_scan_tile_kernel); PGI_GUIDED_ANGLE=0 keeps the
-    // bin-bucketed scan, PGI_GUIDED_LANES = 1 | 2 | 4 sets the lanes per source keypoint (read per call: tests switch them)
+    // default for the binned mode: the fine angular index + pooled scan (guided_scan_flat_kernel); PGI_GUIDED_ANGLE=0 keeps the
+    // bin-bucketed scan, PGI_GUIDED_LANES=2 the round-3 tile scan, PGI_GUIDED_CAP = 4 | 16 the pooled scan with shorter lists
+    // (read per call: tests switch them)
     const char* angle_txt = getenv("PGI_GUIDED_ANGLE");
     const bool angle_env = !angle_txt || atoi(angle_txt) != 0;
     const bool angular = n_bins > 0 && angle_env && max_kp <= 65535u;  // (record positions are packed in 16 bits)
@@ -2174,14 +2546,33 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         hipLaunchKernelGGL(guided_angle_bucket_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_pairs, d_ent, d_key, d_gst, d_span,
                            d_cj /* the source order: guided_select_kernel overwrites it only after the scan */);
         const char* lanes_txt = getenv("PGI_GUIDED_LANES");
-        const int lanes_env = lanes_txt ? atoi(lanes_txt) : 2;
-        if (lanes_env == 1)
-            hipLaunchKernelGGL(guided_scan_tile_kernel<1>, dim3((max_n1 + 63) / 64, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
-                               d_cj, d_best, d_rat);
-        else if (lanes_env == 4)
-            hipLaunchKernelGGL(guided_scan_tile_kernel<4>, dim3((max_n1 + 15) / 16, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
-                               d_cj, d_best, d_rat);
-        else
+        const int lanes_env = lanes_txt ? atoi(lanes_txt) : 0;
+        const char* cap_txt = getenv("PGI_GUIDED_CAP");
+        const int cap_env = cap_txt ? atoi(cap_txt) : kGfCap;
+        const uint32_t flat_per_pair = (max_n1 + 63u) / 64u, flat_blocks = flat_per_pair * n_pairs;
+        const dim3 flat_grid((flat_blocks + 7u) / 8u * 8u);
+        const char* ph_txt = getenv("PGI_GUIDED_PHASES");
+        const bool phases = ph_txt && atoi(ph_txt) != 0;
+#define PGI_FLAT(CAP, PHV) hipLaunchKernelGGL((guided_scan_flat_kernel<CAP, PHV>), flat_grid, dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span, d_cj, \
+                                              d_best, d_rat, flat_per_pair, flat_blocks)
+        if (lanes_env == 0 && phases) {  // diagnostics: where the wavefronts' time goes
+            unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}, got[8];
+            HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_guided_phase), zero, sizeof(zero), 0, hipMemcpyHostToDevice, ctx->stream));
+            PGI_FLAT(kGfCap, true);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_guided_phase), sizeof(got)));
+            double all = 0;
+            for (int k = 0; k < 7; ++k) all += (double)got[k];
+            fprintf(stderr, "[pgi] guided scan phases (%u pairs): setup + source rows %.1f %%, gate pass %.1f, deal %.1f, rows %.1f, sums %.1f, pick %.1f"
+                    " | %.0f s_memtime ticks per wavefront, %u wavefronts launched\n",
+                    n_pairs, 100 * got[0] / all, 100 * got[2] / all, 100 * got[3] / all, 100 * got[4] / all, 100 * got[5] / all, 100 * got[6] / all,
+                    all / flat_blocks, flat_blocks);
+        }
+        else if (lanes_env == 0 && cap_env == 4) PGI_FLAT(4, false);   // (tests: several rounds per source)
+        else if (lanes_env == 0 && cap_env == 16) PGI_FLAT(16, false);
+        else if (lanes_env == 0) PGI_FLAT(kGfCap, false);
+#undef PGI_FLAT
+        else  // PGI_GUIDED_LANES != 0: the round-3 scan, two lanes per source (kept as the cross-check of tests and soaks)
             hipLaunchKernelGGL(guided_scan_tile_kernel<2>, dim3((max_n1 + 31) / 32, n_pairs), dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span,
                                d_cj, d_best, d_rat);
         HIP_TRY(hipGetLastError());

@@ -1,4 +1,5 @@
-"""Guided-matching throughput (pgi_guided_match_batch): P pairs of K keypoints each, SIFT-sized."""
+"""Guided-matching throughput (pgi_guided_match_batch): P pairs of K keypoints each, SIFT-sized.
+    guided_bench.py [points per view (6000)] [repeats of the 30 pairs (1): 17 -> 510 pairs, a wave of config 3]"""
 import os
 import sys
 import time
@@ -23,6 +24,8 @@ def main():
         R = poses[d][0] @ poses[s][0].T
         rt.append(np.r_[R.ravel(), poses[d][1] - R @ poses[s][1]])
     rt = np.array(rt)
+    rep = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    pairs, rt = pairs * rep, np.tile(rt, (rep, 1))
     K = np.mean([len(v["xy"]) for v in views])
     for P in (1, len(pairs)):
         out = eng.guided_match_batch(feats, pairs[:P], rt[:P], max_n=100, raw=True)

@@ -1,0 +1,14 @@
+# phase shares of guided_scan_flat_kernel on config 3 from features (PGI_GUIDED_PHASES=1: one line per wave on stderr)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+python3 - <<'PY'
+import sys
+sys.path.insert(0, "pose-graph-initialization_amd")
+sys.path.insert(0, "tests")
+from pyposegraphbuilder import synthetic as S
+import scene_drivers as SC
+views, poses, cam, sim, pairs = S.make_feature_scene(340, 8000, band=20)
+SC.write_feature_scene("/tmp/config3_features.bin", views, cam, sim, pairs, 512)
+PY
+for c in ${*:-16 24}; do
+  PGI_GUIDED_CAP=$c PGI_GUIDED_PHASES=1 pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out 4 2>&1 | grep "phases" | tail -n 4
+done

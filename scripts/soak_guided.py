@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak of the binned guided matcher (pgi_guided_match_batch, n_bins = 45): the tile scan with 1 / 2 / 4 lanes per source keypoint
-and the bin scan (PGI_GUIDED_ANGLE=0) against the literal restatement pgo_ref_guided_match_binned and against each other, bit
+"""Soak of the binned guided matcher (pgi_guided_match_batch, n_bins = 45): the pooled scan (list caps 20 / 16 / 4), the tile scan with 2 lanes per source
+keypoint and the bin scan (PGI_GUIDED_ANGLE=0) against the literal restatement pgo_ref_guided_match_binned and against each other, bit
 for bit, on random scenes: true / perturbed / forward-motion / tiny-baseline / random poses, three image scales, crowded
 epipolar lines (sources with > 100 candidates: several rounds).  Usage: soak_guided.py [scenes]; exits non-zero on a mismatch."""
 import os, sys, time
@@ -16,7 +16,7 @@ eng = Engine()
 rng = np.random.default_rng(777)
 t0 = time.time()
 n_src = n_match = n_frag = n_crowd = 0
-VARIANTS = (("lanes2", {"PGI_GUIDED_LANES": "2"}), ("lanes1", {"PGI_GUIDED_LANES": "1"}), ("lanes4", {"PGI_GUIDED_LANES": "4"}),
+VARIANTS = (("lanes2", {"PGI_GUIDED_LANES": "2"}), ("flat", {}), ("flat_cap4", {"PGI_GUIDED_CAP": "4"}), ("flat_cap16", {"PGI_GUIDED_CAP": "16"}),
             ("bin_scan", {"PGI_GUIDED_ANGLE": "0"}))
 for q in range(n_scenes):
     views, poses, cam = S.make_feature_views(np.random.default_rng(20000 + q), n_views=2, n_points=int(rng.integers(100, 2500)),
@@ -60,7 +60,7 @@ for q in range(n_scenes):
     keep_o = ~frag[oi].astype(bool)
     first = None
     for name, env in VARIANTS:
-        for k in ("PGI_GUIDED_LANES", "PGI_GUIDED_ANGLE"):
+        for k in ("PGI_GUIDED_LANES", "PGI_GUIDED_ANGLE", "PGI_GUIDED_CAP"):
             os.environ.pop(k, None)
         os.environ.update(env)
         for max_n in (0, 100):
@@ -78,5 +78,5 @@ for q in range(n_scenes):
                 print("MISMATCH between variants at scene", q, "kind", kind, name, "max_n", max_n)
                 sys.exit(1)
     n_src += len(views[0]["xy"]); n_match += len(oi); n_frag += int(frag.sum())
-print("guided soak: %d scenes (%d with crowded lines), %d source keypoints, %d matches, %d source keypoints in the bin-edge band: tile scan "
-      "(1 / 2 / 4 lanes) == bin scan == literal restatement (%.0f s)" % (n_scenes, n_crowd, n_src, n_match, n_frag, time.time() - t0))
+print("guided soak: %d scenes (%d with crowded lines), %d source keypoints, %d matches, %d source keypoints in the bin-edge band: pooled scan (caps 20 / 16 / 4) == tile scan "
+      "(2 lanes) == bin scan == literal restatement (%.0f s)" % (n_scenes, n_crowd, n_src, n_match, n_frag, time.time() - t0))

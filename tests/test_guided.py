@@ -203,13 +203,17 @@ def test_gpu_guided_match_binned_unusual_geometry(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["lanes1", "lanes2", "lanes4", "bin_scan"])
+@pytest.mark.parametrize("variant", ["flat", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
 def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
     """Source keypoints with far more gate-passing candidates than one pass of the tile scan lists (16 per lane): 120
     destination keypoints are moved onto the epipolar line of each of four source keypoints, so those sources are handled
     in several rounds of ascending destination index -- and `second` (the best BEFORE the last improvement, matcher.h:352-371)
     must still come out as the reference's loop over j leaves it.  Every variant of the scan against the literal restatement."""
-    if variant == "bin_scan":
+    if variant.startswith("flat"):   # the default: the pooled scan (PGI_GUIDED_CAP = candidates a source lists per round)
+        monkeypatch.delenv("PGI_GUIDED_LANES", raising=False)
+        if "cap" in variant:
+            monkeypatch.setenv("PGI_GUIDED_CAP", variant.split("cap")[1])
+    elif variant == "bin_scan":
         monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
     else:
         monkeypatch.setenv("PGI_GUIDED_LANES", variant[-1])
@@ -249,12 +253,16 @@ def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["lanes1", "lanes2", "lanes4", "bin_scan"])
+@pytest.mark.parametrize("variant", ["flat", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
 def test_gpu_guided_match_binned_degenerate_inputs(eng, variant, monkeypatch):
     """The binned mode on empty images, a zero pose (F = 0: every record is degenerate, every angle NaN, every destination
     keypoint a candidate of every source: the multi-round path on the records every source visits) and a pure-rotation pose
     (E = 0), against the literal restatement."""
-    if variant == "bin_scan":
+    if variant.startswith("flat"):   # the default: the pooled scan (PGI_GUIDED_CAP = candidates a source lists per round)
+        monkeypatch.delenv("PGI_GUIDED_LANES", raising=False)
+        if "cap" in variant:
+            monkeypatch.setenv("PGI_GUIDED_CAP", variant.split("cap")[1])
+    elif variant == "bin_scan":
         monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
     else:
         monkeypatch.setenv("PGI_GUIDED_LANES", variant[-1])
