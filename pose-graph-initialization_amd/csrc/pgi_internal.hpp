@@ -56,6 +56,9 @@ struct pgi_ctx {
         size_t bucket_bytes = 0;
         void* h_small = nullptr;  // page-locked staging of the chunk's per-pair arrays
         size_t h_small_bytes = 0;
+        void* h_io = nullptr;     // page-locked staging of the chunk's rows (in) and results (out) when the caller's buffers are pageable
+        size_t h_io_bytes = 0;
+        long pending = -1;        // chunk whose results wait in h_io for the copy into the caller's buffers
         hipStream_t stream = nullptr;
         hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
         bool used = false;

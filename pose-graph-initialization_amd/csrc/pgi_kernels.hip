@@ -1694,6 +1694,7 @@ void pgi_destroy(pgi_ctx* ctx) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
         if (ctx->hslot[k].h_small) (void)hipHostFree(ctx->hslot[k].h_small);
+        if (ctx->hslot[k].h_io) (void)hipHostFree(ctx->hslot[k].h_io);
         if (ctx->hslot[k].stream) (void)hipStreamDestroy(ctx->hslot[k].stream);
         if (ctx->hslot[k].in_done) (void)hipEventDestroy(ctx->hslot[k].in_done);
         if (ctx->hslot[k].k_done) (void)hipEventDestroy(ctx->hslot[k].k_done);
@@ -2049,6 +2050,11 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     // (results always return on the chunk's kernel stream, two launches behind the front: measured faster than an
     // immediate copy on a dedicated stream even for page-locked result buffers, 8.6 ms vs 9.0-13 ms)
     const bool pinned = pin_in;
+    // Pageable buffers never meet the device: rows and results pass through page-locked blocks the slots own (hipHostMalloc).
+    // Handing a pageable pointer to hipMemcpyAsync makes the runtime page-lock the caller's pages on the fly; in a long process
+    // (heap pages shared with other allocations, ranges registered and unregistered shortly before) that ended, now and then,
+    // in "Memory access fault by GPU" on a heap address (round 5, tests/test_gpu_parity.py after the partial-registration cases).
+    const bool pin_out = page_locked(h_edges) && page_locked(h_masks);
     if (pinned && ctx->host_direct && page_locked(h_edges) && page_locked(h_masks)) {  // work on the caller's buffers in place
         void* hp[6] = {const_cast<float*>(h_x1), const_cast<float*>(h_y1), const_cast<float*>(h_x2), const_cast<float*>(h_y2), h_edges, h_masks};
         void* dp[6] = {};
@@ -2151,6 +2157,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             HIP_TRY(hipEventCreateWithFlags(&S.out_done, hipEventDisableTiming));
         }
         S.used = false;
+        S.pending = -1;
     }
     Lay lay[kSlots];
     auto fetch = [&](size_t c) -> int {  // edge records and masks of chunk c back to the caller's buffers
@@ -2161,10 +2168,24 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         char* d = (char*)S.d;
         hipStream_t out = ctx->hslot[c & 1].stream;  // behind the chunk's own kernel
         HIP_TRY(hipStreamWaitEvent(out, S.k_done, 0));
-        HIP_TRY(hipMemcpyAsync(h_edges + p0, d + L.edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, out));
-        if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + L.masks, rows, hipMemcpyDeviceToHost, out));
+        if (pin_out) {
+            HIP_TRY(hipMemcpyAsync(h_edges + p0, d + L.edges, (size_t)np * sizeof(pgi_edge), hipMemcpyDeviceToHost, out));
+            if (rows) HIP_TRY(hipMemcpyAsync(h_masks + r0, d + L.masks, rows, hipMemcpyDeviceToHost, out));
+        } else {  // edge records and masks are neighbours on the device: one copy into the slot's block, handed over by drain()
+            HIP_TRY(hipMemcpyAsync((char*)S.h_io + (L.edges - L.x1), d + L.edges, (L.masks + rows) - L.edges, hipMemcpyDeviceToHost, out));
+            S.pending = (long)c;
+        }
         HIP_TRY(hipEventRecord(S.out_done, out));
         return PGI_SUCCESS;
+    };
+    auto drain = [&](pgi_ctx::HostSlot& S, const Lay& L) {  // (after out_done) results of the slot's chunk into the caller's buffers
+        if (S.pending < 0) return;
+        const size_t c = (size_t)S.pending;
+        const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
+        const uint64_t r0 = h_offsets[p0] - h_offsets[0], rows = h_offsets[p0 + np] - h_offsets[p0];
+        memcpy(h_edges + p0, (char*)S.h_io + (L.edges - L.x1), (size_t)np * sizeof(pgi_edge));
+        if (rows) memcpy(h_masks + r0, (char*)S.h_io + (L.masks - L.x1), rows);
+        S.pending = -1;
     };
     uint32_t max_corr_of[kSlots] = {};
     // host side of a chunk in two halves, so that the copies of chunk c + 1 are queued BEFORE the launches of chunk c
@@ -2174,7 +2195,16 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         const uint32_t p0 = cuts[c], np = cuts[c + 1] - p0;
         const uint64_t rbase = h_offsets[p0], rows = h_offsets[p0 + np] - rbase, r0 = rbase - h_offsets[0];
         const Lay L = layout(rows, np);
-        if (S.used) HIP_TRY(hipEventSynchronize(S.out_done));  // the slot's previous chunk has left the device
+        if (S.used) {
+            HIP_TRY(hipEventSynchronize(S.out_done));  // the slot's previous chunk has left the device
+            drain(S, lay[c % kSlots]);
+        }
+        if ((!pin_in || !pin_out) && L.total > S.h_io_bytes) {
+            if (S.h_io) (void)hipHostFree(S.h_io);
+            S.h_io = nullptr; S.h_io_bytes = 0;
+            HIP_TRY(hipHostMalloc(&S.h_io, L.total + L.total / 4, hipHostMallocDefault));
+            S.h_io_bytes = L.total + L.total / 4;
+        }
         if (L.total > S.bytes) {
             if (S.d) (void)hipFree(S.d);
             S.d = nullptr; S.bytes = 0;
@@ -2205,11 +2235,18 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         // pageable buffers: every copy is staged by the runtime on this thread; keep them on the slot's own stream so
         // that the copies of neighbouring chunks still overlap (one shared copy stream would serialise them)
         hipStream_t in = ctx->copy_in;
-        if (rows) {
+        if (rows && pin_in) {
             HIP_TRY(hipMemcpyAsync(d + L.x1, h_x1 + r0, rows * 4, hipMemcpyHostToDevice, in));
             HIP_TRY(hipMemcpyAsync(d + L.y1, h_y1 + r0, rows * 4, hipMemcpyHostToDevice, in));
             HIP_TRY(hipMemcpyAsync(d + L.x2, h_x2 + r0, rows * 4, hipMemcpyHostToDevice, in));
             HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, in));
+        } else if (rows) {  // pageable: the four arrays into the slot's block in the device layout, one copy
+            char* io = (char*)S.h_io;
+            memcpy(io + (L.x1 - L.x1), h_x1 + r0, rows * 4);
+            memcpy(io + (L.y1 - L.x1), h_y1 + r0, rows * 4);
+            memcpy(io + (L.x2 - L.x1), h_x2 + r0, rows * 4);
+            memcpy(io + (L.y2 - L.x1), h_y2 + r0, rows * 4);
+            HIP_TRY(hipMemcpyAsync(d + L.x1, io, (L.y2 + rows * 4) - L.x1, hipMemcpyHostToDevice, in));
         }
         HIP_TRY(hipMemcpyAsync(d + L.off, hs, guesses ? small_bytes : (L.thr + (size_t)np * 8) - L.off, hipMemcpyHostToDevice, in));
         HIP_TRY(hipEventRecord(S.in_done, in));
@@ -2260,7 +2297,10 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         if (rc2 < 0) return rc2;
     }
     for (size_t k = 0; k < kSlots; ++k)
-        if (ctx->hslot[k].used) HIP_TRY(hipEventSynchronize(ctx->hslot[k].out_done));
+        if (ctx->hslot[k].used) {
+            HIP_TRY(hipEventSynchronize(ctx->hslot[k].out_done));
+            drain(ctx->hslot[k], lay[k]);
+        }
     return PGI_SUCCESS;
 }
 
