@@ -30,7 +30,7 @@ out = {"kernel": K.replace(", fals", ", false>") + " (config 3 from features: 34
        "achieved_GBs": round((fetch_b + write_b) / (avg_us * 1e-6) / 1e9, 1), "frac_hbm": round((fetch_b + write_b) / (avg_us * 1e-6) / 8e12, 4),
        "valu_issue_busy_frac": round(c["SQ_INSTS_VALU"] * 4 / (avg_us * 1e-6 * 2.4e9 * 1024), 3) if "SQ_INSTS_VALU" in c else None,
        "wave_waiting_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if "SQ_WAVE_CYCLES" in c else None,
-       "lane_utilisation": None, "vgprs": 256, "spilled_vgprs": 4 if "tile" in K else 0,
+       "lane_utilisation": None, "vgprs": 256 if "tile" in K else 249, "spilled_vgprs": 4 if "tile" in K else 0,
        "correction": "FETCH_SIZE x2 on gfx950 (64 B tallied per 128-B request); WRITE_SIZE as reported",
        "counters_per_launch": {k: v for k, v in sorted(c.items())}}
 # ~506 image pairs per launch on this workload: 2 x 8000 descriptors x 512 B + 8000 x 48 B records per pair
