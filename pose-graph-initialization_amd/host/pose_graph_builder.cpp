@@ -303,6 +303,8 @@ struct PoseGraphBuilder::Staging {
     struct Release { uint32_t* word; uint32_t value; };
     std::vector<Release> releases;
     std::unique_ptr<HostPool> pool;
+    std::unique_ptr<HostPool> commitPool;  // the team that writes a wave's edges into the pose graph (its own: the scheduler's helper
+                                           // thread converts the NEXT wave's rows on `pool` at that very time)
     std::mutex busy;  // one estimatePoses at a time per process
     // processFeatures (round 5): the feature arena (every view's keypoints, descriptors and prepared copies: 3.5 GB at config
     // 3's size) and the waves' device pool are LENT to one run at a time and never released -- a fresh hipMalloc of the arena
@@ -345,6 +347,7 @@ struct PoseGraphBuilder::Staging {
         if (!preDone && hipEventCreateWithFlags(&preDone, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
         if (!readyWord && hipHostMalloc((void**)&readyWord, 256, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
         if (!pool || pool->size() < std::min<size_t>(threads, std::max(1u, std::thread::hardware_concurrency()))) pool.reset(new HostPool(threads));
+        if (!commitPool) commitPool.reset(new HostPool(std::min<size_t>(8, std::max<size_t>(1, threads))));
     }
     static void growHost(void*& p, size_t& have, size_t want) {
         if (want <= have) return;
@@ -704,7 +707,8 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     size_t added = 0, inliers = 0;
     for (size_t i = 0; i < P; ++i) inliers += edges[i].n_inl;
     // the edges in pair order (pose_graph_builder.h:645-654; a failed pair is skipped, :641-642), one locked batch
-    auto insertAll = [&pairs, &poseGraph_, P](const std::vector<pgi_edge>& e) {
+    HostPool* team = staging->commitPool.get();
+    auto insertAll = [&pairs, &poseGraph_, P, team](const std::vector<pgi_edge>& e) {
         std::vector<PoseGraph::NewEdge> items;
         items.reserve(P);
         for (size_t i = 0; i < P; ++i) {
@@ -712,7 +716,11 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             items.push_back(PoseGraph::NewEdge{pairs[i].src, pairs[i].dst, (double)e[i].n_inl / (double)std::max(1, pairs[i].correspondences.rows),
                                                e[i].R, e[i].t});
         }
-        poseGraph_.addEdges(items.data(), items.size());
+        // (the records and adjacency lists of a wave are written by the host team: 260 -> ~80 ns per edge at 10^4 edges per wave)
+        static const bool serial = [] { const char* e = std::getenv("PGI_COMMIT_TEAM"); return e && std::atoi(e) == 0; }();
+        if (serial) poseGraph_.addEdges(items.data(), items.size());
+        else poseGraph_.addEdges(items.data(), items.size(), team->size(),
+                                 [team](size_t parts, const std::function<void(size_t)>& fn) { team->run(parts, fn); });
         return items.size();
     };
     if (deferredInsertion && edges_out) {
@@ -868,8 +876,19 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
             }
         }
     }
-    std::vector<uint32_t> order(cand.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = keys[i].index;
+    // what wave formation reads of a candidate, in heap order: the formation streams through this array and never touches the
+    // candidate records (10^5 cache misses on the 100-byte records were two thirds of its 13 ms; gathered here by the team)
+    struct Ordered { ViewId src, dst; double similarity, normalizedThreshold; const double* rows; int count; };
+    std::vector<Ordered> ordered(cand.size());
+    {
+        const size_t n = ordered.size(), parts = n >= 32768 ? std::min<size_t>(8, std::max<size_t>(1, kCoreNumber)) : 1;
+        parallelFor(parts, parts, [&](size_t t) {
+            for (size_t i = n * t / parts; i < n * (t + 1) / parts; ++i) {
+                const ViewPair& vp = cand[keys[i].index];
+                ordered[i] = Ordered{vp.src, vp.dst, vp.similarity, vp.normalizedThreshold, vp.correspondences.ptr(), vp.correspondences.rows};
+            }
+        });
+    }
     std::vector<OrderKey>().swap(keys);
     statistics.addTime("[Scheduler] candidate order", std::chrono::duration<double>(Clock::now() - tSort).count(), 1);
     ViewId maxId = 0;
@@ -980,11 +999,10 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
         while (cursor < cand.size() && wave.size() < waveSize) {
             pick.clear(); pickSrc.clear(); pickDst.clear();
             for (; cursor < cand.size() && wave.size() + pick.size() < waveSize; ++cursor) {
-                if (cursor + 8 < cand.size()) __builtin_prefetch(&cand[order[cursor + 8]]);
-                const ViewPair& vp = cand[order[cursor]];
+                const Ordered& vp = ordered[cursor];
                 if (vp.similarity < kSimilarityThreshold) { cursor = cand.size(); break; }  // heap holds sim >= threshold only
-                if ((size_t)vp.correspondences.rows < kMinimumPointNumber) continue;   // :550-551
-                pick.push_back(order[cursor]);
+                if ((size_t)vp.count < kMinimumPointNumber) continue;   // :550-551
+                pick.push_back((uint32_t)cursor);
                 pickSrc.push_back(vp.src);
                 pickDst.push_back(vp.dst);
             }
@@ -992,7 +1010,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
             poseGraph_.admitPairs(pickSrc.data(), pickDst.data(), pick.size(), admit.data());   // :426-431 + addVertex x 2
             for (size_t k = 0; k < pick.size(); ++k) {
                 if (!admit[k]) continue;
-                const ViewPair& vp = cand[pick[k]];
+                const Ordered& vp = ordered[pick[k]];
                 // the wave holds HEADERS over the candidates' matrices (cv::Mat semantics): the rows stay where the caller put them and
                 // are released when the caller releases its list -- a wave that owned them paid for unmapping 2.4 GB of matrices inside
                 // the run (0.09 s of a 0.25 s run at 10^5 pairs)
@@ -1001,7 +1019,7 @@ PoseGraphBuilder::RunStatistics PoseGraphBuilder::run(std::vector<ViewPair>& can
                 header.dst = vp.dst;
                 header.similarity = vp.similarity;
                 header.normalizedThreshold = vp.normalizedThreshold;
-                header.correspondences = CorrespondenceMatrix::viewOf(vp.correspondences.ptr(), vp.correspondences.rows);
+                header.correspondences = CorrespondenceMatrix::viewOf(vp.rows, vp.count);
                 wave.push_back(std::move(header));
             }
         }

@@ -20,13 +20,17 @@
 #include <cmath>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <shared_mutex>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -168,6 +172,47 @@ class PoseGraphEdge {  // include/pose_graph.h:28-60; score = inlier ratio (pose
     Pose T_dst_src;
 };
 
+// The edge records of a PoseGraph: one array in insertion order that grows WITHOUT constructing its new tail -- addEdges' team
+// writes the records of a wave concurrently (round 5), each thread touching its part of the fresh pages first.
+class EdgeArray {
+   public:
+    EdgeArray() = default;
+    EdgeArray(const EdgeArray&) = delete;
+    EdgeArray& operator=(const EdgeArray&) = delete;
+    ~EdgeArray() { std::free(p_); }
+    size_t size() const { return n_; }
+    size_t capacity() const { return cap_; }
+    void reserve(size_t cap) {
+        static_assert(std::is_trivially_copyable<PoseGraphEdge>::value && std::is_trivially_destructible<PoseGraphEdge>::value,
+                      "the records move with memcpy and are never destroyed one by one");
+        if (cap <= cap_) return;
+        PoseGraphEdge* q = static_cast<PoseGraphEdge*>(std::malloc(cap * sizeof(PoseGraphEdge)));
+        if (!q) throw std::bad_alloc();
+        if (n_) std::memcpy(static_cast<void*>(q), static_cast<const void*>(p_), n_ * sizeof(PoseGraphEdge));
+        std::free(p_);
+        p_ = q;
+        cap_ = cap;
+    }
+    PoseGraphEdge& operator[](size_t k) { return p_[k]; }
+    const PoseGraphEdge& operator[](size_t k) const { return p_[k]; }
+    template <class... A>
+    void emplace_back(A&&... a) {
+        if (n_ == cap_) reserve(std::max<size_t>(16, 2 * cap_));
+        new (p_ + n_++) PoseGraphEdge(std::forward<A>(a)...);
+    }
+    // m more records whose storage the caller constructs (every one of them, before anyone reads); returns the first
+    PoseGraphEdge* extend(size_t m) {
+        if (n_ + m > cap_) reserve(std::max(n_ + m, 2 * cap_));
+        PoseGraphEdge* first = p_ + n_;
+        n_ += m;
+        return first;
+    }
+
+   private:
+    PoseGraphEdge* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing ids)
    public:
     // Storage (round 4): the edges live in ONE array in insertion order; the id -> edge and vertex -> edges relations are
@@ -218,6 +263,10 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     void admitPairs(const ViewId* s, const ViewId* d, size_t n, uint8_t* admit) {
         std::unique_lock<std::shared_mutex> l(mu);
         for (size_t i = 0; i < n; ++i) {
+            if (i + 8 < n) {  // (the two probes of a pair start in unrelated lines of a table of 10^5 keys)
+                edge_index.prefetch({s[i + 8], d[i + 8]});
+                edge_index.prefetch({d[i + 8], s[i + 8]});
+            }
             admit[i] = (edge_index.count({s[i], d[i]}) != 0 || edge_index.count({d[i], s[i]}) != 0) ? 0 : 1;
             if (!admit[i]) continue;
             for (const ViewId id : {s[i], d[i]}) {
@@ -305,6 +354,69 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
             neighboursForUpdate(d).push_back(Neighbour{s, items[i].score, k});
             ++added;
         }
+        return added;
+    }
+    // The same with a team (round 5): `team(parts, fn)` runs fn(0) .. fn(parts - 1) concurrently and returns when all are done.
+    // Which items become edges, and their positions, is decided serially (the id index: first occurrence wins, as above); the
+    // 208-byte records and the adjacency entries -- the cache misses and the first touch of fresh pages -- are written by the
+    // team: part p writes the records of its slice of the items and the lists of its vertices (blocks of 64 ids dealt round
+    // robin: neighbouring list headers share cache lines), scanning the items in order, so every list has the order the serial insertion gives it.
+    template <class Team>
+    size_t addEdges(const NewEdge* items, size_t n, size_t parts, Team&& team) {
+        if (parts <= 1 || n < 1024) return addEdges(items, n);
+        std::unique_lock<std::shared_mutex> l(mu);
+        const size_t want = edge_store.size() + n;
+        if (want > edge_store.capacity()) edge_store.reserve(std::max(want, 2 * edge_store.capacity()));
+        edge_index.reserve(want);
+        degree_scratch.clear();
+        for (size_t i = 0; i < n; ++i)
+            for (ViewId v : {items[i].src, items[i].dst})
+                if (v < kDenseIds) {
+                    if (v >= degree_scratch.size()) degree_scratch.resize(std::max<size_t>(v + 1, 2 * degree_scratch.size()), 0);
+                    ++degree_scratch[v];
+                }
+        if (degree_scratch.size() > adjacency_dense.size()) adjacency_dense.resize(degree_scratch.size());
+        slot_scratch.resize(n);
+        const uint32_t base = (uint32_t)edge_store.size();
+        uint32_t added = 0;
+        bool sparse = false;
+        for (size_t i = 0; i < n; ++i) {
+            const ViewId s = items[i].src, d = items[i].dst;
+            slot_scratch[i] = EdgeIndex::npos;
+            if (!hasVertexUnlocked(s) || !hasVertexUnlocked(d)) continue;
+            if (!edge_index.insert(EdgeId{s, d}, base + added)) continue;
+            slot_scratch[i] = base + added++;
+            sparse = sparse || s >= kDenseIds || d >= kDenseIds;
+        }
+        PoseGraphEdge* fresh = edge_store.extend(added) - base;  // fresh[k] is record k
+        const uint32_t* slot = slot_scratch.data();
+        team(parts, [&](size_t p) {
+            for (size_t v = 0; v < degree_scratch.size(); ++v)
+                if (degree_scratch[v] && (v >> 6) % parts == p) {
+                    std::vector<Neighbour>& nb = adjacency_dense[v];
+                    if (nb.size() + degree_scratch[v] > nb.capacity()) nb.reserve(std::max<size_t>(nb.size() + degree_scratch[v], 2 * nb.capacity()));
+                }
+            for (size_t i = n * p / parts; i < n * (p + 1) / parts; ++i) {
+                if (slot[i] == EdgeIndex::npos) continue;
+                SE3d T;
+                for (int c = 0; c < 9; ++c) T.R[c] = items[i].R[c];
+                for (int c = 0; c < 3; ++c) T.t[c] = items[i].t[c];
+                new (fresh + slot[i]) PoseGraphEdge(items[i].src, items[i].dst, Pose(T), items[i].score);
+            }
+            for (size_t i = 0; i < n; ++i) {
+                if (slot[i] == EdgeIndex::npos) continue;
+                const ViewId s = items[i].src, d = items[i].dst;
+                if (s < kDenseIds && (s >> 6) % parts == p) adjacency_dense[s].push_back(Neighbour{d, items[i].score, slot[i]});
+                if (d < kDenseIds && (d >> 6) % parts == p) adjacency_dense[d].push_back(Neighbour{s, items[i].score, slot[i]});
+            }
+        });
+        if (sparse)
+            for (size_t i = 0; i < n; ++i) {
+                if (slot[i] == EdgeIndex::npos) continue;
+                const ViewId s = items[i].src, d = items[i].dst;
+                if (s >= kDenseIds) adjacency_sparse[s].push_back(Neighbour{d, items[i].score, slot[i]});
+                if (d >= kDenseIds) adjacency_sparse[d].push_back(Neighbour{s, items[i].score, slot[i]});
+            }
         return added;
     }
     // room for n more edges (one rehash instead of a dozen while a wave of 10^4 edges is committed)
@@ -400,7 +512,7 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     size_t vertex_count = 0;
     std::vector<uint8_t> vertex_dense;
     std::unordered_map<ViewId, PoseGraphVertex> vertex_sparse;
-    std::vector<PoseGraphEdge> edge_store;                         // insertion order
+    EdgeArray edge_store;                                          // insertion order
     // (src, dst) -> position in edge_store.  Ids below 2^32 (every real case) live in an open-addressing table of packed
     // 64-bit keys -- no node allocation per edge, one probe sequence in one array; anything larger in a std hash map.
     class EdgeIndex {
@@ -419,6 +531,9 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
             }
         }
         size_t count(const EdgeId& id) const { return find(id) != npos; }
+        void prefetch(const EdgeId& id) const {
+            if (!keys.empty() && !inBig(id)) __builtin_prefetch(&keys[slot(pack(id))]);
+        }
         bool insert(const EdgeId& id, uint32_t v) {  // false if the id is already there
             if (inBig(id)) return big.emplace(id, v).second;
             if ((used + 1) * 2 > keys.size()) grow(std::max<size_t>(64, 2 * keys.size()));
@@ -472,6 +587,7 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     EdgeIndex edge_index;
     std::vector<std::vector<Neighbour>> adjacency_dense;           // per vertex, insertion order
     std::vector<uint32_t> degree_scratch;                          // addEdges: new edges per vertex of the wave
+    std::vector<uint32_t> slot_scratch;                            // addEdges with a team: the position each item's edge takes
     std::unordered_map<ViewId, std::vector<Neighbour>> adjacency_sparse;
 };
 

@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <random>
+#include <thread>
 #include "pose_graph_builder.hpp"
 using namespace reconstruction;
 int main() {
@@ -24,5 +25,35 @@ int main() {
         for (size_t w = 0; w < W; ++w) added += g.addEdges(items.data() + w * (E / W), E / W);
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("rep %d: %zu edges in %.4f s = %.0f ns per edge\n", rep, added, s, 1e9 * s / added);
+    }
+    // the same with a team of 8 (threads started per call here; the builder keeps a pool), and the graph compared with the serial one
+    auto team = [](size_t parts, const std::function<void(size_t)>& fn) {
+        std::vector<std::thread> th;
+        for (size_t p = 1; p < parts; ++p) th.emplace_back(fn, p);
+        fn(0);
+        for (std::thread& t : th) t.join();
+    };
+    PoseGraph ref;
+    for (size_t v = 0; v < V; ++v) ref.addVertex(v);
+    ref.reserveEdges(E);
+    for (size_t w = 0; w < W; ++w) ref.addEdges(items.data() + w * (E / W), E / W);
+    for (int rep = 0; rep < 3; ++rep) {
+        PoseGraph g;
+        for (size_t v = 0; v < V; ++v) g.addVertex(v);
+        g.reserveEdges(E);
+        auto t0 = std::chrono::steady_clock::now();
+        size_t added = 0;
+        for (size_t w = 0; w < W; ++w) added += g.addEdges(items.data() + w * (E / W), E / W, (size_t)(getenv("PARTS") ? atoi(getenv("PARTS")) : 8), team);
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        bool same = g.getEdgeIds() == ref.getEdgeIds();
+        for (size_t v = 0; v < V && same; ++v) {
+            std::vector<EdgeId> a, b;
+            same = g.getEdgesByVertex(v, a) == ref.getEdgesByVertex(v, b) && a == b;
+        }
+        for (const EdgeId& id : ref.getEdgeIds()) {
+            const PoseGraphEdge x = g.getEdgeById(id), y = ref.getEdgeById(id);
+            same = same && std::memcmp(&x, &y, sizeof x) == 0;
+        }
+        std::printf("team of 8, rep %d: %zu edges in %.4f s = %.0f ns per edge; the serial graph: %s\n", rep, added, s, 1e9 * s / added, same ? "equal" : "DIFFERENT");
     }
 }
