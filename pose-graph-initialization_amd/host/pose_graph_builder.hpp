@@ -362,8 +362,8 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
     // team: part p writes the records of its slice of the items and the lists of its vertices (blocks of 64 ids dealt round
     // robin: neighbouring list headers share cache lines), scanning the items in order, so every list has the order the serial insertion gives it.
     template <class Team>
-    size_t addEdges(const NewEdge* items, size_t n, size_t parts, Team&& team) {
-        if (parts <= 1 || n < 1024) return addEdges(items, n);
+    size_t addEdges(const NewEdge* items, size_t n, size_t parts, Team&& team, size_t serialBelow = 1024) {
+        if (parts <= 1 || n < serialBelow) return addEdges(items, n);
         std::unique_lock<std::shared_mutex> l(mu);
         const size_t want = edge_store.size() + n;
         if (want > edge_store.capacity()) edge_store.reserve(std::max(want, 2 * edge_store.capacity()));

@@ -181,6 +181,22 @@ static int graphops(char** argv) {
             }
             for (size_t i = 0; i < n; ++i) { items[i].R = poses[i].R.data(); items[i].t = poses[i].t.data(); }
             out << g.addEdges(items.data(), n) << "\n";
+        } else if (op == "T") {  // the same batch through the team overload (three parts, started here as threads)
+            size_t n; in >> n;
+            std::vector<PoseGraph::NewEdge> items(n);
+            std::vector<SE3d> poses(n);
+            for (size_t i = 0; i < n; ++i) {
+                in >> items[i].src >> items[i].dst >> items[i].score;
+                poses[i] = poseOf(items[i].score);
+            }
+            for (size_t i = 0; i < n; ++i) { items[i].R = poses[i].R.data(); items[i].t = poses[i].t.data(); }
+            auto team = [](size_t parts, const std::function<void(size_t)>& fn) {
+                std::vector<std::thread> th;
+                for (size_t p = 1; p < parts; ++p) th.emplace_back(fn, p);
+                fn(0);
+                for (std::thread& t : th) t.join();
+            };
+            out << g.addEdges(items.data(), n, 3, team, 0) << "\n";
         } else if (op == "A") {  // admitPairs: n, then n x (src dst) -> the admit flags and the vertex count afterwards
             size_t n; in >> n;
             std::vector<ViewId> s(n), d(n);

@@ -18,6 +18,7 @@ EDGE = st.tuples(IDS, IDS, SCORE)
 OP = st.one_of(st.tuples(st.just("V"), IDS), st.tuples(st.just("P"), IDS, IDS), st.tuples(st.just("E"), EDGE),
                st.tuples(st.just("B"), st.lists(EDGE, min_size=0, max_size=12)), st.tuples(st.just("H"), IDS, IDS),
                st.tuples(st.just("G"), IDS, IDS), st.tuples(st.just("N"), IDS), st.tuples(st.just("I")),
+               st.tuples(st.just("T"), st.lists(EDGE, min_size=0, max_size=12)),
                st.tuples(st.just("A"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)),
                st.tuples(st.just("Y"), st.lists(st.tuples(IDS, IDS), min_size=0, max_size=10)))
 
@@ -46,7 +47,7 @@ class Model:
             return str(len(self.vertices))
         if k == "E":
             return "1" if self.add_edge(*op[1]) else "0"
-        if k == "B":
+        if k in ("B", "T"):   # T: PoseGraph::addEdges with a team -- the same graph as the serial batch
             return str(sum(1 for e in op[1] if self.add_edge(*e)))
         if k == "A":   # PoseGraph::admitPairs: not an edge yet in either direction -> admitted, both vertices added
             flags = []
@@ -82,8 +83,8 @@ def script(ops):
     for op in ops:
         if op[0] == "E":
             lines.append("E %d %d %r" % op[1])
-        elif op[0] == "B":
-            lines.append("B %d" % len(op[1]))
+        elif op[0] in ("B", "T"):
+            lines.append("%s %d" % (op[0], len(op[1])))
             lines += ["%d %d %r" % e for e in op[1]]
         elif op[0] in ("A", "Y"):
             lines.append("%s %d" % (op[0], len(op[1])))
