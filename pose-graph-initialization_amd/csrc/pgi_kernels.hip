@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -2242,10 +2243,16 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
             HIP_TRY(hipMemcpyAsync(d + L.y2, h_y2 + r0, rows * 4, hipMemcpyHostToDevice, in));
         } else if (rows) {  // pageable: the four arrays into the slot's block in the device layout, one copy
             char* io = (char*)S.h_io;
-            memcpy(io + (L.x1 - L.x1), h_x1 + r0, rows * 4);
-            memcpy(io + (L.y1 - L.x1), h_y1 + r0, rows * 4);
-            memcpy(io + (L.x2 - L.x1), h_x2 + r0, rows * 4);
-            memcpy(io + (L.y2 - L.x1), h_y2 + r0, rows * 4);
+            const float* from[4] = {h_x1 + r0, h_y1 + r0, h_x2 + r0, h_y2 + r0};
+            const size_t at[4] = {0, L.y1 - L.x1, L.x2 - L.x1, L.y2 - L.x1};
+            if (rows * 4 >= ((size_t)1 << 20)) {  // four arrays, four threads: one thread copies at ~10 GB/s, a chunk holds 16 MB
+                std::thread helpers[3];
+                for (int k = 1; k < 4; ++k) helpers[k - 1] = std::thread([=] { memcpy(io + at[k], from[k], rows * 4); });
+                memcpy(io + at[0], from[0], rows * 4);
+                for (std::thread& th : helpers) th.join();
+            } else {
+                for (int k = 0; k < 4; ++k) memcpy(io + at[k], from[k], rows * 4);
+            }
             HIP_TRY(hipMemcpyAsync(d + L.x1, io, (L.y2 + rows * 4) - L.x1, hipMemcpyHostToDevice, in));
         }
         HIP_TRY(hipMemcpyAsync(d + L.off, hs, guesses ? small_bytes : (L.thr + (size_t)np * 8) - L.off, hipMemcpyHostToDevice, in));
