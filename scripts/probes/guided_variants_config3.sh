@@ -15,7 +15,7 @@ for v in ${*:-PGI_GUIDED_LANES=2 PGI_GUIDED_CAP=16 PGI_GUIDED_CAP=20}; do
   rm -rf gpurun_out/v3
   rocprofv3 --kernel-trace -d gpurun_out/v3 -o v -- pose-graph-initialization_amd/test_pipeline /tmp/config3_features.bin /tmp/config3_features.out 4 > gpurun_out/v3.log 2>&1
   echo "== $v: $(grep -i "seconds\|run " gpurun_out/v3.log | tail -n 1 | cut -c1-150)"
-  python3 scripts/rocpd_summary.py $(find gpurun_out/v3 -name "*.db" | head -1) 2>&1 | grep "guided_scan\|guided_angle" | cut -c1-130
+  python3 scripts/rocpd_summary.py $(find gpurun_out/v3 -name "*.db" | head -1) 2>&1 | grep "guided_scan\|guided_angle\|guided_gate\|guided_sums" | cut -c1-130
   rm -rf gpurun_out/v3
   unset PGI_GUIDED_LANES PGI_GUIDED_CAP
 done
