@@ -821,15 +821,21 @@ PoseGraphBuilder::GlobalRotations PoseGraphBuilder::averageRotations(const PoseG
     GlobalRotations out;
     out.rotations.assign(numViews, Matrix3d{{1, 0, 0, 0, 1, 0, 0, 0, 1}});
     if (!numViews) return out;
-    std::vector<pgi_rot_edge> re;
-    for (const EdgeId& id : poseGraph_.getEdgeIds()) {
-        const PoseGraphEdge e = poseGraph_.getEdgeById(id);
-        pgi_rot_edge r{};
-        r.src = (uint32_t)id.first;
-        r.dst = (uint32_t)id.second;
-        for (int c = 0; c < 9; ++c) r.R[c] = e.getValue().getRotation()[c];
-        r.weight = e.getScore();
-        re.push_back(r);
+    // the edge list in insertion order, gathered straight from the graph's record array by the host team (an id list plus a
+    // locked look-up and a 208-byte copy per edge took 6 ms of the 15 at 10^5 edges)
+    std::vector<pgi_rot_edge> re(poseGraph_.numEdges());
+    {
+        const size_t E = re.size(), parts = E >= 16384 ? std::min<size_t>(8, std::max<size_t>(1, kCoreNumber)) : 1;
+        parallelFor(parts, parts, [&](size_t t) {
+            poseGraph_.forEachEdge(E * t / parts, E * (t + 1) / parts, [&](size_t k, const PoseGraphEdge& e) {
+                pgi_rot_edge r{};
+                r.src = (uint32_t)e.getSourceId();
+                r.dst = (uint32_t)e.getDestinationId();
+                for (int c = 0; c < 9; ++c) r.R[c] = e.getValue().getRotation()[c];
+                r.weight = e.getScore();
+                re[k] = r;
+            });
+        });
     }
     out.edgesUsed = (uint32_t)re.size();
     Engine::check(pgi_rotation_average(engine->get(), re.data(), (uint32_t)re.size(), (uint32_t)numViews, rotavgParams,

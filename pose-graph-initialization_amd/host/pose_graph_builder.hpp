@@ -431,6 +431,12 @@ class PoseGraph {  // include/pose_graph.h:62-226 (value semantics for missing i
         const uint32_t k = edge_index.find(id);
         return k == EdgeIndex::npos ? PoseGraphEdge() : edge_store[k];
     }
+    // the edges first .. last - 1 in insertion order, by reference and under ONE shared lock: fn(position, edge)
+    template <class Fn>
+    void forEachEdge(size_t first, size_t last, Fn fn) const {
+        std::shared_lock<std::shared_mutex> l(mu);
+        for (size_t k = first; k < std::min(last, edge_store.size()); ++k) fn(k, edge_store[k]);
+    }
     std::vector<EdgeId> getEdgeIds() const {  // insertion order, like the reference's edges_ids
         std::shared_lock<std::shared_mutex> l(mu);
         std::vector<EdgeId> ids(edge_store.size());
