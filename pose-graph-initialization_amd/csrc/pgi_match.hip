@@ -738,13 +738,19 @@ struct GuidedPair {
 constexpr int kGmMaxBuckets = 64;  // bins the bucketed scan handles (the reference uses 45); more -> the tiled scan below
 constexpr double kRadianToDegree = 180.0 / 3.14159265358979323846;
 // matcher.h:292-301 / :318-324: angle of a line normal -> bin index
-__device__ __forceinline__ int32_t epipolar_bin(double ny, double nx, double min_angle, double range, int32_t bins) {
+__device__ __forceinline__ double epipolar_angle(double ny, double nx) {  // the folded angle, (0, 180]
     double angle = kRadianToDegree * atan2(ny, nx) + 180.0;
     if (angle > 180) angle -= 180;
+    return angle;
+}
+__device__ __forceinline__ int32_t epipolar_bin_of(double angle, double min_angle, double range, int32_t bins) {
     angle = (double)(bins - 1) * (angle - min_angle) / range;
     const double r = round(angle);
     int32_t b = (r >= 2147483647.0) ? 2147483647 : (r > -2147483648.0 ? (int32_t)r : (int32_t)(-2147483647 - 1));  // NaN -> INT_MIN like x86
     return b < 0 ? 0 : (b > bins - 1 ? bins - 1 : b);
+}
+__device__ __forceinline__ int32_t epipolar_bin(double ny, double nx, double min_angle, double range, int32_t bins) {
+    return epipolar_bin_of(epipolar_angle(ny, nx), min_angle, range, bins);
 }
 constexpr int kGmTile = 512;  // destination keypoints whose epipolar-line records are staged per step
 constexpr int kGmList = 32;   // candidates a thread collects before the wavefront evaluates their descriptors
@@ -1585,7 +1591,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
     const double b1 = rx * rx + ry * ry;
     const double vx = x1 - P.ep0, vy = y1 - P.ep1;
-    const int32_t my_bin = epipolar_bin(vx, -vy, P.min_angle, P.range, P.bins);
+    // (the folded angle of the source's epipolar line is both what its bin is cut from and the centre of its gate window:
+    //  atan2(vx, -vy) = atan2(vy, vx) + a quarter turn, which ga_source_centre adds back -- one arc tangent instead of two)
+    const double my_angle = epipolar_angle(vx, -vy);
+    const int32_t my_bin = epipolar_bin_of(my_angle, P.min_angle, P.range, P.bins);
     const uint32_t* st = starts + (size_t)pair_id * (kGaBuckets + 2);
     const double amin = spans[2 * (size_t)pair_id], amax = spans[2 * (size_t)pair_id + 1];
     // the fine buckets of this source's bin and of its gate window, as in guided_scan_tile_kernel
@@ -1603,8 +1612,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int g0[2] = {0, 0}, g1[2] = {kGaBuckets - 1, -1};
     const double d2 = vx * vx + vy * vy;
     if (d2 > 4.0 && d2 < 1.0e300 && b1 > 0.0 && b1 < 1.0e300) {
-        const double c = ga_source_centre(vx, vy);
-        const double half = kRadianToDegree * asin(0.75 / sqrt(d2)) * 1.0001 + 1.0e-5;
+        const double c = my_angle >= 180.0 ? my_angle - 180.0 : my_angle;  // [0, 180)
+        // asin(x) <= x + 0.18 x^3 on x <= 0.375 (d2 > 4): a bound is all the window needs (the exact gate decides)
+        const double xs = 0.75 / sqrt(d2);
+        const double half = kRadianToDegree * (xs + 0.18 * xs * xs * xs) * 1.0001 + 1.0e-5;
         if (2.0 * half < 179.0) {
             double lo[2] = {c - half, 0.0}, hi[2] = {c + half, -1.0};
             if (lo[0] <= 0.0) { lo[1] = lo[0] + 180.0; hi[1] = 180.0; lo[0] = 0.0; }
