@@ -1550,11 +1550,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {  // every l
 }
 // PGI_GUIDED_PHASES=1 (diagnostics): PH counts the clock ticks a wavefront spends per phase into g_guided_phase
 __device__ unsigned long long g_guided_phase[8];
-template <int C, bool PH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_scan_flat_kernel(
+// The scan as two kernels (the default since r05; PGI_GUIDED_SPLIT=0 keeps it in one).  What a wavefront's sums need is a LIST: per round the tiles (first record,
+// items) and the items themselves.  MODE 1 of the body below produces exactly that and nothing else -- window arithmetic, gate
+// pass, dealing; no descriptor in registers, no distances: 67 registers, 15 KB of LDS, twelve wavefronts per CU for the part of
+// the scan that mostly waits -- into blocks of a device arena, one block per round, chained:
+//     [0] tiles  [1] items  [2] next block (word offset + 1, 0: none)  [3] unused
+//     [4 .. 67]  candidates listed per source, [68 .. 95] unused (the rows below start on a 128-byte line, as every block does)
+//     then C x 64 destination indices as u16 (row c = every source's c-th listed candidate),
+//     then kDealTiles x {first record, items}, then the items in tile order.
+// guided_sum_kernel walks the chain with the source descriptors in registers: stage rows, sum, pick.  A wavefront whose
+// lists do not fit (more than kDealTiles tiles in a round, arena full) raises its flag, is skipped by the sum kernel and
+// redone by MODE 2 = MODE 0 for flagged wavefronts only.
+constexpr uint32_t kDealTiles = 64, kDealArenas = 64, kDealHead = 96;
+constexpr int kSplitCap = 24;  // candidates a source lists per round in the two-kernel form (20: 1023 + 1883 us per 512 pairs, 24: 832 + 1863,
+                                // 28: 748 + 1964, 32: 787 + 1985 -- the deal kernel has fewer later rounds, the sum kernel fewer wavefronts per CU)
+struct DealOut {
+    uint32_t* words;       // the arena: kDealArenas parts of part_words each
+    uint32_t* heads;       // words taken per part
+    uint32_t* first;       // per wavefront: its first block (word offset into `words` + 1; 0: none)
+    uint32_t* flags;       // per wavefront: 1 = redo in one kernel
+    uint32_t part_words;
+};
+template <int C, bool PH, int MODE>
+__device__ __forceinline__ void guided_scan_flat_body(
     const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
     const double* __restrict__ spans, const uint32_t* __restrict__ order, int32_t* __restrict__ best_out, double* __restrict__ ratio_out,
-    uint32_t blocks_per_pair, uint32_t n_blocks) {
+    uint32_t blocks_per_pair, uint32_t n_blocks, const DealOut out) {
     static_assert(C >= 2 && C <= 32, "a candidate's place in the list is five bits of an item");
     static_assert(kGtRows == 16, "sixteen rows in flight per pass; a row number is four bits of an item");
     constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -1570,6 +1591,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const GuidedPair P = pairs[pair_id];
     const uint32_t lane = threadIdx.x;
     if (bx * 64u >= P.n1) return;      // (wavefront-uniform; in a live wavefront every lane stays for the shared steps)
+    if (MODE == 2 && out.flags[logical] == 0u) return;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ph = PH ? __builtin_amdgcn_s_memtime() : 0ull;
     auto tick = [&](int k) {
         if (PH) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph[k] += now - t_ph; t_ph = now; }
@@ -1578,7 +1600,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t i = active ? order[P.off + bx * 64u + lane] : 0u;
     // (1)
     float a[kD];
-    {
+    if (MODE != 1) {
         const float4* row = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
 #pragma unroll
         for (int q = 0; q < kD / 4; ++q) {
@@ -1723,6 +1745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     uint32_t count = 0;
     int64_t after = -1;
     bool more = true;
+    uint32_t* deal_prev = nullptr;  // MODE 1: the block of the round before
     while (__any(more)) {
         const uint32_t total = collect(after, !more);
         tick(2);
@@ -1731,6 +1754,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (total > (uint32_t)C) {
             jcap = 0u;
             for (uint32_t c = 0; c < (uint32_t)C; ++c) jcap = max(jcap, list[c][lane] >> 16);
+        }
+        uint32_t* blk = nullptr;  // MODE 1: this round's block
+        uint32_t blk_tiles = 0, blk_items = 0;
+        if (MODE == 1) {
+            const uint32_t listed = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(nlist), 63);
+            const uint32_t words = (kDealHead + (uint32_t)C * 32u + 2u * kDealTiles + listed + 31u) & ~31u;  // (an item holds one or two candidates)
+            const uint32_t part = logical % kDealArenas;
+            uint32_t at = 0;
+            if (lane == 0u) at = atomicAdd(&out.heads[part], words);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (at + words > out.part_words) {  // arena full: this wavefront is redone in one kernel
+                if (lane == 0u) out.flags[logical] = 1u;
+                return;
+            }
+            const uint32_t where = part * out.part_words + at;
+            blk = out.words + where;
+            if (lane == 0u) {
+                if (deal_prev) deal_prev[2] = where + 1u; else out.first[logical] = where + 1u;
+            }
+            deal_prev = blk;
+            blk[4u + lane] = nlist;
+            unsigned short* jt = reinterpret_cast<unsigned short*>(blk + kDealHead);
+            for (uint32_t c = 0; c < nlist; ++c) jt[c * 64u + lane] = (unsigned short)(list[c][lane] >> 16);
         }
         // (3) the tiles of sixteen records that hold listed candidates, ascending
         wave_sync();  // (the lists are complete; the tile is free)
@@ -1763,8 +1809,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // tiles E0 (dealt and summed now), E1 (its rows travel meanwhile) and E2 (its destination indices travel): each start is
         // fixed two tiles ahead, so no load waits for the one before it
         uint32_t E1 = E0 == kNone ? kNone : tile_after(E0 + (uint32_t)kGtRows);
-        uint32_t rj1 = tile_index(E1);
-        if (E0 != kNone) fetch_rows(E0, tile_index(E0));
+        uint32_t rj1 = MODE != 1 ? tile_index(E1) : 0u;
+        if (MODE != 1 && E0 != kNone) fetch_rows(E0, tile_index(E0));
         while (E0 != kNone) {
             const uint32_t nrow = min((uint32_t)kGtRows, P.n2 - E0);
             // the next sixteen of this lane's ordered list: those inside the tile are a run from `cur` (positions are distinct:
@@ -1792,9 +1838,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             cur += n_mine;
             const uint32_t E2 = E1 == kNone ? kNone : tile_after(E1 + (uint32_t)kGtRows);
-            const uint32_t rj2 = tile_index(E2);
+            const uint32_t rj2 = MODE != 1 ? tile_index(E2) : 0u;
             tick(3);
             wave_sync();  // (the previous tile's sums are done)
+            if (MODE == 1) {  // the tile and its items go to the block; nothing is summed here
+                if (blk_tiles == kDealTiles) {  // (wavefront-uniform) more tiles than a block describes: redone in one kernel
+                    if (lane == 0u) out.flags[logical] = 1u;
+                    return;
+                }
+                uint32_t* th = blk + kDealHead + (uint32_t)C * 32u;
+                if (lane == 0u) { th[2u * blk_tiles] = E0; th[2u * blk_tiles + 1u] = B; }
+                uint32_t* it = th + 2u * kDealTiles + blk_items;
+                for (uint32_t k = lane; k < B; k += 64u) it[k] = batch[k];
+                ++blk_tiles;
+                blk_items += B;
+                wave_sync();  // (the items are read before the next tile's are written)
+                E0 = E1; E1 = E2;
+                continue;
+            }
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u)
                 if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
@@ -1850,6 +1911,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             E0 = E1; E1 = E2; rj1 = rj2;
         }
         wave_sync();
+        if (MODE == 1) {
+            if (lane == 0u) { blk[0] = blk_tiles; blk[1] = blk_items; blk[2] = 0u; blk[3] = 0u; }
+            more = more && jcap != kNone;
+            if (more) after = (int64_t)jcap;
+            continue;
+        }
         // (4) the round's smallest (distance, index), then the smallest distance among smaller indices
         double m_d = DBL_MAX;
         uint32_t m_j = kNone;
@@ -1871,8 +1938,185 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (more) after = (int64_t)jcap;
         tick(6);
     }
+    if (MODE == 1) return;
     if (PH && lane == 0u)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_guided_phase[k], ph[k]);
+    if (!active) return;
+    double corr = 1.0;
+    if (count < 20u) corr = 0.65 * 0.65;
+    if (count < 10u) corr = 0.6 * 0.6;
+    if (count < 5u) corr = 0.5 * 0.5;
+    if (count < 3u) corr = 0.25 * 0.25;
+    const double ratio = (best / second) / corr;
+    const bool keep = !(ratio < 0.00001) && best_index > -1 && (ratio < 0.8 * 0.8 || count == 1u);
+    best_out[P.off + i] = keep ? best_index : -1;
+    ratio_out[P.off + i] = ratio;
+}
+template <int C, bool PH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_scan_flat_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
+    const double* __restrict__ spans, const uint32_t* __restrict__ order, int32_t* __restrict__ best_out, double* __restrict__ ratio_out,
+    uint32_t blocks_per_pair, uint32_t n_blocks) {
+    guided_scan_flat_body<C, PH, 0>(pairs, entries, starts, spans, order, best_out, ratio_out, blocks_per_pair, n_blocks, DealOut{});
+}
+template <int C>
+__global__ __launch_bounds__(64) void guided_deal_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
+    const double* __restrict__ spans, const uint32_t* __restrict__ order, uint32_t blocks_per_pair, uint32_t n_blocks, const DealOut out) {
+    guided_scan_flat_body<C, false, 1>(pairs, entries, starts, spans, order, nullptr, nullptr, blocks_per_pair, n_blocks, out);
+}
+template <int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_redo_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ starts,
+    const double* __restrict__ spans, const uint32_t* __restrict__ order, int32_t* __restrict__ best_out, double* __restrict__ ratio_out,
+    uint32_t blocks_per_pair, uint32_t n_blocks, const DealOut out) {
+    guided_scan_flat_body<C, false, 2>(pairs, entries, starts, spans, order, best_out, ratio_out, blocks_per_pair, n_blocks, out);
+}
+// the second kernel of the pair: source descriptors in registers, the rounds' blocks walked in order -- stage a tile's rows, sum
+// its items (as in the body above), and after a round's tiles pick the round's best and the smallest distance before it
+template <int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void guided_sum_kernel(
+    const GuidedPair* __restrict__ pairs, const GaEntry* __restrict__ entries, const uint32_t* __restrict__ order,
+    int32_t* __restrict__ best_out, double* __restrict__ ratio_out, uint32_t blocks_per_pair, uint32_t n_blocks, const DealOut out) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    __shared__ double dist[64][C | 1];
+    __shared__ __attribute__((aligned(16))) float tile[kGtRows][kGtStride];
+    const uint32_t per_xcd = (n_blocks + 7u) / 8u;
+    const uint32_t logical = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    if (logical >= n_blocks) return;
+    const uint32_t pair_id = logical / blocks_per_pair, bx = logical % blocks_per_pair;
+    const GuidedPair P = pairs[pair_id];
+    const uint32_t lane = threadIdx.x;
+    if (bx * 64u >= P.n1) return;
+    if (out.flags[logical] != 0u) return;  // (redone by guided_redo_kernel)
+    const bool active = bx * 64u + lane < P.n1;
+    const uint32_t i = active ? order[P.off + bx * 64u + lane] : 0u;
+    float a[kD];
+    {
+        const float4* row = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
+#pragma unroll
+        for (int q = 0; q < kD / 4; ++q) {
+            const float4 t = row[q];
+            a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+        }
+    }
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    double best = DBL_MAX, second = DBL_MAX;
+    int32_t best_index = -1;
+    uint32_t count = 0;
+    uint32_t at = out.first[logical];
+    while (at != 0u) {
+        const uint32_t* blk = out.words + (at - 1u);
+        const uint32_t n_tiles = blk[0];
+        at = blk[2];
+        const uint32_t nlist = blk[4u + lane];
+        const unsigned short* jt = reinterpret_cast<const unsigned short*>(blk + kDealHead);
+        const uint32_t* th = blk + kDealHead + (uint32_t)C * 32u;
+        const uint32_t* items = th + 2u * kDealTiles;
+        // this source's listed destination indices, fetched now and used after the tiles (the loads travel behind the sums)
+        uint32_t jv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) jv[c] = (uint32_t)c < nlist ? (uint32_t)jt[c * 64 + (int)lane] : 0u;
+        // lane t holds tile t: its first record and its item count (at most kDealTiles = 64 tiles per block)
+        uint32_t tE = kNone, tB = 0u;
+        if (lane < n_tiles) { tE = th[2u * lane]; tB = th[2u * lane + 1u]; }
+        auto tile_index = [&](uint32_t E) -> uint32_t {
+            return (E != kNone && lane < min((uint32_t)kGtRows, P.n2 - E)) ? entries[P.off2 + E + lane].j : 0u;
+        };
+        float2 bv[16];
+        auto fetch_rows = [&](uint32_t E, uint32_t rj) {
+            const uint32_t nr = min((uint32_t)kGtRows, P.n2 - E);
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u) {
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rj, (int)u);
+                if (u < nr) bv[u] = reinterpret_cast<const float2*>(P.d2 + (size_t)j * kD)[lane];
+            }
+        };
+        auto first_of = [&](uint32_t t) { return t < n_tiles ? (uint32_t)__builtin_amdgcn_readlane((int)tE, (int)t) : kNone; };
+        wave_sync();  // (the round before is done with dist and the tile)
+        uint32_t E0 = first_of(0u), E1 = first_of(1u);
+        uint32_t rj1 = tile_index(E1);
+        if (E0 != kNone) fetch_rows(E0, tile_index(E0));
+        uint32_t item_at = 0;
+        const uint32_t n_items_round = blk[1];
+        uint32_t item_ahead = lane < n_items_round ? items[lane] : lane;  // the items are one stream: a batch's words are fetched a batch ahead
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            const uint32_t nrow = min((uint32_t)kGtRows, P.n2 - E0);
+            const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)tB, (int)t);
+            const uint32_t E2 = first_of(t + 2u);
+            const uint32_t rj2 = tile_index(E2);
+            wave_sync();  // (the previous tile's sums are done)
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; ++u)
+                if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+            if (E1 != kNone) fetch_rows(E1, rj1);
+            wave_sync();
+            for (uint32_t base = 0; base < B; base += 64u) {
+                const bool valid = base + lane < B;
+                const uint32_t item = valid ? item_ahead : lane;
+                {   // the next batch: the rest of this tile's items, or the start of the next tile's
+                    const uint32_t nx = item_at + (base + 64u < B ? base + 64u : B) + lane;
+                    item_ahead = nx < n_items_round ? items[nx] : lane;
+                }
+                const uint32_t owner = item & 63u;
+                const uint32_t ca = (item >> 6) & 31u, cb = (item >> 15) & 31u;
+                const float4* ta = reinterpret_cast<const float4*>(&tile[(item >> 11) & 15u][0]);
+                const float4* tb = reinterpret_cast<const float4*>(&tile[(item >> 20) & 15u][0]);
+                const int from = (int)(owner << 2);
+                double da = 0.0, db = 0.0;
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                auto pull = [&](float s) { return __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(s))); };
+                float4 u = ta[0], v = tb[0];
+                float s0 = pull(a[0]), s1 = pull(a[1]), s2 = pull(a[2]), s3 = pull(a[3]);
+#pragma unroll
+                for (int q = 0; q < kD / 4; ++q) {
+                    float4 un = u, vn = v;
+                    float n0 = s0, n1 = s1, n2 = s2, n3 = s3;
+                    if (q + 1 < kD / 4) {
+                        un = ta[q + 1]; vn = tb[q + 1];
+                        n0 = pull(a[4 * q + 4]); n1 = pull(a[4 * q + 5]); n2 = pull(a[4 * q + 6]); n3 = pull(a[4 * q + 7]);
+                    }
+                    const pk2 a01 = {s0, s1}, a23 = {s2, s3};
+                    const pk2 du01 = a01 - pk2{u.x, u.y}, du23 = a23 - pk2{u.z, u.w}, dv01 = a01 - pk2{v.x, v.y}, dv23 = a23 - pk2{v.z, v.w};
+                    const double u0 = (double)du01.x, u1 = (double)du01.y, u2 = (double)du23.x, u3 = (double)du23.y;
+                    const double w0 = (double)dv01.x, w1 = (double)dv01.y, w2 = (double)dv23.x, w3 = (double)dv23.y;
+                    da = fma(u0, u0, da); db = fma(w0, w0, db);
+                    da = fma(u1, u1, da); db = fma(w1, w1, db);
+                    da = fma(u2, u2, da); db = fma(w2, w2, db);
+                    da = fma(u3, u3, da); db = fma(w3, w3, db);
+                    u = un; v = vn; s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+                    asm volatile("" : "+v"(da), "+v"(db));  // (ties the chains to their step: see the body above)
+                }
+                if (valid) {
+                    dist[owner][ca] = da;
+                    dist[owner][cb] = db;
+                }
+            }
+            item_at += B;
+            E0 = E1; E1 = E2; rj1 = rj2;
+        }
+        wave_sync();
+        double m_d = DBL_MAX;
+        uint32_t m_j = kNone;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if ((uint32_t)c < nlist) {
+                const double dc = dist[lane][c];
+                if (dc < m_d || (dc == m_d && jv[c] < m_j)) { m_d = dc; m_j = jv[c]; }
+            }
+        double s_d = DBL_MAX;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if ((uint32_t)c < nlist && jv[c] < m_j) s_d = fmin(s_d, dist[lane][c]);
+        count += nlist;
+        if (m_d < best) {
+            second = fmin(best, s_d);
+            best = m_d;
+            best_index = (int32_t)m_j;
+        }
+    }
     if (!active) return;
     double corr = 1.0;
     if (count < 20u) corr = 0.65 * 0.65;
@@ -2525,8 +2769,21 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     const size_t ga_entry_bytes = angular ? ((size_t)total2 * sizeof(GaEntry) + 255) / 256 * 256 : 0,
                  ga_key_bytes = angular ? ((size_t)total2 * 4 + 255) / 256 * 256 : 0,
                  ga_start_bytes = angular ? ((size_t)n_pairs * (kGaBuckets + 2) * 4 + (size_t)n_pairs * 16 + 255) / 256 * 256 : 0;
+    // the scan as two kernels (the default; PGI_GUIDED_SPLIT=0: one kernel): per wavefront two table words, kDealArenas heads, an arena
+    const char* split_txt = getenv("PGI_GUIDED_SPLIT");
+    const char* cap_txt0 = getenv("PGI_GUIDED_CAP");
+    const char* lanes_txt0 = getenv("PGI_GUIDED_LANES");
+    const bool split = angular && !(split_txt && atoi(split_txt) == 0) && !cap_txt0 && !(lanes_txt0 && atoi(lanes_txt0) != 0);
+    // words of arena per wavefront on average (a round's block reserves ~1800 at 24 candidates per source, about a sixth of the
+    // wavefronts take a second one); PGI_GUIDED_ARENA_WORDS shrinks it (tests: wavefronts that do not fit are redone in one kernel)
+    const char* aw_txt = getenv("PGI_GUIDED_ARENA_WORDS");
+    const size_t kDealWords = aw_txt && atoi(aw_txt) > 0 ? (size_t)atoi(aw_txt) : 2560;
+    const size_t deal_waves = (size_t)((max_n1 + 63u) / 64u) * n_pairs;
+    const size_t deal_part_words = split ? (deal_waves * kDealWords + kDealArenas - 1) / kDealArenas : 0;
+    const size_t deal_table_bytes = split ? ((kDealArenas + 2 * deal_waves) * 4 + 255) / 256 * 256 : 0;
+    const size_t deal_arena_bytes = split ? (deal_part_words * kDealArenas * 4 + 255) / 256 * 256 : 0;
     const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + ga_entry_bytes + ga_key_bytes +
-                         ga_start_bytes + 256;
+                         ga_start_bytes + deal_table_bytes + deal_arena_bytes + 256;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -2578,6 +2835,34 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
                     " | %.0f s_memtime ticks per wavefront, %u wavefronts launched\n",
                     n_pairs, 100 * got[0] / all, 100 * got[2] / all, 100 * got[3] / all, 100 * got[4] / all, 100 * got[5] / all, 100 * got[6] / all,
                     all / flat_blocks, flat_blocks);
+        }
+        else if (lanes_env == 0 && split && cap_env == kGfCap && deal_part_words < 0xFFFFFFFFull / kDealArenas) {
+            char* dq = q + ga_start_bytes;
+            DealOut dout;
+            dout.heads = (uint32_t*)dq;
+            dout.first = dout.heads + kDealArenas;
+            dout.flags = dout.first + deal_waves;
+            dout.words = (uint32_t*)(dq + deal_table_bytes);
+            dout.part_words = (uint32_t)deal_part_words;
+            HIP_TRY(hipMemsetAsync(dq, 0, deal_table_bytes, ctx->stream));
+            hipLaunchKernelGGL((guided_deal_kernel<kSplitCap>), flat_grid, dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span, d_cj, flat_per_pair,
+                               flat_blocks, dout);
+            hipLaunchKernelGGL((guided_sum_kernel<kSplitCap>), flat_grid, dim3(64), 0, ctx->stream, d_pairs, d_ent, d_cj, d_best, d_rat, flat_per_pair,
+                               flat_blocks, dout);
+            hipLaunchKernelGGL((guided_redo_kernel<kGfCap>), flat_grid, dim3(64), 0, ctx->stream, d_pairs, d_ent, d_gst, d_span, d_cj, d_best, d_rat,
+                               flat_per_pair, flat_blocks, dout);
+            if (getenv("PGI_GUIDED_ARENA_REPORT")) {  // diagnostics: how full the arena got, how many wavefronts were redone
+                std::vector<uint32_t> h(kDealArenas + 2 * deal_waves);
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                HIP_TRY(hipMemcpy(h.data(), dq, h.size() * 4, hipMemcpyDeviceToHost));
+                uint64_t used = 0, redone = 0;
+                uint32_t fullest = 0;
+                for (uint32_t k = 0; k < kDealArenas; ++k) { used += std::min<uint32_t>(h[k], dout.part_words); fullest = std::max(fullest, h[k]); }
+                for (size_t k = 0; k < deal_waves; ++k) redone += h[kDealArenas + deal_waves + k];
+                fprintf(stderr, "[pgi] guided scan arena (%u pairs): %.1f MB of %.1f MB used (%.0f words per wavefront, fullest part %.0f %%), %llu of %zu wavefronts redone\n",
+                        n_pairs, used * 4e-6, (double)deal_part_words * kDealArenas * 4e-6, (double)used / deal_waves,
+                        100.0 * fullest / dout.part_words, (unsigned long long)redone, deal_waves);
+            }
         }
         else if (lanes_env == 0 && cap_env == 4) PGI_FLAT(4, false);   // (tests: several rounds per source)
         else if (lanes_env == 0 && cap_env == 16) PGI_FLAT(16, false);

@@ -16,7 +16,7 @@ eng = Engine()
 rng = np.random.default_rng(777)
 t0 = time.time()
 n_src = n_match = n_frag = n_crowd = 0
-VARIANTS = (("lanes2", {"PGI_GUIDED_LANES": "2"}), ("flat", {}), ("flat_cap4", {"PGI_GUIDED_CAP": "4"}), ("flat_cap16", {"PGI_GUIDED_CAP": "16"}),
+VARIANTS = (("lanes2", {"PGI_GUIDED_LANES": "2"}), ("flat", {}), ("flat_fused", {"PGI_GUIDED_SPLIT": "0"}), ("flat_tiny_arena", {"PGI_GUIDED_ARENA_WORDS": "700"}), ("flat_cap4", {"PGI_GUIDED_CAP": "4"}), ("flat_cap16", {"PGI_GUIDED_CAP": "16"}),
             ("bin_scan", {"PGI_GUIDED_ANGLE": "0"}))
 for q in range(n_scenes):
     views, poses, cam = S.make_feature_views(np.random.default_rng(20000 + q), n_views=2, n_points=int(rng.integers(100, 2500)),
@@ -60,7 +60,7 @@ for q in range(n_scenes):
     keep_o = ~frag[oi].astype(bool)
     first = None
     for name, env in VARIANTS:
-        for k in ("PGI_GUIDED_LANES", "PGI_GUIDED_ANGLE", "PGI_GUIDED_CAP"):
+        for k in ("PGI_GUIDED_LANES", "PGI_GUIDED_ANGLE", "PGI_GUIDED_CAP", "PGI_GUIDED_SPLIT", "PGI_GUIDED_ARENA_WORDS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         for max_n in (0, 100):
@@ -78,5 +78,5 @@ for q in range(n_scenes):
                 print("MISMATCH between variants at scene", q, "kind", kind, name, "max_n", max_n)
                 sys.exit(1)
     n_src += len(views[0]["xy"]); n_match += len(oi); n_frag += int(frag.sum())
-print("guided soak: %d scenes (%d with crowded lines), %d source keypoints, %d matches, %d source keypoints in the bin-edge band: pooled scan (caps 20 / 16 / 4) == tile scan "
+print("guided soak: %d scenes (%d with crowded lines), %d source keypoints, %d matches, %d source keypoints in the bin-edge band: pooled scan (two kernels, one kernel, redone wavefronts, caps 16 / 4) == tile scan "
       "(2 lanes) == bin scan == literal restatement (%.0f s)" % (n_scenes, n_crowd, n_src, n_match, n_frag, time.time() - t0))

@@ -203,7 +203,7 @@ def test_gpu_guided_match_binned_unusual_geometry(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["flat", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
+@pytest.mark.parametrize("variant", ["flat", "flat_fused", "flat_tiny_arena", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
 def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
     """Source keypoints with far more gate-passing candidates than one pass of the tile scan lists (16 per lane): 120
     destination keypoints are moved onto the epipolar line of each of four source keypoints, so those sources are handled
@@ -213,6 +213,10 @@ def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
         monkeypatch.delenv("PGI_GUIDED_LANES", raising=False)
         if "cap" in variant:
             monkeypatch.setenv("PGI_GUIDED_CAP", variant.split("cap")[1])
+        if "fused" in variant:   # the scan in ONE kernel (the default is two: window + gate pass + dealing, then sums + pick)
+            monkeypatch.setenv("PGI_GUIDED_SPLIT", "0")
+        if "tiny_arena" in variant:   # most wavefronts' lists do not fit: they are redone in one kernel
+            monkeypatch.setenv("PGI_GUIDED_ARENA_WORDS", "700")
     elif variant == "bin_scan":
         monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
     else:
@@ -253,7 +257,7 @@ def test_gpu_guided_match_crowded_epipolar_lines(eng, variant, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["flat", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
+@pytest.mark.parametrize("variant", ["flat", "flat_fused", "flat_tiny_arena", "flat_cap4", "flat_cap16", "lanes2", "bin_scan"])
 def test_gpu_guided_match_binned_degenerate_inputs(eng, variant, monkeypatch):
     """The binned mode on empty images, a zero pose (F = 0: every record is degenerate, every angle NaN, every destination
     keypoint a candidate of every source: the multi-round path on the records every source visits) and a pure-rotation pose
@@ -262,6 +266,10 @@ def test_gpu_guided_match_binned_degenerate_inputs(eng, variant, monkeypatch):
         monkeypatch.delenv("PGI_GUIDED_LANES", raising=False)
         if "cap" in variant:
             monkeypatch.setenv("PGI_GUIDED_CAP", variant.split("cap")[1])
+        if "fused" in variant:   # the scan in ONE kernel (the default is two: window + gate pass + dealing, then sums + pick)
+            monkeypatch.setenv("PGI_GUIDED_SPLIT", "0")
+        if "tiny_arena" in variant:   # most wavefronts' lists do not fit: they are redone in one kernel
+            monkeypatch.setenv("PGI_GUIDED_ARENA_WORDS", "700")
     elif variant == "bin_scan":
         monkeypatch.setenv("PGI_GUIDED_ANGLE", "0")
     else:
