@@ -2779,7 +2779,8 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     const char* aw_txt = getenv("PGI_GUIDED_ARENA_WORDS");
     const size_t kDealWords = aw_txt && atoi(aw_txt) > 0 ? (size_t)atoi(aw_txt) : 2560;
     const size_t deal_waves = (size_t)((max_n1 + 63u) / 64u) * n_pairs;
-    const size_t deal_part_words = split ? (deal_waves * kDealWords + kDealArenas - 1) / kDealArenas : 0;
+    // (a part serves every 64th wavefront: small launches get room for a dozen blocks per part whatever the average says)
+    const size_t deal_part_words = split ? std::max<size_t>((deal_waves * kDealWords + kDealArenas - 1) / kDealArenas, aw_txt ? 0 : 32768) : 0;
     const size_t deal_table_bytes = split ? ((kDealArenas + 2 * deal_waves) * 4 + 255) / 256 * 256 : 0;
     const size_t deal_arena_bytes = split ? (deal_part_words * kDealArenas * 4 + 255) / 256 * 256 : 0;
     const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + ga_entry_bytes + ga_key_bytes +
