@@ -865,8 +865,8 @@ def main():
                                        "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
                     gj, gname, gwhy = replay_profile("guided", None, None, L)
                     feat["dominant_kernel"] = dict(
-                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (six wavefronts per CU; VALU 37 %, LDS 34 % busy); roofline frac priced against hbm"},
-                        **({k: gj.get(k) for k in ("kernel_us_trace_avg", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
+                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (seven wavefronts per CU in the sum kernel; VALU 39 % busy); roofline frac priced against hbm over all kernels of the scan"},
+                        **({k: gj.get(k) for k in ("kernel_us_trace_avg", "scan_us_all_kernels", "companion_kernels", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
                                                     "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "valu_issue_busy_frac", "wave_waiting_frac", "lane_utilisation", "vgprs", "spilled_vgprs")}
                            if gj else {}),
                         source=("replayed from %s; source hash matches the loaded build" % gname) if gj else "none: %s" % gwhy)
