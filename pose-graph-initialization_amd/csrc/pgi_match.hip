@@ -24,6 +24,16 @@ constexpr int kD = PGI_DESC_DIM;   // 128
 constexpr int kPadRows = 256;      // keypoint padding: the largest workgroup covers 8 wavefronts x one 32-row MFMA tile
 constexpr int kTileJ = 64;         // columns of B staged per step: 2 MFMA tiles per wavefront
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A pointer that arrives inside a struct (GuidedPair, ScreenPair, MatchPair) is a generic pointer to the compiler: its loads
+// become flat_load, which count on BOTH wait counters -- an LDS wait (lgkmcnt) then also waits for loads that were meant to
+// travel behind the arithmetic.  These say what the host knows: the pointer is device memory (global_load, vmcnt only).
+#define PGI_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 load_global_f32x4(const float* p, size_t k) { return ((const f32x4 PGI_GLOBAL*)p)[k]; }
+__device__ __forceinline__ f32x2 load_global_f32x2(const float* p, size_t k) { return ((const f32x2 PGI_GLOBAL*)p)[k]; }
+__device__ __forceinline__ float load_global_f32(const float* p, size_t k) { return ((const float PGI_GLOBAL*)p)[k]; }
+__device__ __forceinline__ uint32_t load_global_u32(const uint32_t* p, size_t k) { return ((const uint32_t PGI_GLOBAL*)p)[k]; }
 
 struct RowBest {
     float b1, b2;  // smallest and second-smallest squared distance of the row
@@ -346,18 +356,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     const uint32_t x = wgid % wgs_per_pair, rb = x / splits, split = x % splits;
     constexpr uint32_t kRows = NW * 32u;
     if (rb * kRows >= P.n_a_pad) return;
-    const uint32_t n_listed = P.row_list ? *P.row_count : 0u;
+    const uint32_t n_listed = P.row_list ? load_global_u32(P.row_count, 0) : 0u;
     if (P.row_list && rb * kRows >= n_listed) return;  // (workgroup-uniform)
     const uint32_t tiles = P.n_b_pad / kTileJ;
     const uint32_t t0 = (uint32_t)((uint64_t)tiles * split / splits), t1 = (uint32_t)((uint64_t)tiles * (split + 1) / splits);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
     const uint32_t row_base = rb * kRows + w * 32u;
     // slot -> row of A (slots past the end of a list repeat row 0: computed, never read)
-    auto row_of = [&](uint32_t slot) { return P.row_list ? (slot < n_listed ? P.row_list[P.row_off + slot] : 0u) : slot; };
+    auto row_of = [&](uint32_t slot) { return P.row_list ? (slot < n_listed ? load_global_u32(P.row_list, P.row_off + slot) : 0u) : slot; };
 
     // largest column norm (for eps): every wavefront scans the norm array once
     float nbmax = 0.0f;
-    for (uint32_t j = tid; j < P.n_b_pad; j += NW * 64u) nbmax = fmaxf(nbmax, P.nb[j]);
+    for (uint32_t j = tid; j < P.n_b_pad; j += NW * 64u) nbmax = fmaxf(nbmax, load_global_f32(P.nb, j));
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) nbmax = fmaxf(nbmax, __shfl_xor(nbmax, m));
     if (lane == 0) s_nbmax[w] = nbmax;
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     const uint32_t a_row = row_of(row_base + c);
 #pragma unroll
     for (int ks = 0; ks < kD / 16; ++ks)
-        a[ks] = *reinterpret_cast<const f16x8*>(P.abf + f16_offset(a_row, 16u * (uint32_t)ks + 8u * h));
+        a[ks] = *(const f16x8 PGI_GLOBAL*)(P.abf + f16_offset(a_row, 16u * (uint32_t)ks + 8u * h));
     // Per lane and row: the three smallest KEYS seen so far, b1 <= b2 <= b3, as unsigned integers.  A key is the bit
     // pattern of the approximate squared distance d~ = max(0, na + nb - 2 s~) -- non-negative floats order like their bit
     // patterns -- with the column's position inside this lane's stream (code = 2 * (tile - t0) + sub, 9 bits: at most
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
     uint32_t b1[16], b2[16], b3[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        nar[r] = P.na[row_of(row_base + mfma_row(r, h))];
+        nar[r] = load_global_f32(P.na, row_of(row_base + mfma_row(r, h)));
         b1[r] = kKeyInf; b2[r] = kKeyInf; b3[r] = kKeyInf;
     }
     auto med3u = [](uint32_t x, uint32_t y, uint32_t z) {
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
             const uint32_t cg = (uint32_t)q * NW + w;
             // operand order in HBM: a wavefront reads 1 KB contiguous (the row-major layout made every lane touch its own
             // 256-byte row, and the vector L1 then spent 64 tag cycles per load instruction)
-            dst[q] = *reinterpret_cast<const f16x8*>(P.bbf + (size_t)tile * (kTileJ * kD) + (cg * 64u + lane) * 8u);
+            dst[q] = *(const f16x8 PGI_GLOBAL*)(P.bbf + (size_t)tile * (kTileJ * kD) + (cg * 64u + lane) * 8u);
         }
     };
     auto lwrite = [&](const f16x8 (&src)[kChunks], uint32_t buf) {
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void desc_screen_kernel(c
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t j = tile * kTileJ + 32u * sub + c;
-            nbj[sub] = j < P.n_b ? P.nb[j] : kFar;  // padded columns: never near any window
+            nbj[sub] = j < P.n_b ? load_global_f32(P.nb, j) : kFar;  // padded columns: never near any window
         }
         f32x16 acc[2];
 #pragma unroll
@@ -1601,14 +1611,14 @@ __device__ __forceinline__ void guided_scan_flat_body(
     // (1)
     float a[kD];
     if (MODE != 1) {
-        const float4* row = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
+        const float* row = P.d1 + (size_t)i * kD;
 #pragma unroll
         for (int q = 0; q < kD / 4; ++q) {
-            const float4 t = row[q];
+            const f32x4 t = load_global_f32x4(row, (size_t)q);
             a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
         }
     }
-    const double x1 = (double)P.kp1[2 * (size_t)i], y1 = (double)P.kp1[2 * (size_t)i + 1];
+    const double x1 = (double)load_global_f32(P.kp1, 2 * (size_t)i), y1 = (double)load_global_f32(P.kp1, 2 * (size_t)i + 1);
     const double rx = (P.F[0] * x1 + P.F[1] * y1) + P.F[2];
     const double ry = (P.F[3] * x1 + P.F[4] * y1) + P.F[5];
     const double b1 = rx * rx + ry * ry;
@@ -1785,13 +1795,13 @@ __device__ __forceinline__ void guided_scan_flat_body(
         auto tile_index = [&](uint32_t E) -> uint32_t {  // destination indices of the records E .. E + 15, one per lane
             return (E != kNone && lane < min((uint32_t)kGtRows, P.n2 - E)) ? entries[P.off2 + E + lane].j : 0u;
         };
-        float2 bv[16];  // a tile's rows travel while the tile before it is summed
+        f32x2 bv[16];  // a tile's rows travel while the tile before it is summed
         auto fetch_rows = [&](uint32_t E, uint32_t rj) {
             const uint32_t nr = min((uint32_t)kGtRows, P.n2 - E);
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u) {
                 const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rj, (int)u);
-                if (u < nr) bv[u] = reinterpret_cast<const float2*>(P.d2 + (size_t)j * kD)[lane];
+                if (u < nr) bv[u] = load_global_f32x2(P.d2 + (size_t)j * kD, lane);
             }
         };
         // the wavefront's first listed record position at or after `from` (kNone: none).  A lane looks at the next sixteen of its
@@ -1858,7 +1868,7 @@ __device__ __forceinline__ void guided_scan_flat_body(
             }
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u)
-                if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+                if (u < nrow) *reinterpret_cast<f32x2*>(&tile[u][2 * lane]) = bv[u];
             if (E1 != kNone) fetch_rows(E1, rj1);
             wave_sync();
             tick(4);
@@ -1993,10 +2003,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t i = active ? order[P.off + bx * 64u + lane] : 0u;
     float a[kD];
     {
-        const float4* row = reinterpret_cast<const float4*>(P.d1 + (size_t)i * kD);
+        const float* row = P.d1 + (size_t)i * kD;
 #pragma unroll
         for (int q = 0; q < kD / 4; ++q) {
-            const float4 t = row[q];
+            const f32x4 t = load_global_f32x4(row, (size_t)q);
             a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
         }
     }
@@ -2025,13 +2035,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         auto tile_index = [&](uint32_t E) -> uint32_t {
             return (E != kNone && lane < min((uint32_t)kGtRows, P.n2 - E)) ? entries[P.off2 + E + lane].j : 0u;
         };
-        float2 bv[16];
+        f32x2 bv[16];
         auto fetch_rows = [&](uint32_t E, uint32_t rj) {
             const uint32_t nr = min((uint32_t)kGtRows, P.n2 - E);
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u) {
                 const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)rj, (int)u);
-                if (u < nr) bv[u] = reinterpret_cast<const float2*>(P.d2 + (size_t)j * kD)[lane];
+                if (u < nr) bv[u] = load_global_f32x2(P.d2 + (size_t)j * kD, lane);
             }
         };
         auto first_of = [&](uint32_t t) { return t < n_tiles ? (uint32_t)__builtin_amdgcn_readlane((int)tE, (int)t) : kNone; };
@@ -2050,7 +2060,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             wave_sync();  // (the previous tile's sums are done)
 #pragma unroll
             for (uint32_t u = 0; u < 16u; ++u)
-                if (u < nrow) *reinterpret_cast<float2*>(&tile[u][2 * lane]) = bv[u];
+                if (u < nrow) *reinterpret_cast<f32x2*>(&tile[u][2 * lane]) = bv[u];
             if (E1 != kNone) fetch_rows(E1, rj1);
             wave_sync();
             for (uint32_t base = 0; base < B; base += 64u) {
