@@ -389,7 +389,9 @@ typedef struct {
 } pgi_feature_view;
 /* h_pose_Rt: n_pairs x 12 doubles (R_dst_src row-major, t_dst_src).  Outputs per pair at stride
  * out_stride (>= max_n, or >= the largest source keypoint count when max_n = 0).  d_ratio holds
- * dist_ratio_sq_adapted (:394).  Asynchronous on the stream. */
+ * dist_ratio_sq_adapted (:394).  Asynchronous on the stream.  Workspace (grow-only, owned by the context, shared with the
+ * descriptor matcher): ~100 bytes per keypoint of the batch plus, for n_bins > 0, 10 KB per 64 source keypoints (the lists the
+ * scan's first kernel hands to its second: 0.7 GB for 512 pairs x 8000 keypoints; the first call of a larger batch allocates). */
 int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pgi_feature_view* h_dst,
                            uint32_t n_pairs, const double* h_pose_Rt, uint32_t n_bins, uint32_t max_n,
                            uint32_t out_stride, uint32_t* d_match_src, uint32_t* d_match_dst, double* d_ratio,
