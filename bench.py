@@ -245,6 +245,69 @@ def compact_summary(out):
     return {k: r(v) for k, v in s.items()}
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "quality", "exchange_verified")
+COMPACT_LIMIT = 8192   # the driver keeps a bounded tail of stdout: a longer line is cut at the front and is no JSON any more
+
+
+def _short(v, n=120):
+    """strings cut to n characters, floats to 10 significant digits, containers walked"""
+    if isinstance(v, str):
+        return v if len(v) <= n else v[:n - 1] + "~"
+    if isinstance(v, float):
+        return float("%.10g" % v)
+    if isinstance(v, dict):
+        return {k: _short(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x, n) for x in v]
+    return v
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, `quality` and the flat
+    `summary`, never more than COMPACT_LIMIT bytes; every per-leg block, repetition list and variant lives in bench_full.json.
+    Notes are dropped before anything else; if a run ever still overflows, the optional blocks go one by one."""
+    line = {k: out[k] for k in COMPACT_KEYS if k in out}
+    if isinstance(line.get("roofline"), dict):
+        line["roofline"] = {k: v for k, v in line["roofline"].items() if k not in ("note",)}
+    if isinstance(line.get("cpu_baseline"), dict):
+        cb = dict(line["cpu_baseline"])
+        ocv = cb.pop("opencv", None)
+        cb.pop("build", None)
+        if isinstance(ocv, dict):
+            cb["opencv_available"] = bool(ocv.get("available"))
+        line["cpu_baseline"] = cb
+    if isinstance(out.get("exchange"), dict):
+        line["exchange"] = {k: v for k, v in out["exchange"].items() if k not in ("note", "uneven_counts")}
+    line["summary"] = out.get("summary") or compact_summary(out)
+    if full_path:
+        line["full_record"] = full_path
+    line = _short(line)
+    for drop in (None, "full_record", "exchange", "quality"):
+        if drop:
+            line.pop(drop, None)
+        txt = json.dumps(line, separators=(",", ":"))
+        if len(txt.encode()) < COMPACT_LIMIT:
+            return txt
+    # last resort: the contract's scalar keys + roofline + cpu_baseline with every string cut hard
+    line = _short({k: v for k, v in line.items() if k != "summary"}, 40)
+    return json.dumps(line, separators=(",", ":"))
+
+
+def emit(out):
+    """full record -> bench_full.json beside this script (path on stderr); compact line -> stdout, LAST thing printed"""
+    full_path = os.environ.get("PGI_BENCH_FULL", os.path.join(ROOT, "bench_full.json"))
+    try:
+        with open(full_path, "w") as f:
+            json.dump(out, f)
+        print("bench.py: full record (per-leg blocks, repetitions, variants) in %s" % full_path, file=sys.stderr)
+    except OSError as ex:
+        print("bench.py: could not write %s: %s" % (full_path, ex), file=sys.stderr)
+        full_path = None
+    sys.stderr.flush()
+    print(compact_line(out, os.path.basename(full_path) if full_path else None), flush=True)
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -924,7 +987,7 @@ def main():
         out["exchange_verified"] = bool(flag.item())
         if args.require_rccl and not out["exchange_verified"]:
             if rank == 0:
-                print(json.dumps(out))
+                emit(out)
             raise SystemExit("bench.py --require-rccl: a rank holds records that differ from their owner's")
     if world > 1 and not args.no_variants:
         # BASELINE configs 4 and 5 on `world` GPUs: rank 0 starts the C++ driver as world child processes (the bench's own
@@ -935,12 +998,12 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 out["graphs"] = {"error": repr(ex)[-800:]}
                 if args.require_rccl:
-                    print(json.dumps(out))
+                    emit(out)
                     raise
         dist.barrier()
     if rank == 0:
-        out["summary"] = compact_summary(out)   # LAST key, < 1 KB: what the driver's 8 KB tail of this line must still show
-        print(json.dumps(out))
+        out["summary"] = compact_summary(out)
+        emit(out)   # compact line (< 8 KB) LAST on stdout; everything else in bench_full.json
     if comm is not None:
         comm.close()
     eng.close()
