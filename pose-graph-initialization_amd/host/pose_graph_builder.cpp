@@ -463,6 +463,13 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
     if (!rowsOnly) stagingBusy.lock();
     HIP_OK(hipSetDevice(engineDevice(engine->get())));  // this thread's allocations, stream and events belong to the engine's device
     staging->init(kCoreNumber ? kCoreNumber : 1);
+    if (rowsOnly && !L) {
+        // This rank's block of the NEXT wave is empty (fewer pairs than ranks, or one heavy pair): there is nothing to upload, and
+        // nothing below -- the collective, the download, the insertion, the statistics -- is a prefetch's business: the peers
+        // issue no second all-gather, and the other block holds no records of this wave.
+        staging->pre.valid = false;
+        return 0;
+    }
     // Which of the two blocks: a prefetch fills the one the running wave does not use; a wave whose rows were prefetched
     // works where they lie; every other call on the active one.
     const bool prefetched = !rowsOnly && staging->pre.valid && staging->pre.first == (const void*)pairs.data() && staging->pre.P == P &&

@@ -263,6 +263,33 @@ def test_eight_ranks_over_the_host_transport_match_single_process(scene, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["waves", "waves_guided"])
+def test_tail_wave_with_fewer_pairs_than_ranks(tmp_path, mode):
+    """the scheduler's next-wave prefetch on a rank whose block of the NEXT wave is empty.  Wave size =
+    all candidates but two, four ranks: the tail wave has two pairs, so at least two ranks own nothing of it while they prefetch
+    it from inside the first wave's call.  Such a prefetch must upload nothing and touch no collective: every rank's result
+    equals the single-process run's byte for byte (before the fix the helper thread ran the full estimate path: a second
+    all-gather the peers never issued)."""
+    from pyposegraphbuilder import distributed as D
+    g, _wave = SC.make_scene("v340_thin")
+    P = len(g["pairs"])
+    wave = P - 2
+    path = str(tmp_path / "scene.bin")
+    write_scene(path, g, wave, sim_kind=2)
+    run_ranks([EXE, path, str(tmp_path / "w1"), mode], 1)
+    single = open(str(tmp_path / "w1.0"), "rb").read()
+    st = struct.unpack_from("<13Q", single, 0)
+    assert st[0] == P and st[7] >= 2, st                      # every pair processed, in at least two waves
+    sizes = np.diff(g["batch"]["offsets"].astype(np.int64))
+    o4 = run_ranks([EXE, path, str(tmp_path / "w4"), mode], 4)
+    assert len(o4) == 4
+    for r in range(4):
+        assert open(str(tmp_path / "w4.%d" % r), "rb").read() == single, r
+    # (the premise: a wave of two pairs leaves at least two of four blocks empty)
+    assert sum(1 for lo, hi in D.shard_bounds(sizes[-2:], 4) if hi == lo) >= 2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("guided", [False, True])
 def test_c_abi_run_pairs_is_the_driver_on_the_dense_scene(scene, guided):
     """pgih_run_pairs of libpgi_host.so (include/pgi_host.h) -- the installed entry point a non-C++ caller binds -- on the
