@@ -41,7 +41,6 @@ typedef enum {
 #define PGI_EDGE_NAN (-1)          /* false (pose_graph_builder.h:1069-1070)             */
 #define PGI_EDGE_FEW_POINTS (-2)   /* fewer than 5 rows                                  */
 #define PGI_EDGE_TOO_MANY_ROWS (-3) /* the pair has more rows than pgi_batch.max_corr promised */
-#define PGI_EDGE_NOT_RESIDENT (-4) /* streamed batch: the pair was never announced through *d_ready (4 s watchdog) */
 
 typedef struct pgi_ctx pgi_ctx;
 
@@ -138,16 +137,6 @@ int pgi_synchronize(pgi_ctx* ctx);
 /* d_edges: n_pairs records; d_masks: one byte per row of the batch. */
 int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_edges,
                             uint8_t* d_masks);
-/* The same for a batch that is STILL BEING UPLOADED (round 5).  d_offsets and d_thr must be resident; the rows (and guesses)
- * of pair k need to be only once *d_ready > k.  *d_ready (a device word, 0 when this is called) is raised by the caller --
- * monotonically, from a copy stream that is ordered behind the uploads it announces (hipMemcpyAsync of the new count after a
- * chunk's copies), never from the context's stream -- up to batch->n_pairs.  One launch sequence for the whole batch: the
- * kernels work on the leading pairs while the rest travels, and the batch pays one wind-down instead of one per chunk group
- * (PoseGraphBuilder::estimatePoses, pose_graph_builder.h:391-413's loop over pairs as the reference runs it, is the user).
- * The call returns at once; the work completes only after *d_ready has reached n_pairs. */
-int pgi_estimate_pose_batch_streamed(pgi_ctx* ctx, const pgi_batch* batch, pgi_edge* d_edges,
-                                     uint8_t* d_masks, const uint32_t* d_ready);
-
 /* Host buffers in, host buffers out (synchronous).  Same result as pgi_estimate_pose_batch on the same rows, ids and
  * seed; internally the batch travels in chunks (a small first one, then multiples of the number of workgroups the
  * device keeps resident) through four device slots, two alternating kernel streams and one high-priority copy stream,

@@ -30,7 +30,6 @@ struct pgi_ctx {
     unsigned long long* d_prof = nullptr;
     uint32_t* d_bucket = nullptr;  // size-bucket lists of the last ragged batch
     size_t bucket_bytes = 0;
-    uint32_t* d_relay = nullptr;   // streamed batches: device mirror of the caller's ready word + the relay lock (launch_estimate)
     // pool of private slots for the re-entrant single-pair drop-in (pgi_estimate_pose): the reference's seam is
     // called from kCoreNumber OpenMP threads (pose_graph_builder.h:391-392), so concurrent callers must overlap
     struct PairSlot {

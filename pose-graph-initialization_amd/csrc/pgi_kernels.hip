@@ -88,11 +88,6 @@ struct K1Args {
     const float* src_y1;
     const float* src_x2;
     const float* src_y2;
-    // Streamed batches (pgi_estimate_pose_batch_streamed): *ready = how many leading pairs of the batch are resident (rows,
-    // thresholds, guesses); the caller's copy stream raises it behind every chunk it uploads WHILE this launch already works on
-    // the earlier ones.  nullptr: everything was resident before the launch.
-    const uint32_t* ready;
-    uint32_t* ready_dev;  // streamed: [0] the device-side mirror of *ready the waiting workgroups poll, [1] the relay's lock, [2] "the caller is gone"
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -1090,67 +1085,6 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     prof.flush(a.prof, lane);
 }
 
-// Streamed batches: a workgroup that took pair `pair` waits until the caller's copy stream has announced it.  Thread 0 polls
-// with a SYSTEM-scope acquire load (the writer is the copy engine; the acquire also drops whatever stale lines this CU / XCD
-// holds of the just-written rows -- a cache line can straddle two chunks), the workgroup barrier passes the order on.
-// A caller that never raises the word (a failed upload, a bug) must not hang the GPU: after 4 s of the constant 100 MHz
-// clock the wait gives up and the pair is reported as PGI_EDGE_NOT_RESIDENT.  Returns false then (workgroup-uniform).
-PGI_DEV bool wait_until_resident(const K1Args& a, uint32_t pair, char* smem) {
-    uint32_t* flag = reinterpret_cast<uint32_t*>(smem);
-    if (threadIdx.x == 0) {
-        // *a.ready lies in the caller's page-locked HOST memory: thousands of waiting workgroups polling it over PCIe starve
-        // the very uploads they wait for (measured: a streamed config 4 took 0.16 s instead of 0.10 s).  So ONE workgroup at
-        // a time -- whoever holds the lock word -- reads the host word and republishes it in device memory; everybody else
-        // polls that mirror on chip.
-        // (ready_dev[2]: the first workgroup whose watchdog fires raises it, and nobody waits after that -- a launch whose caller
-        //  has gone away ends in 4 s, not in 4 s per resident workgroup and list entry)
-        uint32_t ok = 1;
-        uint32_t seen = __hip_atomic_load(a.ready_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen <= pair) {
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                if (__hip_atomic_load(a.ready_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
-                if (atomicCAS(a.ready_dev + 1, 0u, 1u) == 0u) {  // the relay
-                    for (;;) {
-                        const uint32_t v = __hip_atomic_load(a.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (v > seen) {
-                            seen = v;
-                            __hip_atomic_fetch_max(a.ready_dev, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        if (seen > pair) break;
-                        __builtin_amdgcn_s_sleep(32);
-                        if (wall_clock64() - t0 > 400000000ull || __hip_atomic_load(a.ready_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            ok = 0;
-                            break;
-                        }
-                    }
-                    __hip_atomic_store(a.ready_dev + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                for (int k = 0; k < 8; ++k) __builtin_amdgcn_s_sleep(127);
-                seen = __hip_atomic_load(a.ready_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen > pair) break;
-                if (wall_clock64() - t0 > 400000000ull) { ok = 0; break; }
-            }
-            if (!ok) __hip_atomic_store(a.ready_dev + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *flag = ok;
-    }
-    __syncthreads();
-    const bool ok = *flag != 0;
-    __syncthreads();  // everyone has read the flag: the row area is free again
-    if (!ok) {
-        const uint64_t o = a.off[pair];
-        const uint32_t n = (uint32_t)(a.off[pair + 1] - o);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) a.masks[o + i] = 0;
-        if (threadIdx.x == 0) {
-            edge_clear(a.edges + pair);
-            a.edges[pair].status = PGI_EDGE_NOT_RESIDENT;
-        }
-    }
-    return ok;
-}
-
 // The kernel: one pair per workgroup (grid = pairs), or -- a size-bucket launch -- workgroups that take entries of the
 // bucket's list: entry blockIdx.x when the grid covers the whole list, or (round 4, the default for the variants WITHOUT the
 // guess path) as a PERSISTENT grid of as many workgroups as the chip keeps resident, each taking whatever entry the shared
@@ -1184,7 +1118,7 @@ __global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args 
                 if (slot >= *a.pair_count) return;
                 pair = a.pair_list[slot];
             }
-            if (a.ready == nullptr || wait_until_resident(a, pair, smem)) estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
+            estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
             if (!persistent) return;
             __syncthreads();  // the pair's results are written, its LDS state is dead
         }
@@ -1194,7 +1128,7 @@ __global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args 
             if (blockIdx.x >= *a.pair_count) return;
             pair = a.pair_list[blockIdx.x];
         }
-        if (a.ready == nullptr || wait_until_resident(a, pair, smem)) estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
+        estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
     }
 }
 
@@ -1690,7 +1624,6 @@ void pgi_destroy(pgi_ctx* ctx) {
     }
     if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
     if (ctx->d_bucket) (void)hipFree(ctx->d_bucket);
-    if (ctx->d_relay) (void)hipFree(ctx->d_relay);
     for (int k = 0; k < 4; ++k) {
         if (ctx->hslot[k].d) (void)hipFree(ctx->hslot[k].d);
         if (ctx->hslot[k].d_bucket) (void)hipFree(ctx->hslot[k].d_bucket);
@@ -1786,8 +1719,7 @@ static uint32_t k1_rows_cap(const pgi_ctx* ctx, int wgs_per_cu, size_t fixed_byt
 // `src`: four page-locked host arrays (device-visible addresses) the rows are consumed from in place; b->d_x1..d_y2 are
 // then the device mirror for rows that do not fit in LDS.
 static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks,
-                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr,
-                           const uint32_t* d_ready = nullptr) {
+                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1803,14 +1735,7 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.pair_head = nullptr;
     a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
     a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
-    a.ready = d_ready;
-    a.ready_dev = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (d_ready) {  // the on-chip mirror of the caller's ready word and the relay's lock, zeroed in stream order before the kernels
-        if (!ctx->d_relay) HIP_TRY(hipMalloc((void**)&ctx->d_relay, 256));
-        HIP_TRY(hipMemsetAsync(ctx->d_relay, 0, 256, stream));
-        a.ready_dev = ctx->d_relay;
-    }
     // Wavefronts per pair for this call (see kMaxNW above).  Measured on the dense V = 5000 scene's rows (scripts/k1_dense_bench.py,
     // K1D_MAXPAIRS): two wavefronts per pair tie with four at 12 000 pairs and win above (-11 % at 24 000, -14 % at 48 000), one wins from about 10^5 pairs on (its
     // steady rate is 32 % above four's, but a launch winds down for 9 ms: the pairs that run to max_iters are one wavefront's work).
@@ -1934,12 +1859,6 @@ int pgi_estimate_pose_batch(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges,
     if (!ctx) return fail(PGI_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(ctx->mu);  // the size-bucket scratch belongs to the context
     return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes);
-}
-
-int pgi_estimate_pose_batch_streamed(pgi_ctx* ctx, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks, const uint32_t* d_ready) {
-    if (!ctx || !d_ready) return fail(PGI_ERR_INVALID, "null argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return launch_estimate(ctx, ctx->prm, b, d_edges, d_masks, ctx->stream, &ctx->d_bucket, &ctx->bucket_bytes, nullptr, d_ready);
 }
 
 // Page-locked inputs AND results: K1 works on the caller's buffers IN PLACE over PCIe.  The kernel reads every row exactly

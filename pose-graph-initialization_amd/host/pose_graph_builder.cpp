@@ -296,12 +296,6 @@ struct PoseGraphBuilder::Staging {
     hipStream_t copy = nullptr;
     hipEvent_t up[kRing] = {nullptr, nullptr, nullptr};
     hipEvent_t smallUp = nullptr;
-    // streamed launches (estimatePoses): the READY WORD lives in page-locked host memory the device reads in place; host
-    // functions queued on the copy stream behind the uploads raise it (no device copy, no kernel: nothing that would need a
-    // slot on a chip whose every slot holds a waiting estimation workgroup)
-    uint32_t* readyWord = nullptr;
-    struct Release { uint32_t* word; uint32_t value; };
-    std::vector<Release> releases;
     std::unique_ptr<HostPool> pool;
     std::unique_ptr<HostPool> commitPool;  // the team that writes a wave's edges into the pose graph (its own: the scheduler's helper
                                            // thread converts the NEXT wave's rows on `pool` at that very time)
@@ -332,7 +326,6 @@ struct PoseGraphBuilder::Staging {
         for (void* r : ring) if (r) (void)hipHostFree(r);
         for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
         if (smallUp) (void)hipEventDestroy(smallUp);
-        if (readyWord) (void)hipHostFree(readyWord);
         if (copy) (void)hipStreamDestroy(copy);
     }
     void init(size_t threads) {
@@ -345,7 +338,6 @@ struct PoseGraphBuilder::Staging {
             if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
         if (!smallUp && hipEventCreateWithFlags(&smallUp, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
         if (!preDone && hipEventCreateWithFlags(&preDone, hipEventDisableTiming) != hipSuccess) throw PgiError("hipEventCreate failed");
-        if (!readyWord && hipHostMalloc((void**)&readyWord, 256, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
         if (!pool || pool->size() < std::min<size_t>(threads, std::max(1u, std::thread::hardware_concurrency()))) pool.reset(new HostPool(threads));
         if (!commitPool) commitPool.reset(new HostPool(std::min<size_t>(8, std::max<size_t>(1, threads))));
     }
@@ -355,10 +347,6 @@ struct PoseGraphBuilder::Staging {
         p = nullptr; have = 0;
         if (hipHostMalloc(&p, want + want / 4, hipHostMallocDefault) != hipSuccess) throw PgiError("hipHostMalloc failed");
         have = want + want / 4;
-    }
-    static void raiseReady(void* p) {  // hipLaunchHostFunc on the copy stream: everything queued before it has landed
-        const Release* r = static_cast<const Release*>(p);  // (never lowers the word: an aborted call has raised it to the top)
-        if (r->value > __atomic_load_n(r->word, __ATOMIC_RELAXED)) __atomic_store_n(r->word, r->value, __ATOMIC_RELEASE);
     }
     void reserve(int which, size_t smallWant, size_t ringBytes, size_t devWant) {
         growHost(smallBlk[which], smallBytes[which], smallWant);
@@ -441,7 +429,7 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         maxChunkRows = std::max<size_t>(maxChunkRows, off[k1] - off[k]);
         k = k1;
     }
-    // (a short last chunk joins its predecessor: transfers of a few kilobytes are copy kernels, see the streamed launch below)
+    // (a short last chunk joins its predecessor: transfers of a few kilobytes are copy kernels, and a launch pays a fixed wind-down)
     if (chunks.size() >= 2 && off[chunks.back().k1] - off[chunks.back().k0] < chunkRows / 4) {
         const Chunk tail = chunks.back();
         chunks.pop_back();
@@ -539,39 +527,6 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
         float* const dcol[4] = {(float*)(db + o_x1), (float*)(db + o_y1), (float*)(db + o_x2), (float*)(db + o_y2)};
         size_t groupK0 = 0, groupChunks = 0, groupTarget = 1;
         uint32_t groupMaxCorr = 0;
-        // STREAMED (round 5, OPT-IN: PGI_K1_STREAMED=1): ONE launch sequence for the whole block, issued now; a workgroup that
-        // takes pair k waits until the ready word exceeds k, and host functions on the copy stream raise the word behind every
-        // group it has uploaded (pgi_estimate_pose_batch_streamed, include/pgi.h).  The block pays one wind-down instead of
-        // one per launch group.  Measured on the dense V = 5000 scene: config 4 0.0975-0.101 -> 0.0926-0.0968 s, config 5
-        // (rotation-guided) 0.1325 -> 0.1265 s, identical results -- and one first repetition of 12 s: a resident kernel that
-        // WAITS is only safe while nothing it waits for needs the chip or a hardware queue behind it.  Transfers of a few
-        // kilobytes and memsets are kernels in this runtime (a 6 KB guess-flag copy stalled every wave until the 4 s watchdog),
-        // and with four size classes the class streams, the copy stream and the default stream outnumber the hardware queues
-        // (GPU_MAX_HW_QUEUES), so a marker of the copy stream can sit behind a waiting kernel.  Off by default for that reason.
-        // Not with the reference's guess screening: its scoring launches would have to run beside the resident kernels.
-        static const bool streamedOn = [] { const char* e = std::getenv("PGI_K1_STREAMED"); return e && e[0] == '1'; }();
-        const bool streamed = streamedOn && !screen && chunks.size() > 1 && !prefetched && !rowsOnly;
-        if (streamed) {
-            uint32_t blockMaxCorr = 0;
-            for (const Chunk& ch : chunks) blockMaxCorr = std::max(blockMaxCorr, ch.maxCorr);
-            staging->releases.clear();
-            staging->releases.reserve(chunks.size() + 1);  // (the host functions keep pointers into it: never re-housed below)
-            __atomic_store_n(staging->readyWord, 0u, __ATOMIC_RELEASE);  // the previous call's kernels are long done (it synchronised)
-            pgi_batch b{};
-            b.d_x1 = dcol[0]; b.d_y1 = dcol[1]; b.d_x2 = dcol[2]; b.d_y2 = dcol[3];
-            b.d_offsets = (const uint64_t*)(db + o_off); b.d_thr = (const double*)(db + o_thr);
-            b.n_pairs = (uint32_t)L; b.max_corr = blockMaxCorr; b.pair_id_base = lo; b.seed = seed;
-            // The guesses are read IN PLACE from the page-locked mirror (97 bytes per pair, once): a copy of a few kilobytes is
-            // a copy KERNEL in this runtime, and a kernel finds no slot on a chip whose every slot holds a workgroup that waits
-            // for exactly that copy (measured: every wave ran into the 4 s watchdog).  Only copy-engine transfers and host
-            // functions may stand between a streamed launch and its data.
-            if (may_guess) { b.d_guess_Rt = (const double*)(hs + o_guess); b.d_has_guess = (const uint8_t*)(hs + o_has); }
-            Engine::check(pgi_estimate_pose_batch_streamed(engine->get(), &b, d_all + lo, (uint8_t*)(db + o_masks), staging->readyWord));
-        }
-        struct ReleaseAll {  // an exception below must not leave resident workgroups waiting for pairs that will never come
-            uint32_t* word;
-            ~ReleaseAll() { if (word) __atomic_store_n(word, 0xFFFFFFFFu, __ATOMIC_RELEASE); }
-        } releaseAll{streamed ? staging->readyWord : nullptr};
         for (size_t c = 0; c < chunks.size(); ++c) {
             const Chunk& ch = chunks[c];
             if (groupChunks == 0 && may_guess && !rowsOnly) {  // a new launch group starts here: its guesses first (A* on the host team)
@@ -617,16 +572,6 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             ++groupChunks;
             if (groupChunks < groupTarget && c + 1 < chunks.size()) continue;
             const size_t g0 = groupK0, g1 = ch.k1, n = g1 - g0;
-            if (streamed) {  // the ready word announces the pairs below g1 (their guesses, if any, are in the page-locked mirror already)
-                (void)n;
-                staging->releases.push_back(Staging::Release{staging->readyWord, (uint32_t)g1});
-                HIP_OK(hipLaunchHostFunc(copy, Staging::raiseReady, &staging->releases.back()));
-                groupK0 = g1;
-                groupChunks = 0;
-                groupMaxCorr = 0;
-                groupTarget = may_guess ? std::min<size_t>(groupTarget * 2, 4) : 1;  // (without guesses every chunk is its own release)
-                continue;
-            }
             pgi_batch b{};
             b.d_x1 = dcol[0]; b.d_y1 = dcol[1]; b.d_x2 = dcol[2]; b.d_y2 = dcol[3];  // offsets are absolute rows of the block
             b.d_offsets = (const uint64_t*)(db + o_off) + g0; b.d_thr = (const double*)(db + o_thr) + g0;
@@ -654,7 +599,6 @@ size_t PoseGraphBuilder::estimatePoses(const std::vector<ViewPair>& pairs, PoseG
             groupMaxCorr = 0;
             groupTarget = std::min<size_t>(groupTarget * 2, 4);
         }
-        releaseAll.word = nullptr;  // every release is queued: the last one announces the whole block
         if (rowsOnly) {  // the descriptor the next wave's own call recognises its rows by
             HIP_OK(hipEventRecord(staging->preDone, copy));
             staging->pre.first = (const void*)pairs.data();

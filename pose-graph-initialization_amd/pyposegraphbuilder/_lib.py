@@ -49,7 +49,7 @@ assert ROT_EDGE_DTYPE.itemsize == C.sizeof(RotEdge)
 
 # every symbol include/pgi.h declares
 SYMBOLS = ["pgi_last_error", "pgi_device_count", "pgi_default_params", "pgi_create", "pgi_destroy",
-           "pgi_set_stream", "pgi_get_stream", "pgi_get_device", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch", "pgi_estimate_pose_batch_streamed", "pgi_estimate_pose_batch_host",
+           "pgi_set_stream", "pgi_get_stream", "pgi_get_device", "pgi_set_params", "pgi_synchronize", "pgi_estimate_pose_batch", "pgi_estimate_pose_batch_host",
            "pgi_estimate_pose", "pgi_score_pose_batch", "pgi_score_pose_f64", "pgi_score_pose_f64_host", "pgi_decompose_batch", "pgi_pose_from_essential_host", "pgi_screen_guesses",
            "pgi_five_point_batch", "pgi_default_rotavg_params", "pgi_rotation_average", "pgi_desc_padded",
            "pgi_desc_prepare", "pgi_desc_prepare_screen", "pgi_match_descriptors_batch", "pgi_build_correspondences", "pgi_guided_match_batch",
@@ -123,7 +123,6 @@ def load():
     lib.pgi_guided_match_batch.argtypes = [C.c_void_p, C.POINTER(FeatureView), C.POINTER(FeatureView), C.c_uint32, C.c_void_p,
                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
-    lib.pgi_estimate_pose_batch_streamed.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose_batch_host.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.pgi_estimate_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.POINTER(Edge), C.c_void_p]

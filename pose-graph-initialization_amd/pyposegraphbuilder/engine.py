@@ -91,23 +91,6 @@ class Engine:
         L.check(self._lib.pgi_estimate_pose_batch(self._ctx, C.byref(s), _ptr(edges), _ptr(masks)))
         return edges, masks[:rows]
 
-    def estimate_pose_batch_streamed(self, b, ready, edges=None, masks=None):
-        """pgi_estimate_pose_batch_streamed (include/pgi.h): estimate_pose_batch for a batch whose rows (and guesses) may still
-        be on their way.  `ready`: a page-locked int32 / uint32 tensor of one element the DEVICE reads in place -- the number of
-        leading pairs that are resident; the caller raises it (monotonically, up to n_pairs) behind its own uploads.  Offsets
-        and thresholds must be resident at the call.  Returns at once; the work completes once `ready` has reached n_pairs."""
-        if not (ready.is_pinned() and ready.numel() >= 1 and ready.element_size() == 4):
-            raise ValueError("ready must be a page-locked 32-bit tensor")
-        P, rows = b["n_pairs"], b["x1"].numel()
-        if edges is None:
-            edges = torch.empty((P, L.EDGE_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
-        if masks is None:
-            masks = torch.empty(max(rows, 1), dtype=torch.uint8, device=self.device)
-        self._bind_stream()
-        s = self._batch_struct(b)
-        L.check(self._lib.pgi_estimate_pose_batch_streamed(self._ctx, C.byref(s), _ptr(edges), _ptr(masks), C.c_void_p(ready.data_ptr())))
-        return edges, masks[:rows]
-
     def estimate_pose_batch_host(self, x1, y1, x2, y2, offsets, thr, guesses=None, has_guess=None, seed=0, pair_id_base=0,
                                  out=None):
         """Host (numpy) SoA in, (edges structured array, masks) out; copies are pipelined against the kernels.
