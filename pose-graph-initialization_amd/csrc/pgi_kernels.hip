@@ -1095,8 +1095,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
 // loop-free build at every N when the grid covers the list) -- but 64-164 in the guess variants, which therefore keep the
 // one-pair form (-DPGI_K1_LOOP_GUESS builds them with the loop for experiments).
 template <int LDS_PTS, bool GUESS, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void estimate_pose_body(const K1Args& a, char* smem) {
 #ifdef PGI_K1_LOOP_GUESS
     constexpr bool kLoop = true;
 #else
@@ -1130,6 +1129,27 @@ __global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args 
         }
         estimate_pair<LDS_PTS, GUESS, NW>(a, pair, smem);
     }
+}
+
+template <int LDS_PTS, bool GUESS, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void estimate_pose_kernel(const K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PGI_PROFILE
+    // slot occupancy of a launch (instrumented build only, scripts/profile_phases.py): when its workgroups came and went on the
+    // 100 MHz wall clock, per rows variant: [0] sum of residence times, [1] last exit, [2] ~first start, [3] workgroups
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
+    estimate_pose_body<LDS_PTS, GUESS, NW>(a, smem);
+#ifdef PGI_PROFILE
+    if (a.prof && threadIdx.x == 0) {
+        const unsigned long long wg_t1 = wall_clock64();
+        unsigned long long* o = a.prof + kProfSlots + 4 * LDS_PTS;
+        atomicAdd(o + 0, wg_t1 - wg_t0);
+        atomicMax(o + 1, wg_t1);
+        atomicMax(o + 2, ~wg_t0);
+        atomicAdd(o + 3, 1ull);
+    }
+#endif
 }
 
 // Size buckets: dynamic LDS is per launch, so ragged batches are split by row count and every bucket

@@ -2,9 +2,10 @@
 """K1 alone on the rows of the dense V = 5000 scene (BASELINE configs 4/5 at SURVEY 8d's density: ~106 000 pairs, ~77 M rows,
 median 588 rows per pair), resident in HBM, ONE estimate_pose_batch call per repetition -- the floor of config 4's
 estimation stage.  Several builds of libpgi (paths relative to the package) are timed in one process, interleaved, and
-their result bytes compared -- or, "nw=1" / "nw=2" / "nw=4" / "nw=0" (the launcher's own rule), the default build with that
-many wavefronts per pair (PGI_K1_NW, read when the context is made):
-    k1_dense_bench.py [libpgi.so nw=1 nw=2 nw=4 nw=0 ...]
+their result bytes compared -- or, "nw=1" / "nw=2,overlap=0" / "nw=0" ..., the default build with these launcher settings
+(nw: wavefronts per pair, 0 = the launcher's own rule; minwgs / hybrid / overlap / persistent: PGI_LDS_MIN_WGS, PGI_HYBRID_ROWS,
+PGI_CLASS_OVERLAP, PGI_K1_PERSISTENT -- all read when the context is made):
+    k1_dense_bench.py [libpgi.so nw=1 nw=2,overlap=0 nw=4 nw=0 ...]
 Environment: K1D_SCENE (v5000), K1D_ROUNDS (5), K1D_PARAMS ("round_size=16,lo_iters=2": pgi_params overrides for every build),
 K1D_MAXPAIRS (all): keep only the first so-many pairs (profiling runs)."""
 import os, sys, time
@@ -18,6 +19,7 @@ import scene_drivers as SC
 from pyposegraphbuilder.engine import Engine
 
 libs = sys.argv[1:] or ["libpgi.so"]
+SPEC_ENV = {"nw": "PGI_K1_NW", "minwgs": "PGI_LDS_MIN_WGS", "hybrid": "PGI_HYBRID_ROWS", "overlap": "PGI_CLASS_OVERLAP", "persistent": "PGI_K1_PERSISTENT"}
 name = os.environ.get("K1D_SCENE", "v5000")
 t0 = time.time()
 g, _ = SC.make_scene(name)
@@ -42,13 +44,18 @@ for kv in filter(None, os.environ.get("K1D_PARAMS", "").split(",")):
 engs = []
 for path in libs:
     L._lib = None
-    if path.startswith("nw="):
-        os.environ["PGI_K1_NW"] = path[3:]
+    for v in SPEC_ENV.values():
+        os.environ.pop(v, None)
+    if "=" in path:  # "nw=1,overlap=0": the default build with these launcher settings (read when the context is made)
+        for kv in path.split(","):
+            k, v = kv.split("=")
+            os.environ[SPEC_ENV[k]] = v
         L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi.so")
     else:
-        os.environ.pop("PGI_K1_NW", None)
         L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
     e = Engine()
+    for v in SPEC_ENV.values():
+        os.environ.pop(v, None)
     if params:
         e.set_params(**params)
     engs.append(e)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K1 on uniform batches (BASELINE config 2's shape: P pairs x N rows, inlier ratio 0.5) with one / two / four wavefronts per
-pair: time per call at several P -> steady rate and wind-down of each count.  usage: k1_nw_uniform.py [N=2000] [P1,P2,...]"""
+pair: time per call at several P -> steady rate and wind-down of each count.  usage: k1_nw_uniform.py [N=2000] [P1,P2,...] ["nw=4 nw=2,persistent=0 ..."]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +10,16 @@ from pyposegraphbuilder import synthetic as S
 from pyposegraphbuilder.engine import Engine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 Ps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [5000, 10000, 20000, 40000]
+SPEC_ENV = {"nw": "PGI_K1_NW", "minwgs": "PGI_LDS_MIN_WGS", "hybrid": "PGI_HYBRID_ROWS", "overlap": "PGI_CLASS_OVERLAP", "persistent": "PGI_K1_PERSISTENT"}
+specs = sys.argv[3].split() if len(sys.argv) > 3 else ["nw=4", "nw=2", "nw=1"]  # e.g. "nw=4 nw=2,persistent=0"
 engs = {}
-for nw in (4, 2, 1):
-    os.environ["PGI_K1_NW"] = str(nw)
-    engs[nw] = Engine()
+for spec in specs:
+    for kv in spec.split(","):
+        k, v = kv.split("=")
+        os.environ[SPEC_ENV[k]] = v
+    engs[spec] = Engine()
+    for v in SPEC_ENV.values():
+        os.environ.pop(v, None)
 b = S.make_batch(np.arange(max(Ps)), N)
 for P in Ps:
     off = b["offsets"][:P + 1]
@@ -29,6 +35,6 @@ for P in Ps:
             if rep: ts.append(a.elapsed_time(z))
         by = ed.cpu().numpy().tobytes()
         ref = ref or by
-        line += "  NW=%d %.3f ms (%.2f M/s)%s" % (nw, np.median(ts), P / np.median(ts) / 1e3, "" if by == ref else " DIFFERENT")
+        line += "  %s %.3f ms (%.2f M/s)%s" % (nw, np.median(ts), P / np.median(ts) / 1e3, "" if by == ref else " DIFFERENT")
         del db
     print(line, flush=True)

@@ -38,16 +38,28 @@ else:
     N = int(N)
     b = S.make_batch(np.arange(P), N)
 db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=1)
-buf = torch.zeros(32, dtype=torch.int64, device=eng.device)
+buf = torch.zeros(32 + 12, dtype=torch.int64, device=eng.device)
 eng.estimate_pose_batch(db); torch.cuda.synchronize()
 eng._lib.pgi_internal_set_profile_buffer.argtypes = [C.c_void_p, C.c_void_p]
 eng._lib.pgi_internal_set_profile_buffer(eng._ctx, C.c_void_p(buf.data_ptr()))
 a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); e, m = eng.estimate_pose_batch(db); z.record(); torch.cuda.synchronize()
-acc = buf.cpu().numpy().astype(np.float64)
+raw = buf.cpu().numpy()
+acc = raw[:32].astype(np.float64)
 tot = acc.sum()
 got = eng.edges_to_numpy(e)
 print("P=%d N=%s budget=%d  kernel %.3f ms  hyps=%.1f lo=%.2f  (s_memtime ticks, summed over all wavefronts; PGI_K1_NW=%s)" % (
     P, N, fb, a.elapsed_time(z), got["iters"].mean(), got["lo_runs"].mean(), os.environ.get("PGI_K1_NW", "auto")))
 for i in range(25):
     print("%2d %-28s %14.0f  %6.2f%%  %10.0f ticks/pair" % (i, NAMES.get(i, ""), acc[i], 100 * acc[i] / tot, acc[i] / P))
+# slot occupancy per rows variant (one launch each): the workgroups' residence on the 100 MHz wall clock.  A persistent workgroup
+# leaves when its class's list is dry, so (1 - residence / span) is the share of slot time the launch's wind-down leaves empty.
+occ = raw[32:].view(np.uint64).reshape(3, 4)
+used = [i for i in range(3) if occ[i, 3]]
+t_first = min(int(~occ[i, 2] & 0xFFFFFFFFFFFFFFFF) for i in used)
+for i in used:
+    start, end = int(~occ[i, 2] & 0xFFFFFFFFFFFFFFFF), int(occ[i, 1])
+    span = (end - start) / 1e5
+    print("rows variant %d: %6d workgroups, first start %8.3f ms, last exit %8.3f ms (span %7.3f ms), mean residence %7.3f ms = %.1f %% of the span" % (
+        i, occ[i, 3], (start - t_first) / 1e5, (end - t_first) / 1e5, span, occ[i, 0] / occ[i, 3] / 1e5,
+        100.0 * occ[i, 0] / occ[i, 3] / 1e5 / max(span, 1e-9)))
