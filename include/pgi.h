@@ -66,9 +66,9 @@ typedef struct {
     uint32_t lo_linear_pct; /* local optimisation refits an inlier set of at least this many percent of the rows
                                LINEARLY (smallest eigenvector of the 9x9 normal matrix = least-squares epipolar
                                matrix): as accurate as the n-point Nister refit there and several times cheaper;
-                               smaller sets keep the Nister refit.  Default 35; 0 = always Nister.  A final model
+                               smaller sets keep the Nister refit.  Default 35; 0 = always Nister.  A fitted model
                                that comes from a linear refit is not exactly rank 2; R and t come from its SVD
-                               (pose_utils.h:144-169) like for any other E */
+                               (pose_utils.h:144-169) like for any other model, and pgi_edge.E is rebuilt from them */
     uint32_t sampler;       /* 0 = uniform 5-row samples (default).  1 = progressive ("optionally PROSAC --
                                matches are already sorted by SNN ratio", feature_utils.h:184-186): hypothesis h draws its
                                five rows from the FIRST n(h) rows only, n(h) = max(5, floor(N * (s / 64)^(1/5))),
@@ -81,7 +81,11 @@ typedef struct {
 /* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.
  * 200 bytes, identical on host and device. */
 typedef struct {
-    double E[9];       /* essential matrix, row-major, unit Frobenius norm          */
+    double E[9];       /* status PGI_EDGE_OK: the essential matrix OF THE RETURNED POSE, [t]x R (pose_utils.h:74-86)
+                          row-major at unit Frobenius norm, with the fitted model's sign -- rank 2 with two equal
+                          singular values to 1e-15, as cv::findEssentialMat's E is in the reference
+                          (pose_graph_builder.h:1057-1066); the inlier mask and n_inl belong to the FITTED model, whose
+                          decomposition R, t are.  Any other status: the fitted model (f32 values), if there is one */
     double R[9];       /* R_dst_src row-major   (Sophus::SE3d rotation, :1073-1075)  */
     double t[3];       /* unit t_dst_src                                            */
     int32_t status;    /* PGI_EDGE_*                                                */

@@ -1293,6 +1293,18 @@ void pgo_estimate_pose(const float* x1, const float* y1, const float* x2, const 
     out->votes = votes[cand];
     out->cand = cand;
     out->status = (has_nan(out->R, 9) || has_nan(out->t, 3)) ? PGO_FAIL_NAN : PGO_OK;
+    /* The record's E is the essential matrix OF THE RETURNED POSE: [t]x R (pose_utils.h:74-86) at unit Frobenius norm
+     * (|t| = 1, so the norm of [t]x R is sqrt 2), with the sign of the fitted model.  The reference hands
+     * getPoseFromEssentialMatrix a rank-2 E from cv::findEssentialMat (pose_graph_builder.h:1057-1066); a model from the
+     * linear refit is only close to the manifold, and a caller that builds F from E (matcher.h:216-217) must not get it.
+     * The mask refers to the fitted model (it is the model's inlier set); R, t are its decomposition. */
+    if (out->status == PGO_OK) {
+        double Ex[9], dot = 0.0;
+        pgo_ref_essential_from_pose(out->R, out->t, Ex);
+        for (int m = 0; m < 9; ++m) dot = fma(Ex[m], out->E[m], dot);
+        const double sc = dot < 0.0 ? -0.70710678118654752440 : 0.70710678118654752440;
+        for (int m = 0; m < 9; ++m) out->E[m] = Ex[m] * sc;
+    }
 }
 
 int pgo_num_threads(void) {

@@ -1079,6 +1079,29 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
             edge->votes = bv;
             edge->cand = best;
             edge->status = bad ? PGI_EDGE_NAN : PGI_EDGE_OK;  // :1069-1070
+            if (!bad) {
+                // E of the record = the essential matrix OF THE RETURNED POSE, [t]x R (pose_utils.h:74-86) at unit Frobenius
+                // norm with the fitted model's sign: rank 2 whatever refit the model came from (the reference's E is
+                // cv::findEssentialMat's, pose_graph_builder.h:1057-1066).  Operation order of pgo_estimate_pose.
+                const double ts = (best & 1u) ? -1.0 : 1.0;
+                const double t0 = ts * tt[0], t1 = ts * tt[1], t2 = ts * tt[2];
+                const double tx[9] = {0, -t2, t1, t2, 0, -t0, -t1, t0, 0};
+                double Ex[9], dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double sacc = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) sacc += tx[3 * i + k] * (second ? R2[3 * k + j] : R1[3 * k + j]);
+                        Ex[3 * i + j] = sacc;
+                    }
+#pragma unroll
+                for (int m = 0; m < 9; ++m) dot = fma(Ex[m], (double)finalE[m], dot);
+                const double sc = dot < 0.0 ? -0.70710678118654752440 : 0.70710678118654752440;
+#pragma unroll
+                for (int m = 0; m < 9; ++m) edge->E[m] = Ex[m] * sc;
+            }
         }
     }
     prof.mark<24>();

@@ -279,16 +279,19 @@ def test_full_size_properties(eng):
         assert abs(np.linalg.norm(E) - 1) < 1e-6 and abs(np.linalg.det(R) - 1) < 1e-9 and abs(t @ t - 1) < 1e-9
         Et = np.cross(np.eye(3), t) @ R
         Et /= np.linalg.norm(Et)
-        # E is the model the mask refers to.  After a LINEAR refit (lo_linear_pct) it is the least-squares epipolar
-        # matrix -- within a few 1e-3 of the essential matrix [t]x R its SVD yields; see the strict check below
+        # E is the essential matrix OF THE RETURNED POSE (round 6): [t]x R at unit norm, rank 2 whatever refit the fitted
+        # model came from (after a LINEAR refit the model itself is only within a few 1e-3 of the manifold -- a caller
+        # that builds F from E, matcher.h:216-217, must not get that)
         dev_lin.append(min(np.linalg.norm(Et - E), np.linalg.norm(Et + E)))
-        assert dev_lin[-1] < 2e-2
+        assert dev_lin[-1] < 1e-9
+        sv = np.linalg.svd(E, compute_uv=False)
+        assert abs(sv[0] - sv[1]) < 1e-9 and sv[2] < 1e-9
         a0, a1 = int(b["offsets"][i]), int(b["offsets"][i + 1])
         assert got["n_inl"][i] == m[a0:a1].sum()
     errs = [S.rot_err_deg(got["R"][i].reshape(3, 3), b["R"][i]) if ok[i] else np.inf for i in range(512)]
     assert S.auc_at(errs) > 0.97
-    print("||E - [t]x R|| after linear refits: median %.2e max %.2e" % (np.median(dev_lin), np.max(dev_lin)))
-    # with the Nister refit only (lo_linear_pct = 0) every returned E is an essential matrix: E == [t]x R up to sign
+    print("||E - [t]x R|| at the default lo_linear_pct: median %.2e max %.2e" % (np.median(dev_lin), np.max(dev_lin)))
+    # ... and with the Nister refit only (lo_linear_pct = 0)
     try:
         eng.set_params(lo_linear_pct=0)
         g0 = eng.edges_to_numpy(eng.estimate_pose_batch(db)[0])
@@ -296,7 +299,7 @@ def test_full_size_properties(eng):
             E, R, t = g0["E"][i].reshape(3, 3), g0["R"][i].reshape(3, 3), g0["t"][i]
             Et = np.cross(np.eye(3), t) @ R
             Et /= np.linalg.norm(Et)
-            assert min(np.linalg.norm(Et - E), np.linalg.norm(Et + E)) < 1e-5
+            assert min(np.linalg.norm(Et - E), np.linalg.norm(Et + E)) < 1e-9
     finally:
         eng.set_params(lo_linear_pct=35)
     # the oracle agrees on a bounded sample of the same workload
