@@ -72,6 +72,7 @@ struct pgi_ctx {
     int resident_wgs = 768;  // workgroups of K1 the device keeps resident (CUs x 3): the chunk quantum of the host path
     void* d_match_ws = nullptr;  // descriptor-matching workspace (views, partial top-2, column best)
     size_t match_ws_bytes = 0;
+    size_t guided_arena_cap = ~(size_t)0;  // bytes the guided scan's list arena may take (lowered when the device runs short; pgi_match.hip)
     uint32_t* d_match_cnt = nullptr;  // per-pair flagged-row counters of the last screened match (forward, then backward)
     uint32_t match_cnt_pairs = 0;
     void* h_match_stage[2] = {nullptr, nullptr};  // page-locked mirrors of the screened matcher's pair tables, used in turn

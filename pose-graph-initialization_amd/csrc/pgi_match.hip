@@ -2704,7 +2704,7 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<GuidedPair> hp(n_pairs);
-    uint64_t total = 0, total2 = 0;
+    uint64_t total = 0, total2 = 0, active_waves = 0;  // active_waves: wavefronts of 64 sources that hold at least one source
     uint32_t max_n1 = 0, max_kp = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
         const pgi_feature_view &a = h_src[p], &b = h_dst[p];
@@ -2759,6 +2759,7 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         hp[p] = g;
         total += a.n;
         total2 += b.n;
+        active_waves += (a.n + 63u) / 64u;
         max_n1 = a.n > max_n1 ? a.n : max_n1;
         max_kp = std::max(max_kp, std::max(a.n, b.n));
     }
@@ -2783,18 +2784,35 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
     const char* split_txt = getenv("PGI_GUIDED_SPLIT");
     const char* cap_txt0 = getenv("PGI_GUIDED_CAP");
     const char* lanes_txt0 = getenv("PGI_GUIDED_LANES");
-    const bool split = angular && !(split_txt && atoi(split_txt) == 0) && !cap_txt0 && !(lanes_txt0 && atoi(lanes_txt0) != 0);
+    bool split = angular && !(split_txt && atoi(split_txt) == 0) && !cap_txt0 && !(lanes_txt0 && atoi(lanes_txt0) != 0);
     // words of arena per wavefront on average (a round's block reserves ~1800 at 24 candidates per source, about a sixth of the
     // wavefronts take a second one); PGI_GUIDED_ARENA_WORDS shrinks it (tests: wavefronts that do not fit are redone in one kernel)
     const char* aw_txt = getenv("PGI_GUIDED_ARENA_WORDS");
     const size_t kDealWords = aw_txt && atoi(aw_txt) > 0 ? (size_t)atoi(aw_txt) : 2560;
-    const size_t deal_waves = (size_t)((max_n1 + 63u) / 64u) * n_pairs;
+    const size_t deal_waves = (size_t)((max_n1 + 63u) / 64u) * n_pairs;  // the launch's wavefront index space (tables: 8 bytes each)
+    // The ARENA is sized by the wavefronts that hold sources (the sum of ceil(n1 / 64) over the pairs), not by the largest view
+    // times the pairs (round 5: 2048 pairs with one 20 000-keypoint view among 2 000-keypoint ones asked for 6.5 GB), and it is
+    // capped -- by what the device had free when the workspace last had to grow (ctx->guided_arena_cap), and by the 32-bit word
+    // offsets of a part.  A smaller arena is not an error: wavefronts whose lists do not fit are flagged and redone by the
+    // one-kernel scan (guided_redo_kernel); without any arena the call runs the one-kernel scan outright.
     // (a part serves every 64th wavefront: small launches get room for a dozen blocks per part whatever the average says)
-    const size_t deal_part_words = split ? std::max<size_t>((deal_waves * kDealWords + kDealArenas - 1) / kDealArenas, aw_txt ? 0 : 32768) : 0;
-    const size_t deal_table_bytes = split ? ((kDealArenas + 2 * deal_waves) * 4 + 255) / 256 * 256 : 0;
-    const size_t deal_arena_bytes = split ? (deal_part_words * kDealArenas * 4 + 255) / 256 * 256 : 0;
-    const size_t bytes = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + ga_entry_bytes + ga_key_bytes +
-                         ga_start_bytes + deal_table_bytes + deal_arena_bytes + 256;
+    const size_t part_words_max = 0xFFFFFFFFull / kDealArenas - 1;
+    auto part_words_for = [&](size_t arena_bytes_cap) -> size_t {
+        size_t w = std::max<size_t>(((size_t)active_waves * kDealWords + kDealArenas - 1) / kDealArenas, aw_txt ? 0 : 32768);
+        w = std::min(w, part_words_max);
+        return std::min(w, arena_bytes_cap / (4 * kDealArenas));
+    };
+    if (const char* e = getenv("PGI_GUIDED_ARENA_CAP_MB"))  // (tests: a device that is short of memory)
+        ctx->guided_arena_cap = std::min(ctx->guided_arena_cap, (size_t)std::max(0, atoi(e)) << 20);
+    size_t deal_part_words = split ? part_words_for(ctx->guided_arena_cap) : 0;
+    if (split && deal_part_words < 4096 && !aw_txt) split = false;  // (a cap that leaves no useful arena)
+    if (!split) deal_part_words = 0;
+    const size_t deal_table_bytes_split = ((kDealArenas + 2 * deal_waves) * 4 + 255) / 256 * 256;
+    size_t deal_table_bytes = split ? deal_table_bytes_split : 0;
+    size_t deal_arena_bytes = split ? (deal_part_words * kDealArenas * 4 + 255) / 256 * 256 : 0;
+    const size_t bytes_fixed = pair_bytes + 5 * slot + so_bytes + do_bytes + rec_bytes + st_bytes + kept_bytes + ga_entry_bytes + ga_key_bytes +
+                               ga_start_bytes + 256;
+    size_t bytes = bytes_fixed + deal_table_bytes + deal_arena_bytes;
     if (bytes > ctx->match_ws_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->d_match_ws) (void)hipFree(ctx->d_match_ws);
@@ -2802,7 +2820,33 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
         ctx->match_ws_bytes = 0;
         ctx->d_match_cnt = nullptr;  // diagnostics pointer into the old workspace
         ctx->match_cnt_pairs = 0;
-        HIP_TRY(hipMalloc(&ctx->d_match_ws, bytes));
+        if (split) {  // the arena may take half of what is free now, and never what the rest of the workspace needs
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t room = free_b / 2 > bytes_fixed + deal_table_bytes ? free_b / 2 - bytes_fixed - deal_table_bytes : 0;
+                if (deal_arena_bytes > room) {
+                    ctx->guided_arena_cap = room;
+                    deal_part_words = part_words_for(room);
+                    if (deal_part_words < 4096) { split = false; deal_part_words = 0; deal_table_bytes = 0; }
+                    deal_arena_bytes = split ? (deal_part_words * kDealArenas * 4 + 255) / 256 * 256 : 0;
+                    bytes = bytes_fixed + deal_table_bytes + deal_arena_bytes;
+                }
+            }
+        }
+        hipError_t me = hipMalloc(&ctx->d_match_ws, bytes);
+        if (me != hipSuccess && split) {  // no room for the lists: the one-kernel scan needs none
+            (void)hipGetLastError();
+            ctx->d_match_ws = nullptr;
+            ctx->guided_arena_cap = 0;
+            split = false;
+            deal_part_words = 0; deal_table_bytes = 0; deal_arena_bytes = 0;
+            bytes = bytes_fixed;
+            me = hipMalloc(&ctx->d_match_ws, bytes);
+        }
+        if (me != hipSuccess) {
+            ctx->d_match_ws = nullptr;
+            return pgi::fail(PGI_ERR_DEVICE, std::string("pgi_guided_match_batch: hipMalloc of the workspace: ") + hipGetErrorString(me));
+        }
         ctx->match_ws_bytes = bytes;
     }
     ctx->d_match_cnt = nullptr;  // the workspace is repurposed: the last screened match's counters are gone
@@ -2847,7 +2891,7 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
                     n_pairs, 100 * got[0] / all, 100 * got[2] / all, 100 * got[3] / all, 100 * got[4] / all, 100 * got[5] / all, 100 * got[6] / all,
                     all / flat_blocks, flat_blocks);
         }
-        else if (lanes_env == 0 && split && cap_env == kGfCap && deal_part_words < 0xFFFFFFFFull / kDealArenas) {
+        else if (lanes_env == 0 && split && cap_env == kGfCap) {
             char* dq = q + ga_start_bytes;
             DealOut dout;
             dout.heads = (uint32_t*)dq;
@@ -2871,7 +2915,7 @@ int pgi_guided_match_batch(pgi_ctx* ctx, const pgi_feature_view* h_src, const pg
                 for (uint32_t k = 0; k < kDealArenas; ++k) { used += std::min<uint32_t>(h[k], dout.part_words); fullest = std::max(fullest, h[k]); }
                 for (size_t k = 0; k < deal_waves; ++k) redone += h[kDealArenas + deal_waves + k];
                 fprintf(stderr, "[pgi] guided scan arena (%u pairs): %.1f MB of %.1f MB used (%.0f words per wavefront, fullest part %.0f %%), %llu of %zu wavefronts redone\n",
-                        n_pairs, used * 4e-6, (double)deal_part_words * kDealArenas * 4e-6, (double)used / deal_waves,
+                        n_pairs, used * 4e-6, (double)deal_part_words * kDealArenas * 4e-6, (double)used / std::max<uint64_t>(1, active_waves),
                         100.0 * fullest / dout.part_words, (unsigned long long)redone, deal_waves);
             }
         }

@@ -340,3 +340,50 @@ def test_gpu_guided_match_binned_images_beyond_the_bin_scan_limit(eng):
     keep_o, keep_g = ~frag[oi].astype(bool), ~frag[gi].astype(bool)
     assert len(oi) > 500
     assert np.array_equal(gi[keep_g], oi[keep_o]) and np.array_equal(gj[keep_g], oj[keep_o]) and np.array_equal(gr[keep_g], orr[keep_o])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap_mb", [1, 0])
+def test_gpu_guided_arena_is_sized_by_the_sources_and_capped(cap_mb, monkeypatch):
+    """the two-kernel scan's list arena.  (i) Its size follows the wavefronts that hold sources -- a batch
+    with ONE large view among small ones must not reserve the large view's share for every pair.  (ii) It is capped by what the
+    device has free (here: PGI_GUIDED_ARENA_CAP_MB): with 1 MB most wavefronts' lists do not fit and are redone by the
+    one-kernel scan, with 0 the call runs the one-kernel scan outright -- never an error, always the uncapped result."""
+    import torch
+    from pyposegraphbuilder import Engine
+    base, poses, cam = scene(41, 10000, 10000)                 # three views of 20 000 keypoints
+    sizes = [20000, 300, 400, 500, 350, 250, 450, 380, 320]     # ... cut into one large view among small ones
+    views = [dict(xy=base[k % 3]["xy"][:n], desc=base[k % 3]["desc"][:n]) for k, n in enumerate(sizes)]
+    sizes = [len(v["xy"]) for v in views]
+    pairs = [(k, (k + 1) % len(sizes)) for k in range(len(sizes))] * 8   # 72 pairs, the large view is the source of 8
+    rt = np.zeros((len(pairs), 12))
+    for p, (s_, d_) in enumerate(pairs):
+        R, t = rel_pose(poses, s_ % 3, d_ % 3)
+        rt[p, :9], rt[p, 9:] = np.asarray(R).ravel(), t
+    monkeypatch.delenv("PGI_GUIDED_LANES", raising=False)
+    monkeypatch.delenv("PGI_GUIDED_ARENA_CAP_MB", raising=False)
+
+    def run():
+        e = Engine()
+        try:
+            feats = [e.upload_features(v["xy"], v["desc"], *cam) for v in views]
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+            out = e.guided_match_batch(feats, pairs, rt, max_n=0, n_bins=45)
+            torch.cuda.synchronize()
+            return out, free0 - torch.cuda.mem_get_info()[0]
+        finally:
+            e.close()
+    ref, ws_uncapped = run()
+    # (i) sum of ceil(n1 / 64) wavefronts x 2560 words (10 KB), not ceil(max n1 / 64) x pairs x 10 KB (= 230 MB here)
+    waves = sum((sizes[s_] + 63) // 64 for s_, _ in pairs)
+    worst = ((max(sizes) + 63) // 64) * len(pairs)
+    assert waves * 5 < worst
+    assert ws_uncapped < waves * 10240 + (96 << 20), (ws_uncapped, waves)
+    monkeypatch.setenv("PGI_GUIDED_ARENA_CAP_MB", str(cap_mb))
+    got, ws_capped = run()
+    assert ws_capped <= ws_uncapped
+    assert sum(len(g[0]) for g in ref) > 100
+    for g, r in zip(got, ref):
+        for a, b in zip(g, r):
+            assert np.array_equal(a, b, equal_nan=True)
