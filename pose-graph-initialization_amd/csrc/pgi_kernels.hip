@@ -1809,7 +1809,9 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
-        launch_k1(nw, 0, guesses, grid_of(), fixed_stash, ls, a);
+        // (the rows-from-memory variant exists at four wavefronts per pair only; below that the hybrid variant with an empty LDS
+        //  part is the same thing -- launch_k1 would otherwise have nothing to launch and the pairs' records would stay unwritten)
+        launch_k1(nw, nw < 4 ? 2 : 0, guesses, grid_of(), fixed_stash, ls, a);
     };
     const uint32_t cap = (b->max_corr + 63u) & ~63u;
     // The kernel is compiled for 128 VGPRs (four wavefronts per SIMD), so LDS decides the occupancy: pairs of up to
@@ -1873,13 +1875,14 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
 #else
             a.pair_head = ctx->k1_persistent && !guesses ? heads + k : nullptr;  // (the guess variants have no loop)
 #endif
-            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : k == 1 && ctx->hybrid_rows ? kLevelWgs[0] : kLevelWgs[k];
+            const bool hybrid_class = k == 1 && (ctx->hybrid_rows || nw < 4);  // (below four wavefronts per pair there are two classes only)
+            class_wgs = k == 4 || (k < 4 && caps[k] > lds_cap) ? kLevelWgs[0] : hybrid_class ? kLevelWgs[0] : kLevelWgs[k];
             const bool side = overlap && k < n_classes - 1;  // the last (largest-row) class stays on the caller's stream
             ls = side ? ctx->class_stream[k] : stream;
             if (side && !keep(hipStreamWaitEvent(ls, ctx->class_fork, 0))) break;
             // class 1 (cap4 < rows <= cap3): with `hybrid_rows` the first cap4 rows stay in LDS and the tail is read
             // from HBM/L2, which keeps four workgroups per CU instead of three
-            hybrid = k == 1 && ctx->hybrid_rows;
+            hybrid = hybrid_class;
             if (hybrid) launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));  // 1280 rows in LDS next to the sample stash (NW = 4)
             else if (k < 4 && caps[k] <= lds_cap) launch_lds(std::min(caps[k], cap)); else launch_global();
             hybrid = false;

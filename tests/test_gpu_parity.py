@@ -529,3 +529,289 @@ def test_host_buffer_batch_equals_device_batch():
         eng.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_page_locked_host_batch_equals_device_batch(direct, monkeypatch):
+    """Page-locked inputs and results: K1 works on them in place over PCIe (rows beyond the LDS part go through a device
+    mirror); PGI_HOST_DIRECT=0 pipelines copies through HBM instead.  Both must equal one launch on resident data -- every size class (LDS,
+    hybrid, two-workgroup LDS, rows from L2), with and without guesses, uniform small pairs (no mirror) and ragged ones."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_HOST_DIRECT", direct)
+    rng = np.random.default_rng(77)
+    eng = Engine()
+    try:
+        for case, (P, choices) in enumerate([(2600, [5, 40, 64, 300, 700, 1300, 1500, 2100, 2600, 4100, 9000]), (900, [200, 640, 1000])]):
+            sizes = rng.choice(choices, P)
+            b = S.make_batch(np.arange(7000, 7000 + P), sizes)
+            guesses = np.zeros((P, 12))
+            has = (rng.random(P) < 0.2).astype(np.uint8)
+            for i in np.nonzero(has)[0]:
+                guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
+            for use_guess in ([True, False] if case == 0 else [False]):
+                kw = dict(guesses=guesses, has_guess=has) if use_guess else {}
+                db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=3, pair_id_base=55, **kw)
+                e, m = eng.estimate_pose_batch(db)
+                ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+                xs = [np.array(b[k], np.float32) for k in ("x1", "y1", "x2", "y2")]
+                out = (np.zeros(P, ref.dtype), np.zeros(len(ref_m), np.uint8))
+                eng.pin(*xs, *out)
+                try:
+                    for rep in range(2):   # the second call reuses the mirror and the staging block
+                        out[0][:] = 0
+                        out[1][:] = 7
+                        got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=55, out=out, **kw)
+                        assert np.array_equal(got_m, ref_m)
+                        for k in ref.dtype.names:
+                            assert np.array_equal(got[k], ref[k]), k
+                    # page-locked inputs, pageable results: the copy pipeline
+                    got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=55, **kw)
+                    assert np.array_equal(got_m, ref_m) and np.array_equal(got["E"], ref["E"])
+                finally:
+                    eng.unpin(*xs, *out)
+    finally:
+        eng.close()
+
+
+def test_partially_page_locked_buffers_are_refused(eng):
+    """A caller may have page-locked a shorter range than the batch needs (a pinned slice of a larger array).  The HIP
+    runtime rejects copies that leave a registered range and a kernel working in place would fault past its end, so the
+    call checks both ends of every range up front and fails loudly; fully registered and fully pageable buffers work."""
+    from pyposegraphbuilder import _lib as L
+    P = 700
+    b = S.make_batch(np.arange(9100, 9100 + P), 600)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=5, pair_id_base=9)
+    e, m = eng.estimate_pose_batch(db)
+    ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+    xs = [np.array(b[k], np.float32) for k in ("x1", "y1", "x2", "y2")]
+    out = (np.zeros(P, ref.dtype), np.zeros(len(ref_m), np.uint8))
+    for part in ([xs[0][:len(xs[0]) // 2]], [out[1][:len(out[1]) // 3]], [xs[2][len(xs[2]) // 2:]]):   # a head, a head, a tail
+        eng.pin(*part)
+        try:
+            with pytest.raises(L.PgiError, match="only in part"):
+                eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=5, pair_id_base=9, out=out)
+        finally:
+            eng.unpin(*part)
+    got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=5, pair_id_base=9, out=out)
+    assert np.array_equal(got_m, ref_m) and np.array_equal(got["E"], ref["E"])
+
+
+def test_rotation_guided_guess_mode_matches_oracle(eng):
+    """guess_mode = 1 (BASELINE config 5): keep the guess's rotation, re-estimate the translation direction
+    from 32 two-point hypotheses, local optimisation, accept at min_inliers, else the robust fit -- bit-identical to the
+    oracle, and a chained pose with a good rotation but a meaningless translation now yields the right edge (the
+    reference's own guess path, mode 0, accepts garbage there because of its un-squared inlier bound)."""
+    sizes = [300, 1000, 64, 2000, 150, 2500, 700, 90]
+    rhos = [0.5, 0.3, 0.6, 0.7, 0.2, 0.5, 0.1, 0.5]
+    ids = np.arange(9100, 9100 + len(sizes))
+    parts = [S.make_pair(int(i), n, inlier_ratio=r) for i, n, r in zip(ids, sizes, rhos)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    cat = lambda k: np.concatenate([p[k] for p in parts])
+    rng = np.random.default_rng(5)
+    guesses = np.zeros((len(sizes), 12))
+    has = np.ones(len(sizes), np.uint8)
+    for i, p in enumerate(parts):
+        Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(0.5)) @ p["R"]       # chained rotation: half a degree off
+        if i == 2:
+            Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(40.0)) @ p["R"]  # a wrong rotation: falls back to the robust fit
+        guesses[i] = np.r_[Rg.ravel(), rng.standard_normal(3)]                    # translation: meaningless
+    has[5] = 0                                                                    # one pair without a guess
+    thr = 7.5e-4
+    db = eng.upload(cat("x1"), cat("y1"), cat("x2"), cat("y2"), off, thr, guesses=guesses, has_guess=has, seed=21, pair_id_base=400)
+    try:
+        eng.set_params(guess_mode=1)
+        edges, masks = eng.estimate_pose_batch(db)
+        got, gm = eng.edges_to_numpy(edges), masks.cpu().numpy()
+        exp, em = O.estimate_pose_batch(cat("x1"), cat("y1"), cat("x2"), cat("y2"), off, thr, O.default_params(guess_mode=1), 21,
+                                        pair_id_base=400, guesses=guesses, has_guess=has)
+        assert np.array_equal(gm, em)
+        for f in ("E", "status", "n_inl", "score", "iters", "used_guess", "lo_runs", "cand", "votes"):
+            assert np.array_equal(got[f], exp[f]), f
+        np.testing.assert_allclose(got["R"], exp["R"], atol=1e-12)
+        assert list(got["used_guess"]) == [1, 1, 0, 1, 1, 0, got["used_guess"][6], 1] and got["iters"][0] == 32
+        for i in (0, 1, 3, 4, 7):
+            assert S.rot_err_deg(got["R"][i].reshape(3, 3), parts[i]["R"]) < 2.0   # pair 4 has ~30 inliers of 150 rows
+        # the reference's guess path on the same input accepts the chained pose's garbage
+        eng.set_params(guess_mode=0)
+        e0 = eng.edges_to_numpy(eng.estimate_pose_batch(db)[0])
+        bad = [S.rot_err_deg(e0["R"][i].reshape(3, 3), parts[i]["R"]) for i in (0, 1, 3) if e0["status"][i] == 1]
+        assert max(bad) > 5.0
+    finally:
+        eng.set_params(guess_mode=0)
+
+
+def test_host_scoring_seam_from_twenty_threads(eng):
+    """pgi_score_pose_f64_host -- the seam EssentialMatrixEvaluator::getInliers (graph_traversal.h:136-168) and
+    InTraversalPoseTester::test (:194-233) sit behind inside A* -- called like the reference calls it: 20 threads, 1000 calls
+    each, host pointers, no shared state.  Every answer equals the literal restatements pgo_ref_get_inliers /
+    pgo_ref_pose_test (index lists; (true, kMin) at the early exit, (false, count) otherwise)."""
+    import threading
+    sizes = [50, 64, 257, 600, 1000, 2000, 5, 1]
+    b = S.make_batch(range(8800, 8800 + len(sizes)), sizes)
+    thr = 7.5e-4
+    cases = []
+    rng = np.random.default_rng(12)
+    for p, n in enumerate(sizes):
+        a, z = int(b["offsets"][p]), int(b["offsets"][p + 1])
+        corr = np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1).astype(np.float64)
+        good = (b["R"][p], b["t"][p])
+        ax = rng.standard_normal(3)
+        bad = (S.rodrigues(ax / np.linalg.norm(ax), 0.4) @ b["R"][p], b["t"][p][::-1].copy())
+        for R, t in (good, bad):
+            E = O.ref_essential_from_pose(R, t)
+            for kmin in (5, 20, 100000):
+                ok, cnt = O.ref_pose_test(corr, R, t, 1.5 * thr, kmin)
+                cases.append(("test", corr, E, (1.5 * thr) ** 2, kmin, (ok, cnt)))
+            for tau in (1.5 * thr, (1.5 * thr) ** 2):          # the un-squared quirk bound (:164) and the squared one
+                cases.append(("inliers", corr, E, tau, 0, O.ref_get_inliers(corr, E, tau)))
+    errors = []
+
+    def worker(tid):
+        r = np.random.default_rng(100 + tid)
+        try:
+            for _ in range(1000):
+                kind, corr, E, tau2, kmin, exp = cases[int(r.integers(len(cases)))]
+                if kind == "test":
+                    reached, cnt, _ = eng.score_pose_host(corr, E, tau2, early_exit_at=kmin, want_mask=False)
+                    if (reached, cnt) != exp:
+                        errors.append((tid, kind, len(corr), kmin, (reached, cnt), exp))
+                else:
+                    reached, cnt, mask = eng.score_pose_host(corr, E, tau2)
+                    if reached or cnt != len(exp) or not np.array_equal(np.nonzero(mask)[0], exp):
+                        errors.append((tid, kind, len(corr), cnt, len(exp)))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(20)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    # with a mask wanted the scan is complete even when an early-exit level is given
+    kind, corr, E, tau2, _, exp = next(c for c in cases if c[0] == "inliers" and len(c[1]) == 2000)
+    reached, cnt, mask = eng.score_pose_host(corr, E, tau2, early_exit_at=5)
+    assert reached and cnt == 5 and np.array_equal(np.nonzero(mask)[0], exp)
+    # empty input
+    assert eng.score_pose_host(np.zeros((0, 4)), np.eye(3), 1.0, early_exit_at=5, want_mask=False)[:2] == (False, 0)
+
+
+def test_config2_at_full_size_equals_the_oracle(eng):
+    """BASELINE config 2 in the suite at its stated size -- all 10 000 pairs x 2 000 correspondences, bench.py's own ids and
+    seed -- against the CPU oracle on every pair (OpenMP over the box's cores: about a second): identical masks, models,
+    counts, iteration and refit numbers; R within 1e-4 rad, t-direction cosine within 1e-3 (north_star's bars)."""
+    P, N, seed, thr = 10000, 2000, 0xB0BA, 7.5e-4
+    b = S.make_batch(np.arange(P), N)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, seed=seed, pair_id_base=0)
+    edges, masks = eng.estimate_pose_batch(db)
+    got = eng.edges_to_numpy(edges)
+    exp, emasks = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], thr, O.default_params(), seed,
+                                        pair_id_base=0)
+    assert np.array_equal(masks.cpu().numpy(), emasks)                     # identical inlier masks, 20 M rows
+    assert np.array_equal(got["E"], exp["E"])
+    for k in ("status", "n_inl", "score", "iters", "lo_runs", "votes", "cand", "used_guess"):
+        assert np.array_equal(got[k], exp[k]), k
+    ok = exp["status"] == 1
+    assert ok.sum() >= 0.999 * P
+    Rg, Re = got["R"][ok].reshape(-1, 3, 3), exp["R"][ok].reshape(-1, 3, 3)
+    ang = np.arccos(np.clip((np.einsum("kij,kij->k", Rg, Re) - 1) / 2, -1, 1))
+    assert ang.max() < R_TOL_RAD
+    assert np.einsum("ki,ki->k", got["t"][ok], exp["t"][ok]).min() > 1 - T_COS_TOL
+    errs = np.array([S.rot_err_deg(got["R"][i].reshape(3, 3), b["R"][i]) if ok[i] else np.inf for i in range(P)])
+    assert S.auc_at(errs) > 0.985
+
+
+def test_config1_single_pair_of_2000_correspondences(eng):
+    """BASELINE config 1 ("single pair, 2k synthetic corrs", the examples/cpp_example.cpp path): exactly N = 2000 through the
+    literal seam pgi_estimate_pose (host pointers, cv::Mat N x 4 CV_64F layout), with and without a pose guess, against
+    the oracle's pgo_estimate_pose."""
+    d = S.make_pair(424242, 2000)
+    corr = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1).astype(np.float64)
+    assert corr.shape == (2000, 4)
+    thr, seed, pid = 7.5e-4, 31, 424242
+    guess = np.concatenate([d["R"].ravel(), d["t"]])
+    for g in (None, guess):
+        ok, e, mask = eng.estimate_pose(corr, thr, guesses=None if g is None else g[None], seed=seed, pair_id=pid)
+        oe, omask = O.estimate_pose(d["x1"], d["y1"], d["x2"], d["y2"], thr, g, O.default_params(), seed, pid)
+        assert ok and e.status == oe.status == 1
+        assert np.array_equal(mask, omask) and np.array_equal(np.array(e.E), np.array(oe.E))
+        assert (e.n_inl, e.iters, e.lo_runs, e.used_guess) == (oe.n_inl, oe.iters, oe.lo_runs, oe.used_guess)
+        assert e.used_guess == (0 if g is None else 1)
+        assert rot_angle(np.array(e.R), np.array(oe.R)) < R_TOL_RAD and np.array(e.t) @ np.array(oe.t) > 1 - T_COS_TOL
+        assert S.rot_err_deg(np.array(e.R).reshape(3, 3), d["R"]) < (0.1 if g is None else 2.0)
+
+
+@pytest.mark.parametrize("nw", [1, 2, 4])
+def test_every_wavefront_count_per_pair_gives_the_oracles_bits(nw, monkeypatch):
+    """K1 is a template over the wavefronts per image pair (round 5: one / two / four; launch_estimate picks by batch size,
+    PGI_K1_NW forces).  A fit's hypotheses, scores and merges are order-free, so every count must give the ORACLE's bits:
+    ragged pairs across the LDS and hybrid classes of each count (320 / 640 / 1344 rows whole in LDS, the rest hybrid or --
+    four wavefronts, huge pairs -- from HBM/L2), tiny and degenerate pairs, then the same rows with pose guesses in both
+    guess modes (the rotation-guided path deals its 32 two-point hypotheses out over the wavefronts)."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_K1_NW", str(nw))
+    e = Engine()
+    try:
+        sizes = ([60, 300, 321, 640, 641, 900, 1344, 1345, 2300, 4, 5, 64] * 6)[:70] + [4100, 9000]
+        rhos = ([0.5, 0.3, 0.7, 0.5, 0.15, 0.6] * 12)[:len(sizes)]
+        ids = np.arange(23000, 23000 + len(sizes))
+        parts = [S.make_pair(int(i), n, inlier_ratio=r) for i, n, r in zip(ids, sizes, rhos)]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        cat = lambda k: np.concatenate([p[k] for p in parts])
+        x1, y1, x2, y2 = cat("x1"), cat("y1"), cat("x2"), cat("y2")
+        db = e.upload(x1, y1, x2, y2, off, 7.5e-4, seed=9, pair_id_base=23000)
+        edges, masks = e.estimate_pose_batch(db)
+        exp, em = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(), 9, pair_id_base=23000)
+        assert np.array_equal(masks.cpu().numpy(), em)
+        assert_edges_match(e.edges_to_numpy(edges), exp)
+        rng = np.random.default_rng(nw)
+        guesses = np.zeros((len(sizes), 12))
+        has = (rng.random(len(sizes)) < 0.8).astype(np.uint8)
+        for i, p in enumerate(parts):
+            Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(0.5 if i % 7 else 40.0)) @ p["R"]
+            guesses[i] = np.r_[Rg.ravel(), p["t"] if i % 3 else rng.standard_normal(3)]
+        dbg = e.upload(x1, y1, x2, y2, off, 7.5e-4, guesses=guesses, has_guess=has, seed=9, pair_id_base=23000)
+        for mode in (0, 1):
+            e.set_params(guess_mode=mode)
+            eg, mg = e.estimate_pose_batch(dbg)
+            expg, emg = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(guess_mode=mode), 9, pair_id_base=23000,
+                                              guesses=guesses, has_guess=has)
+            assert np.array_equal(mg.cpu().numpy(), emg), mode
+            assert_edges_match(e.edges_to_numpy(eg), expg)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("nw,env", [(1, {"PGI_HYBRID_ROWS": "0"}), (2, {"PGI_HYBRID_ROWS": "0", "PGI_LDS_MIN_WGS": "4"}),
+                                    (1, {"PGI_HYBRID_ROWS": "0", "PGI_LDS_MIN_WGS": "4"})])
+def test_rows_from_memory_below_four_wavefronts_per_pair(nw, env, monkeypatch):
+    """with one or two wavefronts per pair the rows-from-memory variant of K1 does not exist; experiment
+    settings that route a class to it (PGI_HYBRID_ROWS=0, PGI_LDS_MIN_WGS=4) used to launch NOTHING and return success, leaving
+    the records of those pairs unwritten.  Every pair must now carry the oracle's bits (the hybrid variant with an empty
+    LDS part serves them)."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_K1_NW", str(nw))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = Engine()
+    try:
+        sizes = ([60, 300, 321, 640, 641, 900, 1344, 1345, 2300, 64] * 8)[:78] + [4100, 9000]
+        b = S.make_batch(np.arange(31000, 31000 + len(sizes)), sizes)
+        db = e.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=4, pair_id_base=31000)
+        edges = torch_full_edges(e, len(sizes))
+        ed, mk = e.estimate_pose_batch(db, edges)
+        exp, em = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(), 4, pair_id_base=31000)
+        got = e.edges_to_numpy(ed)
+        assert not np.any(got["status"] == 77), "records left unwritten"
+        assert np.array_equal(mk.cpu().numpy(), em)
+        assert_edges_match(got, exp)
+    finally:
+        e.close()
+
+
+def torch_full_edges(e, P):
+    """an edge buffer pre-filled with a status no kernel writes (77): an unwritten record shows"""
+    import torch
+    from pyposegraphbuilder import _lib as L
+    host = np.zeros(P, L.EDGE_DTYPE)
+    host["status"] = 77
+    return torch.from_numpy(host.view(np.uint8).reshape(P, -1).copy()).to(e.device)

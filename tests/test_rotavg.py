@@ -212,14 +212,37 @@ def test_dense_graph_with_a_capped_first_step_stays_on_jacobi(capfd, monkeypatch
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["random", "band", "sequence"])
+@pytest.mark.parametrize("kind", ["random", "band", "sequence", "chain_with_weak_closures", "weak_bridges"])
 def test_inner_tolerance_does_not_move_the_fixed_point(kind, monkeypatch):
     """The inner solves stop at a relative 1e-4 by default (PGI_ROTAVG_CG_TOL overrides): the same outer iteration count and
-    the same rotations as with solves to 1e-10, to well under the distance either keeps from the oracle's direct solves."""
+    the same rotations as with solves to 1e-10, to well under the distance either keeps from the oracle's direct solves.
+    ADVICE r5 (low): also on ILL-CONDITIONED graphs -- a 2000-view chain closed by a handful of weak long-range edges, and two
+    dense clusters joined by three edges of weight 1e-3 -- where a loose solve could leave the slow modes (the drift along the
+    chain, the relative rotation of the clusters) unconverged."""
     from pyposegraphbuilder import Engine
+    from scipy.spatial.transform import Rotation
     if kind == "random":
         V = 1500
         src, dst, Rrel, w, _, _ = RO.make_graph(V, 12, noise_deg=2.0, outlier_frac=0.25, seed=5)
+    elif kind == "chain_with_weak_closures":
+        V = 2000
+        src, dst, Rrel, w, Rgt = sequence_graph(V, 1, 0.5, 0.0, seed=23)
+        rng = np.random.default_rng(23)
+        a = rng.integers(0, V // 2, 6)
+        b = a + rng.integers(V // 3, V // 2, 6)
+        noise = Rotation.from_rotvec(rng.standard_normal((6, 3)) * np.deg2rad(0.5) / np.sqrt(3)).as_matrix()
+        src, dst = np.concatenate([src, a]), np.concatenate([dst, b])
+        Rrel = np.concatenate([Rrel, np.einsum("eij,ejk->eik", noise, np.einsum("eij,ekj->eik", Rgt[b], Rgt[a]))])
+        w = np.concatenate([w, np.full(6, 0.02)])
+    elif kind == "weak_bridges":
+        V = 1600
+        s1, d1, R1, w1, g1, _ = RO.make_graph(V // 2, 10, noise_deg=1.0, outlier_frac=0.1, seed=7)
+        s2, d2, R2, w2, g2, _ = RO.make_graph(V // 2, 10, noise_deg=1.0, outlier_frac=0.1, seed=8)
+        a, b = np.array([3, 400, 777]), np.array([5, 123, 650]) + V // 2
+        Rgt = np.concatenate([g1, g2])
+        src, dst = np.concatenate([s1, s2 + V // 2, a]), np.concatenate([d1, d2 + V // 2, b])
+        Rrel = np.concatenate([R1, R2, np.einsum("eij,ekj->eik", Rgt[b], Rgt[a])])
+        w = np.concatenate([w1, w2, np.full(3, 1e-3)])
     else:
         V = 3000
         src, dst, Rrel, w, _ = sequence_graph(V, 12 if kind == "band" else 4, 1.0, 0.05, seed=19)
