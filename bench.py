@@ -238,6 +238,11 @@ def compact_summary(out):
         if len(warm) >= 2:
             worst = max(worst, max(warm) / float(np.median(warm)))
     s["worst_over_median_repetition"] = round(worst, 3) if worst else None
+    # progressive vs uniform sampling where the cap binds: [edges/s, mean hypotheses, AUC@5] each
+    for key, name in (("rho0.3_uniform", "inlier_ratio_0.3_ratio_sorted_uniform"), ("rho0.3_progressive", "inlier_ratio_0.3_ratio_sorted_progressive"),
+                      ("thr0.4_uniform", "thr_0.4px_ratio_sorted_uniform"), ("thr0.4_progressive", "thr_0.4px_ratio_sorted_progressive")):
+        v = dig("variants", name)
+        s["sampler_" + key] = [v.get("edges_per_s"), v.get("mean_hypotheses"), v.get("rot_err_auc_at_5deg")] if v else None
     if out.get("n_gpus", 1) > 1:
         s["exchange_verified"] = out.get("exchange_verified")
         s["allgather_ms"] = dig("exchange", "allgather_ms")
@@ -854,7 +859,16 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_variants and not args.fixed_budget:
         # ---- SURVEY 8d's other settings of config 2 (same kernel, same 10 000 pairs; never `value`) -------------------
-        def run_variant(batch, thr_v, reps=3):
+        def run_variant(batch, thr_v, reps=3, **prm_v):
+            if prm_v:
+                eng.set_params(**prm_v)
+            try:
+                return run_variant_(batch, thr_v, reps)
+            finally:
+                if prm_v:
+                    eng.set_params(**{k: 0 for k in prm_v})   # (only switches that default to 0 are varied here: sampler)
+
+        def run_variant_(batch, thr_v, reps):
             dbv = eng.upload(batch["x1"], batch["y1"], batch["x2"], batch["y2"], batch["offsets"], thr_v, seed=seed, pair_id_base=pair_base)
             ev_, mv_ = eng.estimate_pose_batch(dbv)
             torch.cuda.synchronize()
@@ -882,6 +896,16 @@ def main():
                                              note="N ~ U{50..4000} per pair: bucketed on the device into occupancy classes, one launch per class")
         for rho_v in (0.3, 0.7):
             variants["inlier_ratio_%.1f" % rho_v] = run_variant(S.make_batch(ids_v, N, inlier_ratio=rho_v), thr)
+        # Progressive sampling (pgi_params.sampler = 1) where the iteration cap binds, on rows in the reference's order
+        # (ascending SNN ratio, feature_utils.h:184-186; S.ratio_sorted): VERDICT r5 item 9.  Uniform sampling on the
+        # same sorted rows beside it (the order alone changes nothing for a uniform sampler).
+        b_lo = S.ratio_sorted(S.make_batch(ids_v, N, inlier_ratio=0.3))
+        b_srt = S.ratio_sorted(b)
+        variants["inlier_ratio_0.3_ratio_sorted_uniform"] = run_variant(b_lo, thr)
+        variants["inlier_ratio_0.3_ratio_sorted_progressive"] = dict(run_variant(b_lo, thr, sampler=1), note="sampler = 1")
+        variants["thr_0.4px_ratio_sorted_uniform"] = run_variant(b_srt, 0.4 / S.FOCAL_PX)
+        variants["thr_0.4px_ratio_sorted_progressive"] = dict(run_variant(b_srt, 0.4 / S.FOCAL_PX, sampler=1), note="sampler = 1")
+        del b_lo, b_srt
         variants["seconds_incl_generation"] = round(time.time() - t0, 1)
         out["variants"] = variants
         # ---- graph level (BASELINE configs 3 / 4 / 5 on their surrogates AT SURVEY 8d's DENSITY; 1DSfM data is on neither box):

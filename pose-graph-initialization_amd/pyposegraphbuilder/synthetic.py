@@ -109,6 +109,23 @@ def auc_at(errors_deg, limit=5.0):
 
 
 # ---- scene-graph surrogates for BASELINE configs 3/4 (1DSfM data is not available on either box) -----------
+def ratio_sorted(batch, seed=77):
+    """The rows of every pair of a make_batch-like SoA in the order the reference's matcher hands them over: ascending
+    second-nearest-neighbour ratio (feature_utils.h:184-186) -- modelled as a quality score that correlates with being an
+    inlier (inliers uniform in [0, 0.8), outliers in [0.2, 1.0); lower = better).  Returns a new dict (same offsets, poses);
+    what pgi_params.sampler = 1 (progressive sampling) is meant for."""
+    rng = np.random.default_rng(seed)
+    out = dict(batch)
+    off = np.asarray(batch["offsets"], np.int64)
+    n = len(batch["x1"])
+    quality = np.where(batch["inlier"], rng.random(n) * 0.8, 0.2 + rng.random(n) * 0.8)
+    pair_of = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    order = np.lexsort((quality, pair_of))          # by pair, then by quality: a stable per-pair sort
+    for k in ("x1", "y1", "x2", "y2", "inlier"):
+        out[k] = np.ascontiguousarray(batch[k][order])
+    return out
+
+
 def make_pair_from_pose(pair_id, n, R, t, inlier_ratio=0.5, noise_px=0.25, seed_base=SEED_BASE):
     """Like make_pair but for a GIVEN relative pose (x_dst ~ R x_src + t, |t| = 1)."""
     rng = np.random.Generator(np.random.Philox(key=seed_base ^ 0x5CE7E ^ (int(pair_id) << 8)))

@@ -182,9 +182,11 @@ def test_gpu_decompose_batch_against_the_literal_rule(eng, k):
     edges, masks = eng.estimate_pose_batch(db)
     est = eng.edges_to_numpy(edges)
     ok = np.nonzero(est["status"] == 1)[0]
-    # the estimator's own epilogue and the stand-alone K3 launch are the same rule
+    # the estimator's own epilogue and the stand-alone K3 launch are the same rule: the record's E is the essential matrix of
+    # the returned pose ([t]x R, round 6), so decomposing it gives that pose back (to rounding: the epilogue decomposed the
+    # fitted f32 model, K3 here the rebuilt f64 matrix) with the same candidate chosen by the same inlier votes
     dec = eng.edges_to_numpy(eng.decompose_batch(db, est["E"], masks))
-    assert np.array_equal(dec["R"][ok], est["R"][ok]) and np.array_equal(dec["t"][ok], est["t"][ok])
+    assert np.abs(dec["R"][ok] - est["R"][ok]).max() < 1e-9 and np.abs(dec["t"][ok] - est["t"][ok]).max() < 1e-9
     eng.set_params(vote_all_rows=1)
     try:
         dec_all = eng.edges_to_numpy(eng.decompose_batch(db, est["E"], masks))
