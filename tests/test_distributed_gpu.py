@@ -284,7 +284,7 @@ def test_tail_wave_with_fewer_pairs_than_ranks(tmp_path, mode):
     o4 = run_ranks([EXE, path, str(tmp_path / "w4"), mode], 4)
     assert len(o4) == 4
     for r in range(4):
-        assert open(str(tmp_path / "w4.%d" % r), "rb").read() == single, r
+        assert open(str(tmp_path / ("w4.%d" % r)), "rb").read() == single, r
     # (the premise: a wave of two pairs leaves at least two of four blocks empty)
     assert sum(1 for lo, hi in D.shard_bounds(sizes[-2:], 4) if hi == lo) >= 2
 
