@@ -108,6 +108,37 @@ PGI_DEV double wave_sum_exact(double x) {
     return x;
 }
 
+// One elimination step of the row-per-lane Gauss-Jordan sweeps: columns [J0, J1) of this lane's row are scaled, the pivot
+// lane's scaled values fetched (ds_bpermute, byte address `addr` = 4 x pivot lane) and the update applied --
+//     v = row[j] * scale;  p = v of the pivot lane;  row[j] = fma(-f, p, v)
+// element for element what the plain loop does, but in BATCHES of CH columns: all products, then all fetches in flight
+// together, then all updates.  Written as one statement per column the compiler waited for every fetch on its own
+// (v_mul, 2 ds_bpermute, s_waitcnt lgkmcnt(0), v_fma -- 145 exposed LDS round trips per 10x20 sweep and wavefront, the
+// single largest stall of K1: round 6, profiles/r06_k1_gj_isa.txt); sched_barriers pin the three phases.
+#ifndef PGI_GJ_CH
+#define PGI_GJ_CH 8  // columns per batch (experiment builds: make variant NAME=ch1 DEFS=-DPGI_GJ_CH=1 is the old one-by-one form)
+#endif
+template <int J0, int J1, int CH = PGI_GJ_CH>
+PGI_DEV void eliminate_columns(double* row, double scale, double f, int addr) {
+    if constexpr (J0 < J1) {
+        constexpr int N = (J1 - J0) < CH ? (J1 - J0) : CH;
+        int lo[N], hi[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) row[J0 + c] = row[J0 + c] * scale;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            lo[c] = __builtin_amdgcn_ds_bpermute(addr, __double2loint(row[J0 + c]));
+            hi[c] = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(row[J0 + c]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < N; ++c) row[J0 + c] = fma(-f, __hiloint2double(hi[c], lo[c]), row[J0 + c]);
+        __builtin_amdgcn_sched_barrier(0);
+        eliminate_columns<J0 + N, J1, CH>(row, scale, f, addr);
+    }
+}
+
 // ---- counter-based RNG --------------------------------------------------------
 PGI_DEV uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -396,11 +427,12 @@ PGI_DEV void nullspace5_group(const float4 pt, int s, int gbase, const GroupScra
         }
         const double scale = is_p ? 1.0 / a[k] : 1.0;  // x * 1.0 == x exactly: no per-column select
         const double f = is_p ? 0.0 : a[k];             // the pivot row runs the same update with factor 0
-#pragma unroll
-        for (int j = k + 1; j < 9; ++j) {
-            const double v = a[j] * scale;
-            const double pj = __shfl(v, pl);
-            a[j] = fma(-f, pj, v);
+        switch (k) {  // (k is a compile-time constant in the unrolled loop; the column range must be one for the template)
+            case 0: eliminate_columns<1, 9>(a, scale, f, pl << 2); break;
+            case 1: eliminate_columns<2, 9>(a, scale, f, pl << 2); break;
+            case 2: eliminate_columns<3, 9>(a, scale, f, pl << 2); break;
+            case 3: eliminate_columns<4, 9>(a, scale, f, pl << 2); break;
+            default: eliminate_columns<5, 9>(a, scale, f, pl << 2); break;
         }
     }
     // v_f[k] = -a[prow[k]][5+f]; v_f[5+g] = delta_fg
@@ -535,11 +567,17 @@ PGI_DEV bool backend_group(const GroupScratch gs, int s, int gbase, SAMPLE sampl
         }
         const double scale = is_p ? 1.0 / row[k] : 1.0;  // x * 1.0 == x exactly: no per-column select
         const double f = is_p ? 0.0 : row[k];             // the pivot row runs the same update with factor 0
-#pragma unroll
-        for (int j = k + 1; j < 20; ++j) {
-            const double v = row[j] * scale;
-            const double pj = __shfl(v, pl);
-            row[j] = fma(-f, pj, v);
+        switch (k) {  // (k is a compile-time constant in the unrolled loop)
+            case 0: eliminate_columns<1, 20>(row, scale, f, pl << 2); break;
+            case 1: eliminate_columns<2, 20>(row, scale, f, pl << 2); break;
+            case 2: eliminate_columns<3, 20>(row, scale, f, pl << 2); break;
+            case 3: eliminate_columns<4, 20>(row, scale, f, pl << 2); break;
+            case 4: eliminate_columns<5, 20>(row, scale, f, pl << 2); break;
+            case 5: eliminate_columns<6, 20>(row, scale, f, pl << 2); break;
+            case 6: eliminate_columns<7, 20>(row, scale, f, pl << 2); break;
+            case 7: eliminate_columns<8, 20>(row, scale, f, pl << 2); break;
+            case 8: eliminate_columns<9, 20>(row, scale, f, pl << 2); break;
+            default: eliminate_columns<10, 20>(row, scale, f, pl << 2); break;
         }
     }
     prof.mark<PB + 1>();

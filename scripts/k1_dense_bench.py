@@ -46,13 +46,11 @@ for path in libs:
     L._lib = None
     for v in SPEC_ENV.values():
         os.environ.pop(v, None)
-    if "=" in path:  # "nw=1,overlap=0": the default build with these launcher settings (read when the context is made)
-        for kv in path.split(","):
-            k, v = kv.split("=")
-            os.environ[SPEC_ENV[k]] = v
-        L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", "libpgi.so")
-    else:
-        L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", path)
+    lib_name, _, spec = path.rpartition(":") if ":" in path else (("", "", path) if "=" in path else (path, "", ""))
+    for kv in filter(None, spec.split(",")):  # "nw=1,overlap=0" (or "libpgi_x.so:nw=1"): launcher settings, read when the context is made
+        k, v = kv.split("=")
+        os.environ[SPEC_ENV[k]] = v
+    L.LIB_PATH = os.path.join(ROOT, "pose-graph-initialization_amd", lib_name or "libpgi.so")
     e = Engine()
     for v in SPEC_ENV.values():
         os.environ.pop(v, None)
