@@ -243,6 +243,10 @@ def compact_summary(out):
                       ("thr0.4_uniform", "thr_0.4px_ratio_sorted_uniform"), ("thr0.4_progressive", "thr_0.4px_ratio_sorted_progressive")):
         v = dig("variants", name)
         s["sampler_" + key] = [v.get("edges_per_s"), v.get("mean_hypotheses"), v.get("rot_err_auc_at_5deg")] if v else None
+    # graph-cut local optimisation beside the default on the same batches: [edges/s, mean hypotheses, AUC@5]
+    for key, name in (("rho0.5", "graph_cut_lo"), ("rho0.3", "inlier_ratio_0.3_graph_cut_lo"), ("rho0.3_default", "inlier_ratio_0.3")):
+        v = dig("variants", name)
+        s["gc_lo_" + key] = [v.get("edges_per_s"), v.get("mean_hypotheses"), v.get("rot_err_auc_at_5deg")] if v else None
     if out.get("n_gpus", 1) > 1:
         s["exchange_verified"] = out.get("exchange_verified")
         s["allgather_ms"] = dig("exchange", "allgather_ms")
@@ -906,6 +910,10 @@ def main():
         variants["thr_0.4px_ratio_sorted_uniform"] = run_variant(b_srt, 0.4 / S.FOCAL_PX)
         variants["thr_0.4px_ratio_sorted_progressive"] = dict(run_variant(b_srt, 0.4 / S.FOCAL_PX, sampler=1), note="sampler = 1")
         del b_lo, b_srt
+        # Graph-cut local optimisation (pgi_params.lo_graph_cut = 9: lambda 0.14, the "GC" of GC-RANSAC; off by default): the refit's
+        # rows are the minimum cut of the spatial-coherence energy.  Same kernel, same batches as `value` / inlier_ratio_0.3.
+        variants["graph_cut_lo"] = dict(run_variant(b, thr, lo_graph_cut=9), note="config 2's batch with lo_graph_cut = 9")
+        variants["inlier_ratio_0.3_graph_cut_lo"] = dict(run_variant(S.make_batch(ids_v, N, inlier_ratio=0.3), thr, lo_graph_cut=9), note="lo_graph_cut = 9")
         variants["seconds_incl_generation"] = round(time.time() - t0, 1)
         out["variants"] = variants
         # ---- graph level (BASELINE configs 3 / 4 / 5 on their surrogates AT SURVEY 8d's DENSITY; 1DSfM data is on neither box):
@@ -952,9 +960,9 @@ def main():
                                        "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
                     gj, gname, gwhy = replay_profile("guided", None, None, L)
                     feat["dominant_kernel"] = dict(
-                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (seven wavefronts per CU in the sum kernel; VALU 39 % busy); roofline frac priced against hbm over all kernels of the scan"},
+                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (seven wavefronts per CU in the sum kernel; VALU 39 % busy); frac_hbm = ALGORITHMIC bytes / time of all kernels of the scan / 8 TB/s, traffic_* = the counters' bytes over the same time"},
                         **({k: gj.get(k) for k in ("kernel_us_trace_avg", "scan_us_all_kernels", "companion_kernels", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
-                                                    "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "valu_issue_busy_frac", "wave_waiting_frac", "lane_utilisation", "vgprs", "spilled_vgprs")}
+                                                    "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "traffic_GBs", "traffic_frac_hbm", "valu_issue_busy_frac", "wave_waiting_frac", "lane_utilisation", "vgprs", "spilled_vgprs")}
                            if gj else {}),
                         source=("replayed from %s; source hash matches the loaded build" % gname) if gj else "none: %s" % gwhy)
                     if slow:  # the upload stage reports itself when it is far slower than PCIe allows (a shared box now and then)

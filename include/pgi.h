@@ -76,6 +76,14 @@ typedef struct {
                                in 64 steps, without its forced newest point; scoring, local optimisation and the
                                stopping rule use all rows, so the gain is an earlier good model (it shows where the
                                iteration cap binds), not a lower adaptive count */
+    uint32_t lo_graph_cut;  /* 0 (default) = local optimisation refits the rows inside the threshold.  lambda * 64 > 0 (9 ~ the
+                               paper's 0.14) = GRAPH-CUT local optimisation, the "GC" of GC-RANSAC (Barath & Matas 2018; the
+                               reference keeps only a commented-out binding, bindings.cpp:5,228): the refit's rows are the
+                               minimum s-t cut of the spatial-coherence energy over the grid neighbourhood of the 4-D
+                               correspondences -- kernel K = max(0, 1 - d^2 / (1.5 thr)^2) in 16 levels, cells of 1/8 per
+                               axis in normalised coordinates, the rows of a cell linked in index order, cut exactly by a
+                               forward / backward sweep along the chains (oracle/pgi_oracle.c: pgo_gc_labels).  Scoring, the
+                               acceptance test of a refit and the stopping rule are unchanged */
 } pgi_params;
 
 /* One pose-graph edge: what estimatePose returns (SE3 + inlier count) plus E.

@@ -124,6 +124,7 @@ void pgo_default_params(pgo_params* p) {
     p->vote_all_rows = 0;
     p->guess_mode = 0;
     p->lo_linear_pct = 35;
+    p->lo_graph_cut = 0;
     p->sampler = 0;
 }
 
@@ -245,6 +246,118 @@ uint32_t pgo_mask_model(const float E[9], const float* x1, const float* y1, cons
         c += in;
     }
     return c;
+}
+
+/* ---- graph-cut local optimisation: the labelling step of GC-RANSAC (Barath & Matas, CVPR 2018) -------------------------
+ * north_star names the estimator "GC-RANSAC"; the reference keeps only a commented-out binding of it
+ * (/root/reference/src/pyposegraphbuilder/src/bindings.cpp:5,228), so this follows the published algorithm: when a new best
+ * model is found, the rows the refit uses are not "residual below the threshold" but the labelling L (inlier / outlier) that
+ * minimises
+ *     E(L) = sum_p U_p(L_p) + lambda * sum_{(p,q) neighbours} B_pq(L_p, L_q)
+ * with the kernel K_p = max(0, 1 - d_p^2 / (1.5 thr)^2) of the squared Sampson distance d_p^2,
+ *     U_p(outlier) = K_p, U_p(inlier) = 1 - K_p,
+ *     B_pq = 1 if the labels differ, (K_p + K_q) / 2 if both are outliers, 1 - (K_p + K_q) / 2 if both are inliers
+ * (the paper's eq. 2-4) -- a row next to good rows is pulled in, a stray row inside the band among bad neighbours is pushed out.
+ * What is specific to this build, so that CPU and GPU agree bit for bit and the cut is cheap:
+ *  - K is quantised to PGO_GC_LEVELS = 16 levels by a ladder of f32 comparisons r^2 < (j / 16) (1.5 thr)^2 den (the operands of
+ *    the scoring staircase): every energy is an integer, U = 128 k, lambda enters as lambda64 = lambda * 64 (9 ~ 0.14, the
+ *    paper's value): B = lambda64 * (k_p + k_q), lambda64 * (32 - k_p - k_q), lambda64 * 32 (all x 2 against the formulas above,
+ *    like U);
+ *  - neighbours: the paper's grid neighbourhood over the 4-D correspondence space (cells of 1/8 in normalised image
+ *    coordinates per axis), with the rows of a cell linked IN INDEX ORDER -- a spanning path of the paper's clique -- so the
+ *    neighbourhood graph is a set of chains;
+ *  - on a set of chains the minimum s-t cut of this (submodular) energy is found exactly by a forward / backward sweep
+ *    (dynamic programming over delta = m(inlier) - m(outlier)); ties go to "outlier".  tests/test_graph_cut.py checks the
+ *    sweep's energy against a generic max-flow (scipy) on the same graphs. */
+uint32_t pgo_gc_cell(float x1, float y1, float x2, float y2) {
+    const int a = (int)floorf(x1 * 8.0f), b = (int)floorf(y1 * 8.0f), c = (int)floorf(x2 * 8.0f), d = (int)floorf(y2 * 8.0f);
+    return (uint32_t)(a & 7) | ((uint32_t)(b & 7) << 3) | ((uint32_t)(c & 7) << 6) | ((uint32_t)(d & 7) << 9);
+}
+
+/* prev[i] = the last row before i in the same cell (PGO_GC_NONE: i starts a chain) */
+void pgo_gc_chains(const float* x1, const float* y1, const float* x2, const float* y2, uint32_t n, uint32_t* prev) {
+    uint32_t last[4096];
+    for (int c = 0; c < 4096; ++c) last[c] = PGO_GC_NONE;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = pgo_gc_cell(x1[i], y1[i], x2[i], y2[i]);
+        prev[i] = last[c];
+        last[c] = i;
+    }
+}
+
+/* k in 0..16: how many of the levels j = 1..16 the row passes, r^2 < (j / 16) * (1.5 thr)^2 * den */
+uint32_t pgo_gc_kernel_level(const float E[9], float x1, float y1, float x2, float y2, float thr2) {
+    float r2, den;
+    sampson_terms(E, x1, y1, x2, y2, &r2, &den);
+    const float t = (den * thr2) * 2.25f;
+    uint32_t k = 0;
+    for (uint32_t j = 1; j <= PGO_GC_LEVELS; ++j) k += r2 < t * ((float)j * 0.0625f);
+    return k;
+}
+
+static inline void gc_pairwise(uint32_t kp, uint32_t kq, uint32_t lambda64, int32_t* v00, int32_t* v11, int32_t* v01) {
+    *v00 = (int32_t)(lambda64 * (kp + kq));
+    *v11 = (int32_t)(lambda64 * (2u * PGO_GC_LEVELS - kp - kq));
+    *v01 = (int32_t)(lambda64 * 2u * PGO_GC_LEVELS);
+}
+
+/* energy of a labelling (test hook: the sweep's result against a generic max-flow) */
+int64_t pgo_gc_energy(const uint32_t* k, const uint32_t* prev, const uint8_t* labels, uint32_t n, uint32_t lambda64) {
+    int64_t e = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        e += labels[i] ? (int64_t)PGO_GC_UNARY * (PGO_GC_LEVELS - k[i]) : (int64_t)PGO_GC_UNARY * k[i];
+        if (prev[i] != PGO_GC_NONE) {
+            int32_t v00, v11, v01;
+            gc_pairwise(k[prev[i]], k[i], lambda64, &v00, &v11, &v01);
+            e += labels[i] != labels[prev[i]] ? v01 : (labels[i] ? v11 : v00);
+        }
+    }
+    return e;
+}
+
+/* The cut itself: kernel levels k and chains prev in, labels out (1 = inlier side of the minimum cut); returns the inliers. */
+uint32_t pgo_gc_cut(const uint32_t* k, const uint32_t* prev, uint32_t n, uint32_t lambda64, uint8_t* labels) {
+    int32_t* delta = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+    /* forward: delta_i = m_i(inlier) - m_i(outlier), messages along prev (prev[i] < i) */
+    for (uint32_t i = 0; i < n; ++i) {
+        int32_t d = (int32_t)PGO_GC_UNARY * ((int32_t)PGO_GC_LEVELS - 2 * (int32_t)k[i]); /* U(in) - U(out) */
+        if (prev[i] != PGO_GC_NONE) {
+            int32_t v00, v11, v01;
+            gc_pairwise(k[prev[i]], k[i], lambda64, &v00, &v11, &v01);
+            const int32_t dp = delta[prev[i]];
+            const int32_t in1 = dp + v11 < v01 ? dp + v11 : v01; /* best way into "inlier", relative to m_prev(outlier) */
+            const int32_t in0 = dp + v01 < v00 ? dp + v01 : v00; /* ... into "outlier" */
+            d += in1 - in0;
+        }
+        delta[i] = d;
+        labels[i] = 2; /* undecided */
+    }
+    /* backward: a row nobody has decided yet ends its chain and takes its own minimum; every row decides its predecessor */
+    uint32_t cnt = 0;
+    for (uint32_t ii = n; ii-- > 0;) {
+        if (labels[ii] == 2) labels[ii] = delta[ii] < 0;
+        cnt += labels[ii];
+        if (prev[ii] != PGO_GC_NONE) {
+            int32_t v00, v11, v01;
+            gc_pairwise(k[prev[ii]], k[ii], lambda64, &v00, &v11, &v01);
+            const int32_t dp = delta[prev[ii]];
+            labels[prev[ii]] = labels[ii] ? (dp + v11 < v01) : (dp + v01 < v00);
+        }
+    }
+    free(delta);
+    return cnt;
+}
+
+/* labels[i] = 1: row i is an inlier of the minimum cut under model E; returns their number (energy: optional out) */
+uint32_t pgo_gc_labels(const float E[9], const float* x1, const float* y1, const float* x2, const float* y2, uint32_t n,
+                       double thr, uint32_t lambda64, const uint32_t* prev, uint8_t* labels, int64_t* energy) {
+    const float thr2 = (float)(thr * thr);
+    uint32_t* k = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; ++i) k[i] = pgo_gc_kernel_level(E, x1[i], y1[i], x2[i], y2[i], thr2);
+    const uint32_t cnt = pgo_gc_cut(k, prev, n, lambda64, labels);
+    if (energy) *energy = pgo_gc_energy(k, prev, labels, n, lambda64);
+    free(k);
+    return cnt;
 }
 
 /* Pre-verification (T(d,d)-style, Matas & Chum): once a best model with n_bar inliers exists, a
@@ -1093,8 +1206,14 @@ static void local_optimise(const float* x1, const float* y1, const float* x2, co
                            uint32_t n, double thr, const pgo_params* prm, best_t* best,
                            uint8_t* mask, uint32_t* lo_runs) {
     const float thr2 = (float)(thr * thr);
+    uint32_t* prev = NULL; /* graph-cut mode: the neighbourhood chains of the pair */
+    if (prm->lo_graph_cut) {
+        prev = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+        pgo_gc_chains(x1, y1, x2, y2, n, prev);
+    }
     for (uint32_t it = 0; it < prm->lo_iters; ++it) {
-        const uint32_t ni = pgo_mask_model(best->E, x1, y1, x2, y2, n, thr2, mask);
+        const uint32_t ni = prev ? pgo_gc_labels(best->E, x1, y1, x2, y2, n, thr, prm->lo_graph_cut < 255u ? prm->lo_graph_cut : 255u, prev, mask, NULL)
+                                 : pgo_mask_model(best->E, x1, y1, x2, y2, n, thr2, mask);
         if (ni < 5) break;
         float models[PGO_MAX_MODELS][9];
         uint32_t nm;
@@ -1119,6 +1238,7 @@ static void local_optimise(const float* x1, const float* y1, const float* x2, co
         best->score = bs;
         best->n_inl = bn;
     }
+    free(prev);
 }
 
 void pgo_ransac_essential(const float* x1, const float* y1, const float* x2, const float* y2,

@@ -66,6 +66,8 @@ typedef struct {
     uint32_t lo_linear_pct;  /* LO refits an inlier set of at least this many percent of the rows linearly
                                 (pgo_linear_refit); smaller sets with the n-point Nister refit.  0 = always Nister */
     uint32_t sampler;        /* 0 uniform, 1 progressive prefix sampling (see include/pgi.h) */
+    uint32_t lo_graph_cut;   /* 0 = LO refits the rows inside the threshold; lambda * 64 > 0 = graph-cut local optimisation:
+                                the refit's rows are the minimum cut of the spatial-coherence energy (pgo_gc_labels) */
 } pgo_params;
 
 typedef struct {
@@ -83,6 +85,18 @@ typedef struct {
 } pgo_edge;
 
 void pgo_default_params(pgo_params* p);
+
+/* ---- graph-cut local optimisation (GC-RANSAC's labelling step; see pgi_oracle.c) ------------------ */
+#define PGO_GC_LEVELS 16u
+#define PGO_GC_UNARY 128      /* weight of one kernel level in the unary terms */
+#define PGO_GC_NONE 0xFFFFFFFFu
+uint32_t pgo_gc_cell(float x1, float y1, float x2, float y2);
+void pgo_gc_chains(const float* x1, const float* y1, const float* x2, const float* y2, uint32_t n, uint32_t* prev);
+uint32_t pgo_gc_kernel_level(const float E[9], float x1, float y1, float x2, float y2, float thr2);
+uint32_t pgo_gc_labels(const float E[9], const float* x1, const float* y1, const float* x2, const float* y2, uint32_t n,
+                       double thr, uint32_t lambda64, const uint32_t* prev, uint8_t* labels, int64_t* energy);
+uint32_t pgo_gc_cut(const uint32_t* k, const uint32_t* prev, uint32_t n, uint32_t lambda64, uint8_t* labels);
+int64_t pgo_gc_energy(const uint32_t* k, const uint32_t* prev, const uint8_t* labels, uint32_t n, uint32_t lambda64);
 
 /* ---- reference in-tree arithmetic, f64 (restatements) ------------------ */
 /* graph_traversal.h:86-116 */

@@ -274,6 +274,50 @@ PGI_DEV void sampson_terms2(const f32x2 e[9], float x1, float y1, float x2, floa
     r2 = r * r;
 }
 
+// ---- graph-cut local optimisation (pgi_params.lo_graph_cut; specification: oracle/pgi_oracle.c, pgo_gc_*) -----------------
+// Integer energies: kernel level k in 0..16 (a ladder of f32 comparisons on the scoring operands), unary weight 128 per level,
+// pairwise terms lambda64 * (k_p + k_q) / (32 - k_p - k_q) / 32; neighbours = the rows of a 4-D grid cell in index order.
+constexpr uint32_t kGcNone = 0xFFFFFFFFu, kGcLevels = 16u, kGcCells = 4096u;
+constexpr int kGcUnary = 128;
+PGI_DEV uint32_t gc_cell(float4 p) {
+    const int a = (int)floorf(p.x * 8.0f), b = (int)floorf(p.y * 8.0f), c = (int)floorf(p.z * 8.0f), d = (int)floorf(p.w * 8.0f);
+    return (uint32_t)(a & 7) | ((uint32_t)(b & 7) << 3) | ((uint32_t)(c & 7) << 6) | ((uint32_t)(d & 7) << 9);
+}
+PGI_DEV uint32_t gc_kernel_level(const float e[9], float4 p, float thr2) {
+    float r2, den;
+    sampson_terms(e, p.x, p.y, p.z, p.w, r2, den);
+    const float t = (den * thr2) * 2.25f;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t j = 1; j <= kGcLevels; ++j) k += r2 < t * ((float)j * 0.0625f) ? 1u : 0u;
+    return k;
+}
+// message of row i given its predecessor's (dp, kp): delta_i = U(in) - U(out) + [best way into "inlier" - into "outlier"]
+PGI_DEV int gc_delta(uint32_t k, bool has_prev, int dp, uint32_t kp, uint32_t lambda64) {
+    int d = kGcUnary * ((int)kGcLevels - 2 * (int)k);
+    if (has_prev) {
+        const int v00 = (int)(lambda64 * (kp + k)), v11 = (int)(lambda64 * (2u * kGcLevels - kp - k)), v01 = (int)(lambda64 * 2u * kGcLevels);
+        const int in1 = dp + v11 < v01 ? dp + v11 : v01;
+        const int in0 = dp + v01 < v00 ? dp + v01 : v00;
+        d += in1 - in0;
+    }
+    return d;
+}
+// label of the predecessor (dp, kp) of a row with kernel level k and label `lab`
+PGI_DEV uint32_t gc_prev_label(uint32_t lab, uint32_t k, int dp, uint32_t kp, uint32_t lambda64) {
+    const int v00 = (int)(lambda64 * (kp + k)), v11 = (int)(lambda64 * (2u * kGcLevels - kp - k)), v01 = (int)(lambda64 * 2u * kGcLevels);
+    return lab ? (dp + v11 < v01 ? 1u : 0u) : (dp + v01 < v00 ? 1u : 0u);
+}
+// message words (one per row, global scratch): delta << 8 | k after the forward sweep (|delta| < 2^15 with lambda64 <= 255);
+// a successor in a higher 64-row block adds its decision: bit 5 = decided, bit 6 = label
+PGI_DEV uint32_t gc_pack(int delta, uint32_t k) { return ((uint32_t)delta << 8) | k; }
+PGI_DEV int gc_word_delta(uint32_t w) { return (int)w >> 8; }
+PGI_DEV uint32_t gc_word_k(uint32_t w) { return w & 31u; }
+// the words are written by one lane and read by another lane of the SAME wavefront later on: agent-scope relaxed accesses go
+// to L2 (no stale L1 line, no cache maintenance); same address = same channel, so program order is memory order
+PGI_DEV uint32_t gc_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PGI_DEV void gc_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- small f64 helpers -----------------------------------------------------------
 PGI_DEV int pivot_key(double a, int row) {
     const uint32_t hi = (uint32_t)__double2hiint(a) & 0x7FFFFFFFu;

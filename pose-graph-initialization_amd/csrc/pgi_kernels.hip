@@ -59,6 +59,7 @@ struct WgShared {
     int lo_score;       // results of a refit run by wave 0 (guess path) / refit counter
     uint32_t lo_ninl, lo_ni, lo_runs;
     float loE[9];
+    uint32_t gc_built;  // graph-cut local optimisation: the pair's neighbourhood chains exist (built by wave 0 at the first refit)
     double Rt[21];  // R1[9] R2[9] t[3]
 };
 
@@ -88,6 +89,11 @@ struct K1Args {
     const float* src_y1;
     const float* src_x2;
     const float* src_y2;
+    // graph-cut local optimisation (prm.lo_graph_cut): per-row scratch of the batch (same row offsets as the coordinates) and
+    // the byte offset, inside the workgroup's dynamic LDS, of the 16 KB cell table the chain builder uses
+    uint32_t* gc_prev;
+    uint32_t* gc_msg;
+    uint32_t gc_lds_off;
 };
 
 // rows either in LDS (float4, NaN padded) or gathered from the SoA in global memory
@@ -223,13 +229,149 @@ PGI_DEV int enqueue_models(bool valid, const float E32[9], uint32_t hyp, float* 
     return __popcll(bal);
 }
 
+// ---- graph-cut local optimisation: the labelling step on ONE wavefront (specification: oracle/pgi_oracle.c, pgo_gc_*) --------
+struct GcCtx {
+    uint32_t* prev;     // [n] predecessor of a row in its cell's chain (kGcNone: none); global
+    uint32_t* msg;      // [n] message words of the sweeps; global
+    uint8_t* lab;       // [n] the labelling (the pair's part of the mask output: the epilogue overwrites it at the end)
+    uint32_t* last;     // LDS, kGcCells words: last row seen per cell while the chains are built; 64 words of scratch afterwards
+    uint32_t lambda64;  // 0: threshold selection (no graph cut)
+};
+
+// prev[i] = the last row before i in the same 4-D grid cell.  64 rows per step: every lane looks its cell's last row up, all
+// write themselves, and a read-back tells who lost a collision -- only cells that occur twice in one step are sorted out one
+// by one (ballot over the lanes of the cell: the nearest lower lane is the predecessor, the highest lane stays in the table).
+template <int LDS_PTS>
+__device__ __noinline__ void gc_build_chains(const Rows<LDS_PTS>* rows_p, uint32_t n, uint32_t npad, const GcCtx* gp, int lane) {
+    const Rows<LDS_PTS> rows = *rows_p;
+    const GcCtx g = *gp;
+    for (uint32_t c = (uint32_t)lane; c < kGcCells; c += 64u) g.last[c] = kGcNone;
+    wave_sync();
+    for (uint32_t base = 0; base < npad; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = i < n;
+        const float4 p = rows.get(i);
+        const uint32_t c = valid ? gc_cell(p) : 0u;
+        uint32_t prev = valid ? g.last[c] : kGcNone;
+        wave_sync();
+        if (valid) g.last[c] = i;
+        wave_sync();
+        const bool lost = valid && g.last[c] != i;
+        wave_sync();
+        uint64_t rem = __ballot(lost);
+        while (rem) {  // (wave-uniform) one cell that occurs more than once in this step
+            const int leader = __ffsll((unsigned long long)rem) - 1;
+            const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)c, leader);
+            const bool mine = valid && c == cl;
+            const uint64_t same = __ballot(mine);
+            if (mine) {
+                const uint64_t lower = same & ((1ull << lane) - 1ull);
+                if (lower) prev = base + (uint32_t)(63 - __clzll((long long)lower));
+                if ((same >> lane) == 1ull) g.last[c] = i;  // the highest lane of the cell
+            }
+            rem &= ~same;
+        }
+        wave_sync();
+        if (valid) gc_store(g.prev + i, prev);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+}
+
+// The minimum cut under model e (LDS, 9 floats): forward sweep (messages delta along the chains), backward sweep (labels), both
+// 64 rows per step in index order; dependencies inside a step are resolved by iterating over the lanes that have become ready
+// (a chain rarely has two rows in one step).  Writes lab[i] in {0, 1} and returns the number of inliers.
+template <int LDS_PTS>
+__device__ __noinline__ uint32_t gc_label_wave(const Rows<LDS_PTS>* rows_p, uint32_t n, uint32_t npad, const float* e_lds, float thr2,
+                                               const GcCtx* gp, int lane) {
+    const Rows<LDS_PTS> rows = *rows_p;
+    const GcCtx g = *gp;
+    const uint32_t lam = g.lambda64;
+    float e[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) e[c] = e_lds[c];
+    for (uint32_t base = 0; base < npad; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = i < n;
+        const float4 p = rows.get(i);
+        const uint32_t k = valid ? gc_kernel_level(e, p, thr2) : 0u;
+        const uint32_t pv = valid ? gc_load(g.prev + i) : kGcNone;
+        const bool has = pv != kGcNone, inblk = has && pv >= base;
+        int d = 0;
+        bool done = !valid;
+        if (valid && !inblk) {
+            int dp = 0;
+            uint32_t kp = 0;
+            if (has) {
+                const uint32_t w = gc_load(g.msg + pv);
+                dp = gc_word_delta(w);
+                kp = gc_word_k(w);
+            }
+            d = gc_delta(k, has, dp, kp, lam);
+            done = true;
+        }
+        const int src = inblk ? (int)(pv - base) : 0;
+        for (;;) {
+            const uint64_t dm = __ballot(done);
+            if (dm == ~0ull) break;
+            const uint32_t ws = (uint32_t)__shfl((int)gc_pack(d, k), src);
+            if (!done && ((dm >> src) & 1ull)) {
+                d = gc_delta(k, true, gc_word_delta(ws), gc_word_k(ws), lam);
+                done = true;
+            }
+        }
+        if (valid) gc_store(g.msg + i, gc_pack(d, k));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t cnt = 0;
+    uint32_t* succ_of = g.last;  // 64 words of LDS scratch (the cell table is dead once the chains exist)
+    for (uint32_t base = npad; base >= 64u;) {
+        base -= 64u;
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = i < n;
+        const uint32_t w = valid ? gc_load(g.msg + i) : 0u;
+        const uint32_t pv = valid ? gc_load(g.prev + i) : kGcNone;
+        const uint32_t k = gc_word_k(w) & 31u;
+        const int d = gc_word_delta(w);
+        succ_of[lane] = 64u;
+        wave_sync();
+        if (valid && pv != kGcNone && pv >= base) succ_of[pv - base] = (uint32_t)lane;
+        wave_sync();
+        const uint32_t succ = succ_of[lane];
+        wave_sync();
+        uint32_t lab = (w >> 6) & 1u;                     // decided by a successor in a higher step ...
+        if (succ == 64u && !((w >> 5) & 1u)) lab = d < 0 ? 1u : 0u;  // ... or the end of a chain: its own minimum (ties: outlier)
+        bool done = !valid || succ == 64u;
+        const int sl = succ == 64u ? 0 : (int)succ;
+        for (;;) {
+            const uint64_t dm = __ballot(done);
+            if (dm == ~0ull) break;
+            const uint32_t ls = (uint32_t)__shfl((int)lab, sl), ks = (uint32_t)__shfl((int)k, sl);
+            if (!done && ((dm >> sl) & 1ull)) {
+                lab = gc_prev_label(ls, ks, d, k, lam);
+                done = true;
+            }
+        }
+        if (valid && pv != kGcNone && pv < base) {  // the predecessor sits in a lower step: leave it the decision
+            const uint32_t wp = gc_load(g.msg + pv);
+            gc_store(g.msg + pv, wp | 32u | (gc_prev_label(lab, k, gc_word_delta(wp), gc_word_k(wp) & 31u, lam) << 6));
+        }
+        if (valid) g.lab[i] = (uint8_t)lab;
+        cnt += (uint32_t)__popcll(__ballot(valid && lab));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wave_sync();
+    return cnt;
+}
+
 // Inlier set of model E at bound tau2 -> exact 9x9 normal matrix in loA (LDS) and the inlier
 // count, by ONE wavefront (local optimisation runs on wave 0 while the others solve hypotheses).
 // Summands are pre-rounded to 2^-34 so every summation order agrees.  Three sweeps of <= 18
 // accumulators keep the register footprint small; tri (45 doubles) is scratch for the triangle.
+// (lab != nullptr: the row set is a labelling -- graph-cut local optimisation -- instead of the rows inside the bound)
 template <int LDS_PTS>
 PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, const float E[9], float tau2,
-                                    double* loA, double* tri, int lane) {
+                                    double* loA, double* tri, int lane, const uint8_t* lab = nullptr) {
     uint32_t cnt = 0;
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
@@ -241,7 +383,7 @@ PGI_DEV uint32_t normal_matrix_wave(const Rows<LDS_PTS>& rows, uint32_t npad, co
             const float4 p = rows.get(base + lane);
             float r2, den;
             sampson_terms(E, p.x, p.y, p.z, p.w, r2, den);
-            const bool in = r2 < tau2 * den;
+            const bool in = lab ? (base + (uint32_t)lane < rows.n && lab[base + lane] != 0) : (r2 < tau2 * den);
             if (blk == 0) cnt += __popcll(__ballot(in));
             if (in) {
                 const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
@@ -430,7 +572,8 @@ template <int LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
                              float thr2, double* wscr0, uint32_t* qhyp0, int lane, int floor_score, uint32_t n_bar,
                              int& r_score, uint32_t& r_ninl, int& r_idx, Prof& prof, int ni_pre = -1,
-                             uint32_t lin_pct = 0u) {
+                             uint32_t lin_pct = 0u, const GcCtx* gc = nullptr, const float* e_lds = nullptr,
+                             uint32_t* gc_built = nullptr) {
     double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
     double* loV = loA + 81;                    // 81 (ends at W_REGA + 228 <= W_DOUBLES)
     double* tri = wscr0 + G_BASIS_SZ;          // 45 doubles over basis of groups 1..2
@@ -439,8 +582,21 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     r_ninl = 0;
     r_idx = -1;
     prof.mark<11>();
-    const uint32_t ni = ni_pre >= 0 ? (uint32_t)ni_pre  // the workgroup already built A (first refit after a merge)
-                                    : normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane);
+    uint32_t ni;
+    if (ni_pre >= 0) {
+        ni = (uint32_t)ni_pre;  // the workgroup already built A (first refit after a merge)
+    } else if (gc && gc->lambda64) {
+        // graph-cut local optimisation: the refit's rows are the minimum cut of the spatial-coherence energy under E
+        if (!__builtin_amdgcn_readfirstlane((int)*gc_built)) {
+            gc_build_chains<LDS_PTS>(&rows, n, npad, gc, lane);
+            if (lane == 0) *gc_built = 1u;
+            wave_sync();
+        }
+        (void)gc_label_wave<LDS_PTS>(&rows, n, npad, e_lds, thr2, gc, lane);
+        ni = normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane, gc->lab);
+    } else {
+        ni = normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane);
+    }
     prof.mark<12>();
     if (ni < 5) return ni;  // wave-uniform
     jacobi9_wave(loA, loV, wscr0 + W_BASIS, lane);
@@ -551,6 +707,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
         sh->pass_ctr = 0;
         sh->nbar = 0;
         sh->lo_runs = 0;
+        sh->gc_built = 0;
     }
     __syncthreads();
     prof.mark<0>();
@@ -579,11 +736,23 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     // Local optimisation of the current best (sh->bestE): up to lo_iters n-point refits while they improve.  Called by
     // ALL threads right after a merge (the first normal matrix is built by the whole workgroup); the refits themselves
     // run on wave 0, which is the only writer of the best until the next workgroup barrier.
+    // graph-cut local optimisation (prm.lo_graph_cut): the labelling context, rebuilt where it is needed (nothing of it is
+    // carried across the round loop)
+    auto make_gc = [&]() {
+        GcCtx g;
+        g.prev = a.gc_prev ? a.gc_prev + o : nullptr;
+        g.msg = a.gc_msg ? a.gc_msg + o : nullptr;
+        g.lab = mask;
+        g.last = reinterpret_cast<uint32_t*>(smem + a.gc_lds_off);
+        g.lambda64 = a.gc_prev ? min(prm.lo_graph_cut, 255u) : 0u;
+        return g;
+    };
     auto local_optimise = [&]() {
         if constexpr (!GUESS) return;  // only the guess variants call it (keeps the plain kernel's code unchanged)
         int ni_first = -1;
+        const GcCtx gc = make_gc();
         if constexpr (NW > 1) {  // (a one-wavefront workgroup builds every normal matrix inside refit_wave0)
-            if (prm.lo_iters) {
+            if (prm.lo_iters && !gc.lambda64) {  // (graph-cut mode: the row set is wave 0's labelling, no shared first matrix)
                 float bE0[9];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
@@ -604,7 +773,8 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                 asm volatile("" : "+v"(ln));
                 const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best, cur_ninl,
-                                                                r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct);
+                                                                r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct,
+                                                                &gc, sh->bestE, &sh->gc_built);
                 if (ni < 5) break;
                 if (lane == 0) sh->lo_runs += 1;
                 if (!(r_score > cur_best)) break;
@@ -916,7 +1086,8 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 // (same steps as local_optimise() above, spelled out: inside the round loop the compiler schedules the
                 // inline form measurably better than the shared lambda -- 2 % on BASELINE config 2)
                 int ni_first = -1;
-                if (NW > 1 && prm.lo_iters) {  // every wavefront is here anyway: build the first refit's normal matrix together
+                const GcCtx gc = make_gc();
+                if (NW > 1 && prm.lo_iters && !gc.lambda64) {  // every wavefront is here anyway: build the first refit's normal matrix together
                     float bE0[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
@@ -942,7 +1113,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                         asm volatile("" : "+v"(ln));
                         const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best,
                                                                        cur_ninl, r_score, r_ninl, r_idx, prof,
-                                                                       it == 0 ? ni_first : -1, prm.lo_linear_pct);
+                                                                       it == 0 ? ni_first : -1, prm.lo_linear_pct, &gc, sh->bestE, &sh->gc_built);
                         if (ni < 5) break;
                         if (lane == 0) sh->lo_runs += 1;
                         if (!(r_score > cur_best)) break;
@@ -1591,6 +1762,7 @@ void pgi_default_params(pgi_params* p) {
     p->guess_mode = 0;
     p->lo_linear_pct = 35;
     p->sampler = 0;
+    p->lo_graph_cut = 0;
 }
 
 pgi_ctx* pgi_create(int device, const pgi_params* params) {
@@ -1762,7 +1934,8 @@ static uint32_t k1_rows_cap(const pgi_ctx* ctx, int wgs_per_cu, size_t fixed_byt
 // `src`: four page-locked host arrays (device-visible addresses) the rows are consumed from in place; b->d_x1..d_y2 are
 // then the device mirror for rows that do not fit in LDS.
 static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch* b, pgi_edge* d_edges, uint8_t* d_masks,
-                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr) {
+                           hipStream_t stream, uint32_t** bucket, size_t* bucket_cap, const float* const* src = nullptr,
+                           uint64_t rows_hint = 0, uint32_t* gc_ext = nullptr) {
     if (!ctx || !b || !d_edges || !d_masks) return fail(PGI_ERR_INVALID, "null argument");
     if (b->n_pairs == 0) return PGI_SUCCESS;
     if (!b->d_x1 || !b->d_y1 || !b->d_x2 || !b->d_y2 || !b->d_offsets || !b->d_thr)
@@ -1778,12 +1951,32 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     a.pair_head = nullptr;
     a.src_x1 = src ? src[0] : nullptr; a.src_y1 = src ? src[1] : nullptr;
     a.src_x2 = src ? src[2] : nullptr; a.src_y2 = src ? src[3] : nullptr;
+    a.gc_prev = nullptr; a.gc_msg = nullptr; a.gc_lds_off = 0;
     HIP_TRY(hipSetDevice(ctx->device));
+    // Graph-cut local optimisation (prm.lo_graph_cut): two scratch words per row of the batch, indexed like the coordinates.
+    // The caller brings them (gc_ext: the single-pair entry) or they follow the size-bucket lists in the caller's scratch; a
+    // device-resident batch does not tell its row count, so it is read back (one 8-byte copy and a stream synchronisation per
+    // call: the price of the optional mode).
+    const bool gc_on = prm.lo_graph_cut != 0u;
+    uint64_t gc_rows = 0;
+    if (gc_on) {
+        if (src) return fail(PGI_ERR_INVALID, "lo_graph_cut: not with rows consumed in place from page-locked host memory (PGI_HOST_DIRECT=0)");
+        gc_rows = rows_hint;
+        if (!gc_rows) {
+            uint64_t last = 0;
+            HIP_TRY(hipMemcpyAsync(&last, b->d_offsets + b->n_pairs, sizeof last, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            gc_rows = last;
+        }
+        if (!gc_ext && !bucket) return fail(PGI_ERR_INVALID, "launch_estimate: lo_graph_cut without scratch");
+    }
+    const size_t gc_words = gc_on && !gc_ext ? (size_t)2 * gc_rows + 32 : 0;
     // Wavefronts per pair for this call (see kMaxNW above).  Measured on the dense V = 5000 scene's rows (scripts/k1_dense_bench.py,
     // K1D_MAXPAIRS): two wavefronts per pair tie with four at 12 000 pairs and win above (-11 % at 24 000, -14 % at 48 000), one wins from about 10^5 pairs on (its
     // steady rate is 32 % above four's, but a launch winds down for 9 ms: the pairs that run to max_iters are one wavefront's work).
     int nw = ctx->k1_nw == 1 || ctx->k1_nw == 2 || ctx->k1_nw == 4 ? ctx->k1_nw : b->n_pairs >= kNw1Pairs ? 1 : b->n_pairs >= kNw2Pairs ? 2 : 4;
-    const size_t fixed = k1_fixed_lds(nw, false), fixed_stash = k1_fixed_lds(nw, true);
+    const size_t gc_lds = gc_on ? (size_t)kGcCells * 4 : 0;  // the chain builder's cell table, behind everything else
+    const size_t fixed = k1_fixed_lds(nw, false) + gc_lds, fixed_stash = k1_fixed_lds(nw, true) + gc_lds;
     const bool guesses = b->d_guess_Rt != nullptr && b->d_has_guess != nullptr;  // selects the kernel variant with the guess path
     auto rows_cap_of = [&](int wgs_per_cu, size_t fixed_bytes) { return k1_rows_cap(ctx, wgs_per_cu, fixed_bytes); };
     auto rows_cap = [&](int wgs_per_cu) { return rows_cap_of(wgs_per_cu, fixed); };
@@ -1805,10 +1998,12 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     auto launch_lds = [&](uint32_t cap_rows) {
         a.pts_cap = cap_rows;
         const size_t lds = (size_t)cap_rows * 16 + (hybrid ? fixed_stash : fixed);
+        a.gc_lds_off = (uint32_t)(lds - gc_lds);
         launch_k1(nw, hybrid ? 2 : 1, guesses, grid_of(), lds, ls, a);  // hybrid: first cap_rows rows in LDS, the tail from HBM/L2
     };
     auto launch_global = [&]() {  // rows stay in HBM/L2 (pairs beyond the LDS capacity)
         a.pts_cap = 0;
+        a.gc_lds_off = (uint32_t)(fixed_stash - gc_lds);
         // (the rows-from-memory variant exists at four wavefronts per pair only; below that the hybrid variant with an empty LDS
         //  part is the same thing -- launch_k1 would otherwise have nothing to launch and the pairs' records would stay unwritten)
         launch_k1(nw, nw < 4 ? 2 : 0, guesses, grid_of(), fixed_stash, ls, a);
@@ -1820,23 +2015,32 @@ static int launch_estimate(pgi_ctx* ctx, const pgi_params& prm, const pgi_batch*
     // occupancy instead (measured: faster than LDS at one workgroup per CU, scripts/lds_capacity_probe.py).
     // PGI_LDS_MIN_WGS overrides the default for experiments.
     const uint32_t lds_cap = ctx->lds_min_wgs >= 4 ? cap4 : ctx->lds_min_wgs == 3 ? cap3 : ctx->lds_min_wgs == 2 ? cap2 : cap1;
-    if (cap <= cap4 || b->n_pairs < 64) {  // every pair already gets the top occupancy (or the batch is tiny): one launch
+    const bool ragged = !(cap <= cap4 || b->n_pairs < 64);
+    const size_t list_words = ragged ? (size_t)5 * b->n_pairs + 16 : 0;  // counts[8] | heads[8] | five lists
+    if (list_words + gc_words) {
+        if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
+        const size_t need = (list_words + gc_words) * sizeof(uint32_t);
+        if (need > *bucket_cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (*bucket) (void)hipFree(*bucket);
+            *bucket = nullptr;
+            *bucket_cap = 0;
+            HIP_TRY(hipMalloc((void**)bucket, need + (gc_words ? need / 4 : 0)));
+            *bucket_cap = need + (gc_words ? need / 4 : 0);
+        }
+    }
+    if (gc_on) {
+        uint32_t* w = gc_ext ? gc_ext : *bucket + ((list_words + 15) & ~(size_t)15);
+        a.gc_prev = w;
+        a.gc_msg = w + gc_rows;
+    }
+    if (!ragged) {  // every pair already gets the top occupancy (or the batch is tiny): one launch
         if (nw < 4 && cap > cap4) {  // (a tiny batch of large pairs in the builds that know two classes: the hybrid one)
             hybrid = true;
             launch_lds(rows_cap_of(kLevelWgs[0], fixed_stash));
             hybrid = false;
         } else if (cap <= lds_cap) launch_lds(cap); else launch_global();
     } else {  // bucket by row count on the device, one launch per occupancy class
-        if (!bucket) return fail(PGI_ERR_INVALID, "launch_estimate: ragged batch without bucket scratch");
-        const size_t need = ((size_t)5 * b->n_pairs + 16) * sizeof(uint32_t);  // counts[8] | heads[8] | five lists
-        if (need > *bucket_cap) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (*bucket) (void)hipFree(*bucket);
-            *bucket = nullptr;
-            *bucket_cap = 0;
-            HIP_TRY(hipMalloc((void**)bucket, need));
-            *bucket_cap = need;
-        }
         uint32_t* counts = *bucket;
         uint32_t* heads = *bucket + 8;
         uint32_t* lists = *bucket + 16;
@@ -2021,7 +2225,7 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
     // (heap pages shared with other allocations, ranges registered and unregistered shortly before) that ended, now and then,
     // in "Memory access fault by GPU" on a heap address (round 5, tests/test_gpu_parity.py after the partial-registration cases).
     const bool pin_out = page_locked(h_edges) && page_locked(h_masks);
-    if (pinned && ctx->host_direct && page_locked(h_edges) && page_locked(h_masks)) {  // work on the caller's buffers in place
+    if (pinned && ctx->host_direct && !ctx->prm.lo_graph_cut && page_locked(h_edges) && page_locked(h_masks)) {  // work on the caller's buffers in place
         void* hp[6] = {const_cast<float*>(h_x1), const_cast<float*>(h_y1), const_cast<float*>(h_x2), const_cast<float*>(h_y2), h_edges, h_masks};
         void* dp[6] = {};
         // The kernel will touch the WHOLE of every range: both ends must be mapped, and contiguously (two separate
@@ -2239,7 +2443,8 @@ int pgi_estimate_pose_batch_host(pgi_ctx* ctx, const float* h_x1, const float* h
         b.d_guess_Rt = guesses ? (const double*)(d + L.guess) : nullptr;
         b.d_has_guess = guesses ? (const uint8_t*)(d + L.has) : nullptr;
         b.n_pairs = np; b.max_corr = max_corr; b.pair_id_base = pair_id_base + p0; b.seed = seed;
-        const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), ks, &S.d_bucket, &S.bucket_bytes);
+        const int rc = launch_estimate(ctx, ctx->prm, &b, (pgi_edge*)(d + L.edges), (uint8_t*)(d + L.masks), ks, &S.d_bucket, &S.bucket_bytes, nullptr,
+                                       h_offsets[cuts[c + 1]] - h_offsets[cuts[c]]);
         if (rc < 0) return rc;
         HIP_TRY(hipEventRecord(S.k_done, ks));
         S.used = true;
@@ -2323,7 +2528,8 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
     // layout (host staging == device scratch): x1 y1 x2 y2 (nf floats each) | off[2] | thr | guess[12] | has | edge | mask
     const size_t nf = ((size_t)n + 3) & ~(size_t)3;
     const size_t o_off = 4 * nf * 4, o_thr = o_off + 16, o_guess = o_thr + 8, o_has = o_guess + 96, o_edge = o_has + 8,
-                 o_mask = o_edge + sizeof(pgi_edge), bytes = o_mask + nf + 64;
+                 o_mask = o_edge + sizeof(pgi_edge), o_gc = (o_mask + nf + 63) & ~(size_t)63,
+                 bytes = o_gc + (prm.lo_graph_cut ? 8 * nf : 0) + 64;  // (graph-cut local optimisation: two scratch words per row)
     if (bytes > S.bytes) {
         const size_t cap = bytes + bytes / 2;
         if (S.d) (void)hipFree(S.d);
@@ -2361,7 +2567,8 @@ int pgi_estimate_pose(pgi_ctx* ctx, const double* corr, uint32_t n, double thr, 
     b.d_has_guess = g ? (uint8_t*)(d + o_has) : nullptr;
     b.n_pairs = 1; b.max_corr = n; b.pair_id_base = pair_id; b.seed = seed;
     // a single pair is never bucketed, so the launch needs no context-owned scratch and no context lock
-    int rc = launch_estimate(ctx, prm, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask), S.stream, nullptr, nullptr);
+    int rc = launch_estimate(ctx, prm, &b, (pgi_edge*)(d + o_edge), (uint8_t*)(d + o_mask), S.stream, nullptr, nullptr, nullptr, nf,
+                             prm.lo_graph_cut ? (uint32_t*)(d + o_gc) : nullptr);
     if (rc != PGI_SUCCESS) return rc;
     HIP_TRY(hipMemcpyAsync(h + o_edge, d + o_edge, sizeof(pgi_edge) + n, hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));

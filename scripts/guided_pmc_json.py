@@ -39,7 +39,9 @@ out = {"kernel": K.replace(", fals", ", false>") + " (+ guided_deal_kernel, guid
                              for k, v in comp.items()},
        "hbm_bytes_per_launch": int(scan_fetch + scan_write), "fetch_bytes_per_launch": int(scan_fetch), "write_bytes_per_launch": int(scan_write),
        "algorithmic_bytes_per_launch": None, "traffic_over_algorithmic": None,
-       "achieved_GBs": round((scan_fetch + scan_write) / (scan_us * 1e-6) / 1e9, 1), "frac_hbm": round((scan_fetch + scan_write) / (scan_us * 1e-6) / 8e12, 4),
+       # (priced below from the ALGORITHMIC bytes; the counter traffic over the same time is kept beside it)
+       "achieved_GBs": None, "frac_hbm": None,
+       "traffic_GBs": round((scan_fetch + scan_write) / (scan_us * 1e-6) / 1e9, 1), "traffic_frac_hbm": round((scan_fetch + scan_write) / (scan_us * 1e-6) / 8e12, 4),
        "valu_issue_busy_frac": round(c["SQ_INSTS_VALU"] * 4 / (avg_us * 1e-6 * 2.4e9 * 1024), 3) if "SQ_INSTS_VALU" in c else None,
        "wave_waiting_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if "SQ_WAVE_CYCLES" in c else None,
        "lane_utilisation": None, "vgprs": 256 if "tile" in K else (252 if "sum" in K else 249), "spilled_vgprs": 4 if "tile" in K else 0,
@@ -49,6 +51,8 @@ out = {"kernel": K.replace(", fals", ", false>") + " (+ guided_deal_kernel, guid
 pairs_per_launch = 6078.0 / max(calls or 12, 1) * (2 if (calls or 12) > 12 else 1)
 alg = pairs_per_launch * (2 * 8000 * 512 + 8000 * 48)
 out["algorithmic_bytes_per_launch"] = int(alg)
+out["achieved_GBs"] = round(alg / (scan_us * 1e-6) / 1e9, 1)          # algorithmic bytes / time of all kernels of the scan
+out["frac_hbm"] = round(alg / (scan_us * 1e-6) / 8e12, 4)              # (r05 divided the COUNTER traffic, 0.287 instead of 0.204)
 out["traffic_over_algorithmic"] = round((scan_fetch + scan_write) / alg, 2)   # all kernels of the scan, the lists they hand over included
 if "SQ_INSTS_VALU_FMA_F64" in c and "SQ_ACTIVE_INST_VALU" in c:
     # useful lane-FMAs per launch: 6.3e9 (round 3: 49 M candidate sums x 128 elements, the same work for every variant of the scan)

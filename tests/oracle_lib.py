@@ -18,7 +18,7 @@ class Params(C.Structure):
                 ("round_size", C.c_uint32), ("lo_iters", C.c_uint32),
                 ("min_inliers", C.c_uint32), ("fixed_budget", C.c_uint32),
                 ("guess_quirk", C.c_uint32), ("vote_all_rows", C.c_uint32),
-                ("guess_mode", C.c_uint32), ("lo_linear_pct", C.c_uint32), ("sampler", C.c_uint32)]
+                ("guess_mode", C.c_uint32), ("lo_linear_pct", C.c_uint32), ("sampler", C.c_uint32), ("lo_graph_cut", C.c_uint32)]
 
 
 class Edge(C.Structure):

@@ -815,3 +815,63 @@ def torch_full_edges(e, P):
     host = np.zeros(P, L.EDGE_DTYPE)
     host["status"] = 77
     return torch.from_numpy(host.view(np.uint8).reshape(P, -1).copy()).to(e.device)
+
+
+@pytest.mark.parametrize("nw", [4, 2, 1])
+def test_graph_cut_local_optimisation_matches_the_oracle(nw, monkeypatch):
+    """pgi_params.lo_graph_cut (the "GC" of GC-RANSAC): the refit's rows are the minimum cut of the spatial-coherence energy over
+    the 4-D grid neighbourhood (oracle/pgi_oracle.c: pgo_gc_labels; tests/test_graph_cut.py checks that sweep against a generic
+    max-flow).  On the device one wavefront builds the chains (collisions inside a 64-row step resolved by ballots) and runs the
+    two sweeps; integer energies, so every result must be the oracle's bit for bit: ragged pairs of every size class at each
+    wavefront count, rows that share cells on purpose (one pair is a 6 x 6 lattice repeated: long chains, many collisions per
+    step), both lambda values, then the rotation-guided guess mode."""
+    from pyposegraphbuilder import Engine
+    monkeypatch.setenv("PGI_K1_NW", str(nw))
+    e = Engine()
+    try:
+        sizes = ([60, 300, 321, 640, 900, 1344, 1345, 2300, 5, 64, 129] * 4)[:40] + [4100]
+        rhos = ([0.5, 0.3, 0.7, 0.4] * 12)[:len(sizes)]
+        ids = np.arange(41000, 41000 + len(sizes))
+        parts = [S.make_pair(int(i), n, inlier_ratio=r) for i, n, r in zip(ids, sizes, rhos)]
+        # one pair whose rows pile up in a few cells: snap its coordinates to a coarse lattice (plus the usual noise)
+        lat = parts[7]
+        for kx in ("x1", "y1", "x2", "y2"):
+            lat[kx] = (np.round(lat[kx] * 6) / 6 + (lat[kx] - np.round(lat[kx] * 6) / 6) * 0.05).astype(np.float32)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        cat = lambda k: np.concatenate([p[k] for p in parts])
+        x1, y1, x2, y2 = cat("x1"), cat("y1"), cat("x2"), cat("y2")
+        db = e.upload(x1, y1, x2, y2, off, 7.5e-4, seed=21, pair_id_base=41000)
+        base_e, _ = e.estimate_pose_batch(db)
+        base = e.edges_to_numpy(base_e).copy()
+        for lam in (9, 40):
+            e.set_params(lo_graph_cut=lam)
+            edges, masks = e.estimate_pose_batch(db)
+            exp, em = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(lo_graph_cut=lam), 21, pair_id_base=41000)
+            got = e.edges_to_numpy(edges)
+            assert np.array_equal(masks.cpu().numpy(), em), lam
+            assert_edges_match(got, exp)
+            assert not np.array_equal(got["E"], base["E"])          # the mode is not a no-op
+        rng = np.random.default_rng(nw)
+        guesses = np.zeros((len(sizes), 12))
+        has = (rng.random(len(sizes)) < 0.8).astype(np.uint8)
+        for i, p in enumerate(parts):
+            Rg = S.rodrigues(rng.standard_normal(3), np.deg2rad(0.5 if i % 7 else 40.0)) @ p["R"]
+            guesses[i] = np.r_[Rg.ravel(), p["t"] if i % 3 else rng.standard_normal(3)]
+        dbg = e.upload(x1, y1, x2, y2, off, 7.5e-4, guesses=guesses, has_guess=has, seed=21, pair_id_base=41000)
+        for mode in (0, 1):
+            e.set_params(guess_mode=mode, lo_graph_cut=9)
+            eg, mg = e.estimate_pose_batch(dbg)
+            expg, emg = O.estimate_pose_batch(x1, y1, x2, y2, off, 7.5e-4, O.default_params(guess_mode=mode, lo_graph_cut=9), 21,
+                                              pair_id_base=41000, guesses=guesses, has_guess=has)
+            assert np.array_equal(mg.cpu().numpy(), emg), mode
+            assert_edges_match(e.edges_to_numpy(eg), expg)
+        # the single-pair seam (pgi_estimate_pose: its own scratch inside the slot buffer)
+        e.set_params(guess_mode=0, lo_graph_cut=9)
+        a0, a1 = int(off[3]), int(off[4])
+        corr = np.stack([x1[a0:a1], y1[a0:a1], x2[a0:a1], y2[a0:a1]], 1).astype(np.float64)
+        ok, edge, m1 = e.estimate_pose(corr, 7.5e-4, seed=21, pair_id=41003)
+        one, om = O.estimate_pose_batch(x1[a0:a1], y1[a0:a1], x2[a0:a1], y2[a0:a1], np.array([0, a1 - a0], np.uint64), 7.5e-4,
+                                        O.default_params(lo_graph_cut=9), 21, pair_id_base=41003)
+        assert np.array_equal(m1, om) and np.array_equal(np.array(edge.E), one["E"][0])
+    finally:
+        e.close()
