@@ -35,7 +35,7 @@ import tracklets_oracle as TO
 
 def run_features(O, views, cam, pairs, similarity, wave_size, *, path_finding=True, hashing=True, rotation_guided=False,
                  min_inliers=20, min_points=50, max_tracklets=5000, max_guided=100, thr_px=0.75, similarity_threshold=0.05,
-                 weight=0.8, max_depth=5, n_bins=45, trace=None):
+                 weight=0.8, max_depth=5, n_bins=45, trace=None, progressive=True):
     """views[v] = dict(xy f32 [K,2], desc f32 [K,128]); cam = (focal, width, height) shared by the views; pairs = [(src, dst,
     similarity)]; similarity(a, b) -> table value.  O: the oracle binding (tests/oracle_lib.py).
     trace (optional list) receives (wave, (src, dst), quick, matches, skipped) per slot.
@@ -48,7 +48,8 @@ def run_features(O, views, cam, pairs, similarity, wave_size, *, path_finding=Tr
     st = dict(pairs_processed=0, edges_added=0, paths_searched=0, paths_found=0, touched_nodes=0, poses_from_guess=0, hypotheses=0,
               waves=0, matching_runs=0, quick_matching_runs=0, guided_matching_runs=0, guided_matches_added=0, too_few_matches=0,
               quirk_only_guesses=0)
-    prm = O.default_params(min_inliers=min_inliers, guess_mode=1 if rotation_guided else 0)
+    # (progressive sampling over the matcher's ratio-sorted rows: processFeatures switches it on, PoseGraphBuilder::setProgressiveSampling)
+    prm = O.default_params(min_inliers=min_inliers, guess_mode=1 if rotation_guided else 0, sampler=1 if progressive else 0)
     k_cam = [cam[0], cam[0], cam[1] / 2.0, cam[2] / 2.0]
     size = (int(cam[1]), int(cam[2]))
     fragile = 0

@@ -880,6 +880,8 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     }
     // tracklets in HBM (pgi_tracklets_*, the default) or in the host store (host/tracklets.hpp); same results
     void setDeviceTracklets(bool on) { deviceTracklets = on; }
+    // processFeatures: progressive sampling over the matcher's ratio-sorted rows (pgi_params.sampler = 1; on by default there)
+    void setProgressiveSampling(bool on) { progressiveSampling = on; }
     // one process per GPU: the host-side channel of this rank (also install the engine's transport: dist::attach)
     void setHostComm(dist::HostComm* comm) { hostComm = comm; }
     uint32_t worldSize() const;
@@ -891,6 +893,7 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     dist::HostComm* hostComm = nullptr;
     bool rotationGuidedGuesses = false;
     bool deviceTracklets = true;
+    bool progressiveSampling = true;
     const size_t kCoreNumber, kMinimumInlierNumber, kMinimumPointNumber, kMaximumPointNumberForEpipolarHashing,
         kMaximumSearchDepth, kMaximumPathNumber, kMaximumTrackletNumber;
     const std::string kImagePath, kWorkspacePath, kSimilarityGraphPath, kFocalLengthPath;

@@ -76,7 +76,7 @@ def test_feature_pipeline_three_configurations(tmp_path):
 
     # the plain C++ run equals the same chain driven from Python through the C ABI, wave by wave, bit for bit
     from pyposegraphbuilder import Engine
-    eng = Engine(min_inliers=20)
+    eng = Engine(min_inliers=20, sampler=1)   # (processFeatures samples progressively over the matcher's ratio-sorted rows)
     try:
         images = [eng.prepare_descriptors(v["desc"]) for v in views]
         kps = [eng.upload_keypoints(v["xy"], *cam) for v in views]
