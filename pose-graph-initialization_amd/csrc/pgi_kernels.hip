@@ -40,6 +40,20 @@ constexpr uint32_t kNw1Pairs = 98304, kNw2Pairs = 12288;  // launch_estimate's r
 constexpr int QCAP = 40;       // models per wavefront pass (4 hypotheses x 10 roots)
 constexpr double QMAGIC = 393216.0;  // 1.5 * 2^18: summands rounded to multiples of 2^-34
 
+// Graph-cut local optimisation (prm.lo_graph_cut): the labelling context of a pair.  It lives in the workgroup's shared state,
+// written once by thread 0 and read by the (noinline) labelling code -- the fit itself carries ONE pointer to it and nothing
+// else, so the mode costs the default path no registers (passing the pieces through refit_wave0 spilled 21 more VGPRs in the
+// round loop: 2.7x HBM traffic on config 2).
+struct GcCtx {
+    uint32_t* prev;      // [n] predecessor of a row in its cell's chain (kGcNone: none); global
+    uint32_t* msg;       // [n] message words of the sweeps; global
+    uint8_t* lab;        // [n] the labelling (the pair's part of the mask output: the epilogue overwrites it at the end)
+    uint32_t* last;      // LDS, kGcCells words: last row seen per cell while the chains are built; 64 words of scratch afterwards
+    const float* e_lds;  // the model the cut is taken under (sh->bestE)
+    uint32_t lambda64;
+    uint32_t built;      // the pair's chains exist (built by wave 0 at the first refit)
+};
+
 template <int NW>
 struct WgShared {
     float bestE[9];
@@ -59,8 +73,8 @@ struct WgShared {
     int lo_score;       // results of a refit run by wave 0 (guess path) / refit counter
     uint32_t lo_ninl, lo_ni, lo_runs;
     float loE[9];
-    uint32_t gc_built;  // graph-cut local optimisation: the pair's neighbourhood chains exist (built by wave 0 at the first refit)
     double Rt[21];  // R1[9] R2[9] t[3]
+    GcCtx gc;  // graph-cut local optimisation: the pair's labelling context (see GcCtx)
 };
 
 struct K1Args {
@@ -230,14 +244,6 @@ PGI_DEV int enqueue_models(bool valid, const float E32[9], uint32_t hyp, float* 
 }
 
 // ---- graph-cut local optimisation: the labelling step on ONE wavefront (specification: oracle/pgi_oracle.c, pgo_gc_*) --------
-struct GcCtx {
-    uint32_t* prev;     // [n] predecessor of a row in its cell's chain (kGcNone: none); global
-    uint32_t* msg;      // [n] message words of the sweeps; global
-    uint8_t* lab;       // [n] the labelling (the pair's part of the mask output: the epilogue overwrites it at the end)
-    uint32_t* last;     // LDS, kGcCells words: last row seen per cell while the chains are built; 64 words of scratch afterwards
-    uint32_t lambda64;  // 0: threshold selection (no graph cut)
-};
-
 // prev[i] = the last row before i in the same 4-D grid cell.  64 rows per step: every lane looks its cell's last row up, all
 // write themselves, and a read-back tells who lost a collision -- only cells that occur twice in one step are sorted out one
 // by one (ballot over the lanes of the cell: the nearest lower lane is the predecessor, the highest lane stays in the table).
@@ -282,14 +288,18 @@ __device__ __noinline__ void gc_build_chains(const Rows<LDS_PTS>* rows_p, uint32
 // 64 rows per step in index order; dependencies inside a step are resolved by iterating over the lanes that have become ready
 // (a chain rarely has two rows in one step).  Writes lab[i] in {0, 1} and returns the number of inliers.
 template <int LDS_PTS>
-__device__ __noinline__ uint32_t gc_label_wave(const Rows<LDS_PTS>* rows_p, uint32_t n, uint32_t npad, const float* e_lds, float thr2,
-                                               const GcCtx* gp, int lane) {
+__device__ __noinline__ uint32_t gc_label_wave(const Rows<LDS_PTS>* rows_p, uint32_t n, uint32_t npad, float thr2, GcCtx* gp, int lane) {
     const Rows<LDS_PTS> rows = *rows_p;
+    if (!__builtin_amdgcn_readfirstlane((int)gp->built)) {  // the pair's chains, once
+        gc_build_chains<LDS_PTS>(rows_p, n, npad, gp, lane);
+        if (lane == 0) gp->built = 1u;
+        wave_sync();
+    }
     const GcCtx g = *gp;
     const uint32_t lam = g.lambda64;
     float e[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) e[c] = e_lds[c];
+    for (int c = 0; c < 9; ++c) e[c] = g.e_lds[c];
     for (uint32_t base = 0; base < npad; base += 64u) {
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = i < n;
@@ -362,6 +372,18 @@ __device__ __noinline__ uint32_t gc_label_wave(const Rows<LDS_PTS>* rows_p, uint
     }
     wave_sync();
     return cnt;
+}
+
+// (the row source by value: its address must not leave the fit, or the whole fit keeps it in scratch memory)
+template <int LDS_PTS>
+__device__ __noinline__ uint32_t gc_label_rows(const float4* lds, const float* x1, const float* y1, const float* x2, const float* y2, uint32_t n,
+                                               uint32_t lds_n, uint32_t npad, float thr2, GcCtx* gp, int lane) {
+    Rows<LDS_PTS> rows;
+    rows.lds = lds;
+    rows.x1 = x1; rows.y1 = y1; rows.x2 = x2; rows.y2 = y2;
+    rows.n = n;
+    rows.lds_n = lds_n;
+    return gc_label_wave<LDS_PTS>(&rows, n, npad, thr2, gp, lane);
 }
 
 // Inlier set of model E at bound tau2 -> exact 9x9 normal matrix in loA (LDS) and the inlier
@@ -572,8 +594,7 @@ template <int LDS_PTS>
 PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npad, const float E[9], float tau2,
                              float thr2, double* wscr0, uint32_t* qhyp0, int lane, int floor_score, uint32_t n_bar,
                              int& r_score, uint32_t& r_ninl, int& r_idx, Prof& prof, int ni_pre = -1,
-                             uint32_t lin_pct = 0u, const GcCtx* gc = nullptr, const float* e_lds = nullptr,
-                             uint32_t* gc_built = nullptr) {
+                             uint32_t lin_pct = 0u, GcCtx* gc = nullptr) {
     double* loA = wscr0 + W_REGA + G_REGA_SZ;  // 81
     double* loV = loA + 81;                    // 81 (ends at W_REGA + 228 <= W_DOUBLES)
     double* tri = wscr0 + G_BASIS_SZ;          // 45 doubles over basis of groups 1..2
@@ -585,14 +606,9 @@ PGI_DEV uint32_t refit_wave0(const Rows<LDS_PTS>& rows, uint32_t n, uint32_t npa
     uint32_t ni;
     if (ni_pre >= 0) {
         ni = (uint32_t)ni_pre;  // the workgroup already built A (first refit after a merge)
-    } else if (gc && gc->lambda64) {
-        // graph-cut local optimisation: the refit's rows are the minimum cut of the spatial-coherence energy under E
-        if (!__builtin_amdgcn_readfirstlane((int)*gc_built)) {
-            gc_build_chains<LDS_PTS>(&rows, n, npad, gc, lane);
-            if (lane == 0) *gc_built = 1u;
-            wave_sync();
-        }
-        (void)gc_label_wave<LDS_PTS>(&rows, n, npad, e_lds, thr2, gc, lane);
+    } else if (gc) {
+        // graph-cut local optimisation: the refit's rows are the minimum cut of the spatial-coherence energy under the best model
+        (void)gc_label_rows<LDS_PTS>(rows.lds, rows.x1, rows.y1, rows.x2, rows.y2, n, rows.lds_n, npad, thr2, gc, lane);
         ni = normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane, gc->lab);
     } else {
         ni = normal_matrix_wave<LDS_PTS>(rows, npad, E, tau2, loA, tri, lane);
@@ -707,7 +723,15 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
         sh->pass_ctr = 0;
         sh->nbar = 0;
         sh->lo_runs = 0;
-        sh->gc_built = 0;
+        if (a.gc_prev) {  // graph-cut local optimisation: the pair's labelling context
+            sh->gc.prev = a.gc_prev + o;
+            sh->gc.msg = a.gc_msg + o;
+            sh->gc.lab = mask;
+            sh->gc.last = reinterpret_cast<uint32_t*>(smem + a.gc_lds_off);
+            sh->gc.e_lds = sh->bestE;
+            sh->gc.lambda64 = min(a.prm.lo_graph_cut, 255u);
+            sh->gc.built = 0;
+        }
     }
     __syncthreads();
     prof.mark<0>();
@@ -736,23 +760,12 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
     // Local optimisation of the current best (sh->bestE): up to lo_iters n-point refits while they improve.  Called by
     // ALL threads right after a merge (the first normal matrix is built by the whole workgroup); the refits themselves
     // run on wave 0, which is the only writer of the best until the next workgroup barrier.
-    // graph-cut local optimisation (prm.lo_graph_cut): the labelling context, rebuilt where it is needed (nothing of it is
-    // carried across the round loop)
-    auto make_gc = [&]() {
-        GcCtx g;
-        g.prev = a.gc_prev ? a.gc_prev + o : nullptr;
-        g.msg = a.gc_msg ? a.gc_msg + o : nullptr;
-        g.lab = mask;
-        g.last = reinterpret_cast<uint32_t*>(smem + a.gc_lds_off);
-        g.lambda64 = a.gc_prev ? min(prm.lo_graph_cut, 255u) : 0u;
-        return g;
-    };
     auto local_optimise = [&]() {
         if constexpr (!GUESS) return;  // only the guess variants call it (keeps the plain kernel's code unchanged)
         int ni_first = -1;
-        const GcCtx gc = make_gc();
+        GcCtx* const gc = a.gc_prev ? &sh->gc : nullptr;  // (uniform: a kernel argument)
         if constexpr (NW > 1) {  // (a one-wavefront workgroup builds every normal matrix inside refit_wave0)
-            if (prm.lo_iters && !gc.lambda64) {  // (graph-cut mode: the row set is wave 0's labelling, no shared first matrix)
+            if (prm.lo_iters && !gc) {  // (graph-cut mode: the row set is wave 0's labelling, no shared first matrix)
                 float bE0[9];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
@@ -773,8 +786,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 int ln = lane;  // opaque copy: keeps the refit's lane-derived addresses out of the round loop's live set
                 asm volatile("" : "+v"(ln));
                 const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best, cur_ninl,
-                                                                r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct,
-                                                                &gc, sh->bestE, &sh->gc_built);
+                                                                r_score, r_ninl, r_idx, prof, it == 0 ? ni_first : -1, prm.lo_linear_pct, gc);
                 if (ni < 5) break;
                 if (lane == 0) sh->lo_runs += 1;
                 if (!(r_score > cur_best)) break;
@@ -1086,8 +1098,8 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                 // (same steps as local_optimise() above, spelled out: inside the round loop the compiler schedules the
                 // inline form measurably better than the shared lambda -- 2 % on BASELINE config 2)
                 int ni_first = -1;
-                const GcCtx gc = make_gc();
-                if (NW > 1 && prm.lo_iters && !gc.lambda64) {  // every wavefront is here anyway: build the first refit's normal matrix together
+                GcCtx* const gc = a.gc_prev ? &sh->gc : nullptr;  // (uniform: a kernel argument)
+                if (NW > 1 && prm.lo_iters && !gc) {  // every wavefront is here anyway: build the first refit's normal matrix together
                     float bE0[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) bE0[c] = sh->bestE[c];
@@ -1113,7 +1125,7 @@ __device__ __forceinline__ void estimate_pair(const K1Args& a, const uint32_t pa
                         asm volatile("" : "+v"(ln));
                         const uint32_t ni = refit_wave0<LDS_PTS>(rows, n, npad, bE, thr2, thr2, wscr_all, sh->q_hyp[0], ln, cur_best,
                                                                        cur_ninl, r_score, r_ninl, r_idx, prof,
-                                                                       it == 0 ? ni_first : -1, prm.lo_linear_pct, &gc, sh->bestE, &sh->gc_built);
+                                                                       it == 0 ? ni_first : -1, prm.lo_linear_pct, gc);
                         if (ni < 5) break;
                         if (lane == 0) sh->lo_runs += 1;
                         if (!(r_score > cur_best)) break;

@@ -12,10 +12,16 @@ from pyposegraphbuilder import Engine, synthetic as S
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 cases = [dict(), dict(round_size=8), dict(lo_iters=0), dict(fixed_budget=96), dict(confidence=0.999, max_iters=300),
          dict(min_inliers=5, vote_all_rows=1), dict(lo_linear_pct=0), dict(guess_mode=1), dict(lo_linear_pct=10, lo_iters=3),
-         dict(guess_mode=1, round_size=16, lo_linear_pct=60), dict(sampler=1), dict(sampler=1, max_iters=160, round_size=24)]
+         dict(guess_mode=1, round_size=16, lo_linear_pct=60), dict(sampler=1), dict(sampler=1, max_iters=160, round_size=24),
+         dict(lo_graph_cut=9), dict(lo_graph_cut=9, guess_mode=1), dict(lo_graph_cut=40, lo_linear_pct=0, lo_iters=3), dict(lo_graph_cut=3, sampler=1)]
+if os.environ.get("SOAK_CASES"):   # e.g. SOAK_CASES=12,13,14,15: only these
+    keep = [int(v) for v in os.environ["SOAK_CASES"].split(",")]
+    cases = [c if i in keep else None for i, c in enumerate(cases)]
 total = 0
 t00 = time.time()
 for ci, kw in enumerate(cases):
+    if kw is None:
+        continue
     rng = np.random.default_rng(1000 + ci)
     sizes = rng.choice([5, 6, 7, 9, 16, 33, 64, 65, 100, 127, 128, 129, 200, 257, 400, 700, 1200, 2500], P)
     ids = np.arange(ci * 1000000, ci * 1000000 + P)
@@ -57,18 +63,19 @@ b = S.make_batch(np.arange(7000000, 7000000 + Pb), sizes, inlier_ratio=0.45, noi
 guesses = np.zeros((Pb, 12)); has = (rng.random(Pb) < 0.25).astype(np.uint8)
 for i in np.nonzero(has)[0]:
     guesses[i, :9], guesses[i, 9:] = b["R"][i].ravel(), b["t"][i]
-eng = Engine()
-db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has, seed=99)
-e, m = eng.estimate_pose_batch(db)
-got, masks = eng.edges_to_numpy(e), m.cpu().numpy()
-exp, emask = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(), 99,
-                                   guesses=guesses, has_guess=has, threads=0)
-ok = np.array_equal(masks, emask) and all(np.array_equal(got[k], exp[k]) for k in ("status", "n_inl", "score", "iters", "E", "R", "t", "votes", "cand", "used_guess", "lo_runs"))
-print("big pairs (2176..12000 rows): %d pairs, %d rows: %s" % (Pb, len(masks), "IDENTICAL" if ok else "MISMATCH"))
-if not ok:
-    sys.exit(1)
-total += Pb
-eng.close()
+for kwb in (dict(), dict(lo_graph_cut=9)):   # (round 6: also with graph-cut local optimisation -- chains across every rows variant)
+    eng = Engine(**kwb)
+    db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, guesses=guesses, has_guess=has, seed=99)
+    e, m = eng.estimate_pose_batch(db)
+    got, masks = eng.edges_to_numpy(e), m.cpu().numpy()
+    exp, emask = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(**kwb), 99,
+                                       guesses=guesses, has_guess=has, threads=0)
+    ok = np.array_equal(masks, emask) and all(np.array_equal(got[k], exp[k]) for k in ("status", "n_inl", "score", "iters", "E", "R", "t", "votes", "cand", "used_guess", "lo_runs"))
+    print("big pairs (2176..12000 rows) %s: %d pairs, %d rows: %s" % (kwb, Pb, len(masks), "IDENTICAL" if ok else "MISMATCH"))
+    if not ok:
+        sys.exit(1)
+    total += Pb
+    eng.close()
 print("estimator soak ok: %d pairs identical in %.0f s" % (total, time.time() - t00))
 
 # ---- matchers: screened descriptor matcher and guided matcher vs the oracle ----
