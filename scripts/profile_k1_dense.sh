@@ -29,6 +29,7 @@ run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 rm -rf ${OUT}_t
+make -C pose-graph-initialization_amd libpgi_prof.so > gpurun_out/${T}_k1_dense_prof_build.log 2>&1   # (the instrumented build of THESE sources)
 echo "# kernel sources sha256 $SHA; instrumented build (libpgi_prof.so), pairs of at most 1344 rows, four wavefronts per pair (PGI_K1_NW=4), then one (PGI_K1_NW=1)" > ${OUT}_phases.txt
 PGI_K1_NW=4 python3 scripts/profile_phases.py 20000 v5000:1344 2>&1 | grep -v amdgpu.ids >> ${OUT}_phases.txt
 PGI_K1_NW=1 python3 scripts/profile_phases.py 20000 v5000:1344 2>&1 | grep -v amdgpu.ids >> ${OUT}_phases.txt

@@ -56,6 +56,9 @@ for i in range(25):
 # leaves when its class's list is dry, so (1 - residence / span) is the share of slot time the launch's wind-down leaves empty.
 occ = raw[32:].view(np.uint64).reshape(3, 4)
 used = [i for i in range(3) if occ[i, 3]]
+if not used:
+    print("(no occupancy counters: libpgi_prof.so predates round 6 -- rebuild it: make -C pose-graph-initialization_amd libpgi_prof.so)")
+    sys.exit(0)
 t_first = min(int(~occ[i, 2] & 0xFFFFFFFFFFFFFFFF) for i in used)
 for i in used:
     start, end = int(~occ[i, 2] & 0xFFFFFFFFFFFFFFFF), int(occ[i, 1])
