@@ -133,9 +133,11 @@ def test_bench_summary_and_amdahl_helpers():
     a = bench.amdahl(0.12, 0.03)
     assert a == {"n2": round(0.12 / (0.03 + 0.045), 2), "n4": round(0.12 / (0.03 + 0.0225), 2), "n8": round(0.12 / (0.03 + 0.01125), 2)}
     assert bench.amdahl(0.1, 0.0)["n8"] == 8.0 and bench.amdahl(0.1, 0.2)["n8"] == 1.0
-    line = json.load(open(os.path.join(SC.ROOT, "profiles", "r05_bench.json")))
+    line = json.load(open(os.path.join(SC.ROOT, "profiles", "r06_bench_full.json")))   # the full record of the round's final run
     s = bench.compact_summary({k: v for k, v in line.items() if k != "summary"})
-    assert s == line["summary"] and len(json.dumps(s)) < 1024
+    assert s == line["summary"] and len(json.dumps(s)) < 2048
+    # ... and the line the driver parses is built from it (tests/test_bench_line.py holds the size and key checks)
+    assert json.loads(bench.compact_line(line))["summary"] == bench._short(s)
     assert list(line)[-1] == "summary"                                   # the last key of the line
     for key in ("k1_edges_per_s", "k1_frac_hbm", "k2_frac_hbm", "match_exact_frac_mfma", "config3_s", "config4_s", "config4_cpu_parity",
                 "config5_guided_s", "worst_over_median_repetition"):
