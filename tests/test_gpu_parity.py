@@ -875,3 +875,40 @@ def test_graph_cut_local_optimisation_matches_the_oracle(nw, monkeypatch):
         assert np.array_equal(m1, om) and np.array_equal(np.array(edge.E), one["E"][0])
     finally:
         e.close()
+
+
+def test_graph_cut_through_the_host_pointer_entries():
+    """lo_graph_cut with host buffers in and out: pgi_estimate_pose_batch_host cuts the batch into chunks and hands every chunk's row
+    count to the launcher (the two scratch words per row follow the chunk's size-bucket lists); page-locked buffers are NOT worked
+    on in place in this mode (the labelling's second pass over the rows would fetch them over PCIe again) but copied like pageable
+    ones.  Both must equal the resident launch, which equals the oracle."""
+    from pyposegraphbuilder import Engine
+    rng = np.random.default_rng(5)
+    eng = Engine(lo_graph_cut=9)
+    try:
+        P = 2200
+        sizes = rng.choice([5, 40, 64, 300, 700, 1300, 1500, 2100, 2600, 4100], P)
+        b = S.make_batch(np.arange(61000, 61000 + P), sizes)
+        db = eng.upload(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, seed=3, pair_id_base=61000)
+        e, m = eng.estimate_pose_batch(db)
+        ref, ref_m = eng.edges_to_numpy(e), m.cpu().numpy()
+        exp, em = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(lo_graph_cut=9), 3,
+                                        pair_id_base=61000)
+        assert np.array_equal(ref_m, em)
+        assert_edges_match(ref, exp)
+        xs = [np.array(b[k], np.float32) for k in ("x1", "y1", "x2", "y2")]
+        got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=61000)      # pageable
+        assert np.array_equal(got_m, ref_m)
+        for k in ref.dtype.names:
+            assert np.array_equal(got[k], ref[k]), k
+        out = (np.zeros(P, ref.dtype), np.zeros(len(ref_m), np.uint8))
+        eng.pin(*xs, *out)
+        try:
+            got, got_m = eng.estimate_pose_batch_host(*xs, b["offsets"], 7.5e-4, seed=3, pair_id_base=61000, out=out)  # page-locked
+            assert np.array_equal(got_m, ref_m)
+            for k in ref.dtype.names:
+                assert np.array_equal(got[k], ref[k]), k
+        finally:
+            eng.unpin(*xs, *out)
+    finally:
+        eng.close()
