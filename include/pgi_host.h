@@ -44,6 +44,11 @@ pgih_builder* pgih_create(const pgih_config* cfg);   /* NULL on failure (no HIP 
 void pgih_destroy(pgih_builder* b);
 /* pgi_params.guess_mode of the builder's engine: 1 = rotation-guided re-estimation of chained poses (BASELINE config 5) */
 int pgih_set_rotation_guided(pgih_builder* b, int on);
+/* pgi_params.lo_graph_cut of the builder's engine: lambda * 64 > 0 (9 ~ the paper's 0.14) = graph-cut local optimisation, the "GC" of
+ * GC-RANSAC (the refit's rows are the minimum cut of the spatial-coherence energy; include/pgi.h), 0 = off (the default) */
+int pgih_set_graph_cut(pgih_builder* b, uint32_t lambda64);
+/* progressive sampling (pgi_params.sampler = 1) in pgih_run_features over the matcher's ratio-sorted rows: on by default */
+int pgih_set_progressive_sampling(pgih_builder* b, int on);
 /* PoseGraphBuilder::run over caller-provided candidate pairs.  Pair p: views src[p] -> dst[p], retrieval similarity,
  * normalised threshold thr[p], correspondences rows [offsets[p], offsets[p+1]) of corr_aos (n x 4 doubles, the reference's
  * cv::Mat N x 4 CV_64F; read in place, never copied on the host).  n_views: every id must be below it (0 = derive it from

@@ -73,7 +73,7 @@ def essential_from_pose(R, t):
 
 
 def run_waves(O, pairs, similarity, n_views, wave_size, *, path_finding=True, rotation_guided=False, min_inliers=20,
-              min_points=50, similarity_threshold=0.05, weight=0.8, max_depth=5, seed_base=0):
+              min_points=50, similarity_threshold=0.05, weight=0.8, max_depth=5, seed_base=0, graph_cut=0):
     """pairs: list of dict(src, dst, similarity, thr, x1, y1, x2, y2 (float32 arrays)).  similarity(a, b) -> table value.
     O: the oracle binding (tests/oracle_lib.py).  Returns (statistics dict, edges in insertion order)."""
     order = sorted(range(len(pairs)), key=lambda i: (-pairs[i]["similarity"], pairs[i]["src"], pairs[i]["dst"]))
@@ -82,7 +82,7 @@ def run_waves(O, pairs, similarity, n_views, wave_size, *, path_finding=True, ro
     st = dict(pairs_processed=0, edges_added=0, paths_searched=0, paths_found=0, touched_nodes=0, poses_from_guess=0,
               hypotheses=0, waves=0, quirk_only_guesses=0)
     edges = []
-    prm = O.default_params(min_inliers=min_inliers, guess_mode=1 if rotation_guided else 0)
+    prm = O.default_params(min_inliers=min_inliers, guess_mode=1 if rotation_guided else 0, lo_graph_cut=graph_cut)
     seed = seed_base
 
     def flush(wave):

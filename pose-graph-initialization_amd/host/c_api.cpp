@@ -98,6 +98,22 @@ int pgih_set_rotation_guided(pgih_builder* b, int on) {
     });
 }
 
+int pgih_set_graph_cut(pgih_builder* b, uint32_t lambda64) {
+    if (!b) return fail("pgih_set_graph_cut: null builder");
+    return guarded("pgih_set_graph_cut", [&]() {
+        b->impl->setGraphCutLocalOptimisation(lambda64);
+        return 0;
+    });
+}
+
+int pgih_set_progressive_sampling(pgih_builder* b, int on) {
+    if (!b) return fail("pgih_set_progressive_sampling: null builder");
+    return guarded("pgih_set_progressive_sampling", [&]() {
+        b->impl->setProgressiveSampling(on != 0);
+        return 0;
+    });
+}
+
 int pgih_run_pairs(pgih_builder* b, uint32_t n_views, uint32_t n_pairs, const uint32_t* src, const uint32_t* dst,
                    const double* similarity, const double* thr, const uint64_t* offsets, const double* corr_aos, uint32_t wave_size,
                    uint64_t seed, pgih_graph_edge* edges, uint32_t edge_capacity, uint32_t* n_edges, uint64_t* stats) {

@@ -882,6 +882,13 @@ class PoseGraphBuilder {  // include/pose_graph_builder.h:25-171
     void setDeviceTracklets(bool on) { deviceTracklets = on; }
     // processFeatures: progressive sampling over the matcher's ratio-sorted rows (pgi_params.sampler = 1; on by default there)
     void setProgressiveSampling(bool on) { progressiveSampling = on; }
+    // graph-cut local optimisation (pgi_params.lo_graph_cut = lambda * 64; 0 = off, the default): the "GC" of GC-RANSAC
+    void setGraphCutLocalOptimisation(uint32_t lambda64) {
+        pgi_params p;
+        Engine::check(pgi_get_params(engine->get(), &p));
+        p.lo_graph_cut = lambda64;
+        Engine::check(pgi_set_params(engine->get(), &p));
+    }
     // one process per GPU: the host-side channel of this rank (also install the engine's transport: dist::attach)
     void setHostComm(dist::HostComm* comm) { hostComm = comm; }
     uint32_t worldSize() const;

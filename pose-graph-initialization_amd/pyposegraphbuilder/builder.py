@@ -72,12 +72,13 @@ class PoseGraphBuilder:
         ok, e, mask = self.engine.estimate_pose(correspondences, threshold, poseGuesses, seed=seed, pair_id=pairId)
         return ok, np.array(e.R).reshape(3, 3), np.array(e.t), mask, int(e.n_inl)
 
-    def run(self, pairs, waveSize=4096, seed=0, *, rotationGuided=False, numViews=0):
+    def run(self, pairs, waveSize=4096, seed=0, *, rotationGuided=False, numViews=0, graphCut=0):
         """pairs: iterable of dict(src, dst, similarity, correspondences[N,4], threshold).
         Returns the pose graph {(src, dst): dict(R, t, score)}; score = inliers / matches (:645-654).
         seed: wave w of the run draws its hypotheses with seed + w.  rotationGuided (keyword only): BASELINE config 5's
         re-estimation of chained poses, set on the C++ builder for THIS call and restored afterwards.  numViews: every
-        view id must be below it (0 = derived from the ids).
+        view id must be below it (0 = derived from the ids).  graphCut (keyword only): lambda * 64 of the graph-cut local
+        optimisation (pgi_params.lo_graph_cut; 9 ~ 0.14; 0 = off), for this call.
 
         This IS the C++ scheduler (host/pose_graph_builder.cpp PoseGraphBuilder::run behind pgih_run_pairs of
         libpgi_host.so, include/pgi_host.h): descending-similarity waves, and -- with kUsePathFinding -- A* pose guesses
@@ -95,7 +96,7 @@ class PoseGraphBuilder:
         off[1:] = np.cumsum([len(r) for r in rows])
         corr = np.concatenate(rows) if P else np.zeros((0, 4))
         lib, h = self._host()
-        if lib.pgih_set_rotation_guided(h, int(bool(rotationGuided))) < 0:
+        if lib.pgih_set_rotation_guided(h, int(bool(rotationGuided))) < 0 or lib.pgih_set_graph_cut(h, int(graphCut)) < 0:
             raise RuntimeError(lib.pgih_last_error().decode())
         edges = np.zeros(max(P, 1), _GRAPH_EDGE)
         n_edges = C.c_uint32(0)
@@ -106,8 +107,10 @@ class PoseGraphBuilder:
                                     int(seed), ptr(edges), len(edges), C.byref(n_edges), ptr(stats))
             err = lib.pgih_last_error().decode() if rc < 0 else None
         finally:
-            if rotationGuided:  # the switch belongs to this call, not to the builder
+            if rotationGuided:  # the switches belong to this call, not to the builder
                 lib.pgih_set_rotation_guided(h, 0)
+            if graphCut:
+                lib.pgih_set_graph_cut(h, 0)
         if rc < 0:
             raise RuntimeError(err)
         self.statistics = dict(zip(("pairs_processed", "edges_added", "paths_searched", "paths_found", "touched_nodes",
@@ -181,6 +184,8 @@ class PoseGraphBuilder:
         lib.pgih_create.argtypes = [C.POINTER(_HostConfig)]
         lib.pgih_destroy.argtypes = [C.c_void_p]
         lib.pgih_set_rotation_guided.argtypes = [C.c_void_p, C.c_int]
+        lib.pgih_set_graph_cut.argtypes = [C.c_void_p, C.c_uint32]
+        lib.pgih_set_progressive_sampling.argtypes = [C.c_void_p, C.c_int]
         lib.pgih_run_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32,
                                                                                                  C.POINTER(C.c_uint32), C.c_void_p]
         lib.pgih_run_features.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,

@@ -29,7 +29,7 @@ def test_host_library_exports_and_header_symbols():
     hdr_h = open(os.path.join(ROOT, "include", "pgi_host.h")).read()
     declared_h = set(re.findall(r"\b(pgih_[a-z0-9_]+)\s*\(", hdr_h))
     assert declared_h == {"pgih_last_error", "pgih_create", "pgih_destroy", "pgih_set_rotation_guided", "pgih_run_pairs", "pgih_run_features",
-                          "pgih_bind_process_to_device_node"}
+                          "pgih_bind_process_to_device_node", "pgih_set_graph_cut", "pgih_set_progressive_sampling"}
     for s in declared_h:
         assert hasattr(host, s), s
     host.pgih_create.restype = C.c_void_p

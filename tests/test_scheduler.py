@@ -144,3 +144,46 @@ def test_next_wave_prefetch_equals_the_sequential_scheduler(tmp_path, mode):
             assert stats["pairs_processed"] < len(g2["pairs"]) and stats["pairs_processed"] >= len(g["pairs"]) - 2
             keys = {(int(e["src"]), int(e["dst"])) for e in edges}
             assert not any((int(d), int(s_)) in keys and (int(s_), int(d)) in keys for s_, d in g["pairs"][dup])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("guided", [False, True])
+def test_python_builder_run_with_graph_cut_equals_the_cpu_restatement(guided):
+    """pgih_set_graph_cut (include/pgi_host.h) through the Python builder: the A*-scheduled run with graph-cut local optimisation
+    (lambda * 64 = 9) equals oracle/scheduler_oracle.py with the same switch -- same edges in the same order, scores equal,
+    poses to 1e-9 -- differs from the default run, and the switch is restored afterwards."""
+    import oracle_lib as O
+    import scheduler_oracle as SO
+    import scene_drivers as SC
+    from pyposegraphbuilder import PoseGraphBuilder
+    V, wave = 60, 48
+    g = S.make_scene_graph(V, k=6, seed=9, outlier_pair_frac=0.03)
+    b, sim = g["batch"], SC.pair_similarity(g)
+    table, pairs_o, pairs_b = {}, [], []
+    for e, (i, j) in enumerate(g["pairs"]):
+        a, z = int(b["offsets"][e]), int(b["offsets"][e + 1])
+        table[(int(i), int(j))] = table[(int(j), int(i))] = float(sim[e])
+        pairs_o.append(dict(src=int(i), dst=int(j), similarity=float(sim[e]), thr=7.5e-4, x1=b["x1"][a:z], y1=b["y1"][a:z],
+                            x2=b["x2"][a:z], y2=b["y2"][a:z]))
+        pairs_b.append(dict(src=int(i), dst=int(j), similarity=float(sim[e]), threshold=7.5e-4,
+                            correspondences=np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1)))
+    lookup = lambda p, q: 1.0 if p == q else table.get((p, q), 0.0)
+    st, ref = SO.run_waves(O, pairs_o, lookup, V, wave, path_finding=True, rotation_guided=guided, graph_cut=9)
+    builder = PoseGraphBuilder(20, 5000, 5, 100, 20, 50, 100, 0.8, 0.05, 0.4, "", "", "", "", True, True, True)
+    try:
+        graph = builder.run(pairs_b, waveSize=wave, rotationGuided=guided, numViews=V, graphCut=9)
+        stats_gc = dict(builder.statistics)
+        plain = builder.run(pairs_b, waveSize=wave, rotationGuided=guided, numViews=V)      # the switch did not stick
+    finally:
+        builder.close()
+    assert len(graph) == len(ref) == stats_gc["graph_edges"]
+    for key in ("pairs_processed", "edges_added", "paths_searched", "paths_found", "poses_from_guess", "hypotheses", "waves"):
+        assert stats_gc[key] == st[key], (key, stats_gc[key], st[key])
+    for (s_, d_, score, R, t), (key, e) in zip(ref, graph.items()):
+        assert key == (s_, d_) and e["score"] == score
+        assert np.abs(e["R"] - R).max() < 1e-9 and np.abs(e["t"] - t).max() < 1e-9
+    st0, ref0 = SO.run_waves(O, pairs_o, lookup, V, wave, path_finding=True, rotation_guided=guided)
+    assert len(plain) == len(ref0)
+    for (s_, d_, score, R, t), (key, e) in zip(ref0, plain.items()):
+        assert key == (s_, d_) and e["score"] == score and np.abs(e["R"] - R).max() < 1e-9
+    assert any(not np.array_equal(graph[k]["R"], plain[k]["R"]) for k in graph if k in plain)   # the mode changes the refits
