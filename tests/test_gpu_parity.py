@@ -912,3 +912,37 @@ def test_graph_cut_through_the_host_pointer_entries():
             eng.unpin(*xs, *out)
     finally:
         eng.close()
+
+
+def test_graph_cut_single_pair_seam_from_many_threads():
+    """pgi_estimate_pose with lo_graph_cut from 12 threads at once: every call leases its own slot, and the labelling's two scratch
+    words per row live INSIDE the slot's device block -- nothing shared between concurrent callers.  Every answer equals the oracle."""
+    import threading
+    from pyposegraphbuilder import Engine
+    sizes = [257, 600, 64, 1500, 333, 1024, 90, 2100, 700, 129, 1344, 45]
+    b = S.make_batch(range(71000, 71000 + len(sizes)), sizes, inlier_ratio=0.55)
+    exp, em = O.estimate_pose_batch(b["x1"], b["y1"], b["x2"], b["y2"], b["offsets"], 7.5e-4, O.default_params(lo_graph_cut=9), 13,
+                                    pair_id_base=71000)
+    off = b["offsets"].astype(np.int64)
+    eng = Engine(lo_graph_cut=9)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(4):
+                p = (t + rep * 5) % len(sizes)
+                a, z = int(off[p]), int(off[p + 1])
+                corr = np.stack([b["x1"][a:z], b["y1"][a:z], b["x2"][a:z], b["y2"][a:z]], 1).astype(np.float64)
+                ok, edge, m = eng.estimate_pose(corr, 7.5e-4, seed=13, pair_id=71000 + p)
+                assert np.array_equal(m, em[a:z]) and np.array_equal(np.array(edge.E), exp["E"][p]) and int(edge.iters) == int(exp["iters"][p]), p
+        except Exception as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+    try:
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    finally:
+        eng.close()
+    assert not errors, errors[:3]
