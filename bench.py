@@ -600,6 +600,118 @@ def main():
                                "frac": round(tfs / 157.3, 4), "hypotheses_per_edge": round(T_mean, 1),
                                "note": "SURVEY 8d formula; nominal work, not executed flops"}
 
+    # (round 6: the variants and the graph-level legs run BEFORE the secondary kernels -- after the matcher leg, which draws the chip's
+    #  full power for seconds, the driver children of configs 4 / 5 read 10-20 % slower: 0.099 / 0.112 s against 0.089 / 0.092 s)
+    if rank == 0 and world == 1 and not args.no_variants and not args.fixed_budget:
+        # ---- SURVEY 8d's other settings of config 2 (same kernel, same 10 000 pairs; never `value`) -------------------
+        def run_variant(batch, thr_v, reps=3, **prm_v):
+            if prm_v:
+                eng.set_params(**prm_v)
+            try:
+                return run_variant_(batch, thr_v, reps)
+            finally:
+                if prm_v:
+                    eng.set_params(**{k: 0 for k in prm_v})   # (only switches that default to 0 are varied here: sampler)
+
+        def run_variant_(batch, thr_v, reps):
+            dbv = eng.upload(batch["x1"], batch["y1"], batch["x2"], batch["y2"], batch["offsets"], thr_v, seed=seed, pair_id_base=pair_base)
+            ev_, mv_ = eng.estimate_pose_batch(dbv)
+            torch.cuda.synchronize()
+            a_, z_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(reps):
+                ev_, mv_ = eng.estimate_pose_batch(dbv)
+            z_.record()
+            torch.cuda.synchronize()
+            ms_ = a_.elapsed_time(z_) / reps
+            gv = eng.edges_to_numpy(ev_)
+            okv = gv["status"] == 1
+            Pv = len(gv)
+            ev_deg = np.array([S.rot_err_deg(gv["R"][i].reshape(3, 3), batch["R"][i]) if okv[i] else np.inf for i in range(Pv)])
+            rows_v = int(batch["offsets"][-1])
+            return {"edges_per_s": round(Pv / (ms_ * 1e-3), 1), "kernel_ms": round(ms_, 3), "rows": rows_v,
+                    "rows_per_s": round(rows_v / (ms_ * 1e-3), 1), "rot_err_auc_at_5deg": round(S.auc_at(ev_deg, 5.0), 4),
+                    "edges_ok": int(okv.sum()), "mean_hypotheses": round(float(gv["iters"].mean()), 1)}
+        variants = {}
+        t0 = time.time()
+        variants["thr_0.4px"] = dict(run_variant(b, 0.4 / S.FOCAL_PX), note="the reference's default threshold (examples/cpp_example.cpp:51)")
+        ids_v = np.arange(pair_base, pair_base + P)
+        sizes_v = S.ragged_sizes(ids_v)
+        variants["ragged_N_U50_4000"] = dict(run_variant(S.make_batch(ids_v, sizes_v), thr),
+                                             note="N ~ U{50..4000} per pair: bucketed on the device into occupancy classes, one launch per class")
+        for rho_v in (0.3, 0.7):
+            variants["inlier_ratio_%.1f" % rho_v] = run_variant(S.make_batch(ids_v, N, inlier_ratio=rho_v), thr)
+        # Progressive sampling (pgi_params.sampler = 1) where the iteration cap binds, on rows in the reference's order
+        # (ascending SNN ratio, feature_utils.h:184-186; S.ratio_sorted): VERDICT r5 item 9.  Uniform sampling on the
+        # same sorted rows beside it (the order alone changes nothing for a uniform sampler).
+        b_lo = S.ratio_sorted(S.make_batch(ids_v, N, inlier_ratio=0.3))
+        b_srt = S.ratio_sorted(b)
+        variants["inlier_ratio_0.3_ratio_sorted_uniform"] = run_variant(b_lo, thr)
+        variants["inlier_ratio_0.3_ratio_sorted_progressive"] = dict(run_variant(b_lo, thr, sampler=1), note="sampler = 1")
+        variants["thr_0.4px_ratio_sorted_uniform"] = run_variant(b_srt, 0.4 / S.FOCAL_PX)
+        variants["thr_0.4px_ratio_sorted_progressive"] = dict(run_variant(b_srt, 0.4 / S.FOCAL_PX, sampler=1), note="sampler = 1")
+        del b_lo, b_srt
+        # Graph-cut local optimisation (pgi_params.lo_graph_cut = 9: lambda 0.14, the "GC" of GC-RANSAC; off by default): the refit's
+        # rows are the minimum cut of the spatial-coherence energy.  Same kernel, same batches as `value` / inlier_ratio_0.3.
+        variants["graph_cut_lo"] = dict(run_variant(b, thr, lo_graph_cut=9), note="config 2's batch with lo_graph_cut = 9")
+        variants["inlier_ratio_0.3_graph_cut_lo"] = dict(run_variant(S.make_batch(ids_v, N, inlier_ratio=0.3), thr, lo_graph_cut=9), note="lo_graph_cut = 9")
+        variants["seconds_incl_generation"] = round(time.time() - t0, 1)
+        out["variants"] = variants
+        # ---- graph level (BASELINE configs 3 / 4 / 5 on their surrogates AT SURVEY 8d's DENSITY; 1DSfM data is on neither box):
+        # the C++ host layer (tests/cpp/test_distributed.cpp: PoseGraphBuilder::estimateAndAverage / run + averageRotations)
+        # as a child process, its own wall clock and stage clocks, warm repetition; global rotation error after gauge
+        # alignment, AUC@5 of the estimated edges
+        out["graphs"] = graph_level(1, eng=eng, torch=torch)
+        import scene_drivers as SC
+        # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
+        # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
+        # -> createCorrespondenceMatrix -> A* guesses -> estimatePose -> guided matching -> tracklets in HBM -- as a child
+        # process (tests/cpp/test_pipeline.cpp), warm repetition, its own wall clock and stage split
+        if os.path.exists(SC.PIPELINE_EXE):
+            t0 = time.time()
+            fviews, fposes, fcam, fsim, fpairs = S.make_feature_scene(340, 8000, band=20)
+            gen_f = time.time() - t0
+            with tempfile.TemporaryDirectory() as tmpd:
+                fin, fout = os.path.join(tmpd, "features.bin"), os.path.join(tmpd, "features.out")
+                SC.write_feature_scene(fin, fviews, fcam, fsim, fpairs, 512)
+                kp_mean = float(np.mean([len(v["xy"]) for v in fviews]))
+                del fviews
+                import subprocess
+                r = subprocess.run([SC.PIPELINE_EXE, fin, fout, "024"], capture_output=True, text=True, timeout=1200,
+                                   env=dict(os.environ, PGI_DRIVER_REPS="4"))
+                slow = [ln for ln in r.stderr.splitlines() if "[processFeatures] upload of" in ln]
+                feat = {"views": 340, "keypoints_per_view": round(kp_mean), "candidate_pairs": len(fpairs), "wave": 512,
+                        "descriptor_bytes": int(340 * kp_mean * 512), "generation_s": round(gen_f, 1)}
+                if r.returncode == 0:
+                    tim = SC.pipeline_timings(r.stdout)
+                    res = SC.parse_pipeline(open(fout, "rb").read(), 3)
+                    for (mode, label), (stf, ef) in zip(((0, "plain_every_pair_descriptor_matched"), (2, "astar_hashing_reference_guesses"),
+                                                         (4, "astar_hashing_rotation_guided")), res):
+                        kf = dict(zip(SC.PIPELINE_KEYS, stf))
+                        errf = np.array([S.rot_err_deg(ef[key][1], fposes[key[1]][0] @ fposes[key[0]][0].T) for key in ef])
+                        feat[label] = {"features_to_graph_s": tim[mode]["seconds"], "all_repetitions_s": tim[mode]["all_seconds"],
+                                       "repetition_reported": tim[mode]["repetition"],  # the median of the warm repetitions
+                                       "all_repetitions_stage_s": tim[mode]["all_stages"],
+                                       "stages_s": tim[mode]["stages"],
+                                       "pairs_per_s": round(len(fpairs) / tim[mode]["seconds"], 1), "edges": len(ef),
+                                       "descriptor_matching_runs": kf["matching_runs"], "tracklet_quick_matching_runs": kf["quick_matching_runs"],
+                                       "guided_matching_runs": kf["guided_matching_runs"], "tracks": kf["track_number"],
+                                       "poses_from_guess": kf["poses_from_guess"], "quirk_only_guesses": kf["quirk_only_guesses"],
+                                       "edge_rot_err_auc_at_5deg": round(S.auc_at(np.concatenate([errf, np.full(len(fpairs) - len(ef), np.inf)]), 5.0), 4),
+                                       "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
+                    gj, gname, gwhy = replay_profile("guided", None, None, L)
+                    feat["dominant_kernel"] = dict(
+                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (seven wavefronts per CU in the sum kernel; VALU 39 % busy); frac_hbm = ALGORITHMIC bytes / time of all kernels of the scan / 8 TB/s, traffic_* = the counters' bytes over the same time"},
+                        **({k: gj.get(k) for k in ("kernel_us_trace_avg", "scan_us_all_kernels", "companion_kernels", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
+                                                    "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "traffic_GBs", "traffic_frac_hbm", "valu_issue_busy_frac", "wave_waiting_frac", "lane_utilisation", "vgprs", "spilled_vgprs")}
+                           if gj else {}),
+                        source=("replayed from %s; source hash matches the loaded build" % gname) if gj else "none: %s" % gwhy)
+                    if slow:  # the upload stage reports itself when it is far slower than PCIe allows (a shared box now and then)
+                        feat["slow_uploads"] = slow[:6]
+                else:
+                    feat["error"] = r.stderr[-500:]
+            out["config3_from_features"] = feat
+
     if rank == 0 and world == 1 and not args.no_extra:
         # secondary lines (not `value`): fixed budget of 256 hypotheses; the HBM-bound K2 score kernel
         eng.set_params(fixed_budget=256)
@@ -860,116 +972,6 @@ def main():
                             "ns_per_match": round(1e9 * t_trk / n_match, 1), "tracks": info_t["tracks"], "events": info_t["events"],
                             "round_launches": info_t["rounds"], "query_ms": round(1e3 * t_q, 2),
                             "correspondences_returned": int(qres[2].sum().item())}
-
-    if rank == 0 and world == 1 and not args.no_variants and not args.fixed_budget:
-        # ---- SURVEY 8d's other settings of config 2 (same kernel, same 10 000 pairs; never `value`) -------------------
-        def run_variant(batch, thr_v, reps=3, **prm_v):
-            if prm_v:
-                eng.set_params(**prm_v)
-            try:
-                return run_variant_(batch, thr_v, reps)
-            finally:
-                if prm_v:
-                    eng.set_params(**{k: 0 for k in prm_v})   # (only switches that default to 0 are varied here: sampler)
-
-        def run_variant_(batch, thr_v, reps):
-            dbv = eng.upload(batch["x1"], batch["y1"], batch["x2"], batch["y2"], batch["offsets"], thr_v, seed=seed, pair_id_base=pair_base)
-            ev_, mv_ = eng.estimate_pose_batch(dbv)
-            torch.cuda.synchronize()
-            a_, z_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a_.record()
-            for _ in range(reps):
-                ev_, mv_ = eng.estimate_pose_batch(dbv)
-            z_.record()
-            torch.cuda.synchronize()
-            ms_ = a_.elapsed_time(z_) / reps
-            gv = eng.edges_to_numpy(ev_)
-            okv = gv["status"] == 1
-            Pv = len(gv)
-            ev_deg = np.array([S.rot_err_deg(gv["R"][i].reshape(3, 3), batch["R"][i]) if okv[i] else np.inf for i in range(Pv)])
-            rows_v = int(batch["offsets"][-1])
-            return {"edges_per_s": round(Pv / (ms_ * 1e-3), 1), "kernel_ms": round(ms_, 3), "rows": rows_v,
-                    "rows_per_s": round(rows_v / (ms_ * 1e-3), 1), "rot_err_auc_at_5deg": round(S.auc_at(ev_deg, 5.0), 4),
-                    "edges_ok": int(okv.sum()), "mean_hypotheses": round(float(gv["iters"].mean()), 1)}
-        variants = {}
-        t0 = time.time()
-        variants["thr_0.4px"] = dict(run_variant(b, 0.4 / S.FOCAL_PX), note="the reference's default threshold (examples/cpp_example.cpp:51)")
-        ids_v = np.arange(pair_base, pair_base + P)
-        sizes_v = S.ragged_sizes(ids_v)
-        variants["ragged_N_U50_4000"] = dict(run_variant(S.make_batch(ids_v, sizes_v), thr),
-                                             note="N ~ U{50..4000} per pair: bucketed on the device into occupancy classes, one launch per class")
-        for rho_v in (0.3, 0.7):
-            variants["inlier_ratio_%.1f" % rho_v] = run_variant(S.make_batch(ids_v, N, inlier_ratio=rho_v), thr)
-        # Progressive sampling (pgi_params.sampler = 1) where the iteration cap binds, on rows in the reference's order
-        # (ascending SNN ratio, feature_utils.h:184-186; S.ratio_sorted): VERDICT r5 item 9.  Uniform sampling on the
-        # same sorted rows beside it (the order alone changes nothing for a uniform sampler).
-        b_lo = S.ratio_sorted(S.make_batch(ids_v, N, inlier_ratio=0.3))
-        b_srt = S.ratio_sorted(b)
-        variants["inlier_ratio_0.3_ratio_sorted_uniform"] = run_variant(b_lo, thr)
-        variants["inlier_ratio_0.3_ratio_sorted_progressive"] = dict(run_variant(b_lo, thr, sampler=1), note="sampler = 1")
-        variants["thr_0.4px_ratio_sorted_uniform"] = run_variant(b_srt, 0.4 / S.FOCAL_PX)
-        variants["thr_0.4px_ratio_sorted_progressive"] = dict(run_variant(b_srt, 0.4 / S.FOCAL_PX, sampler=1), note="sampler = 1")
-        del b_lo, b_srt
-        # Graph-cut local optimisation (pgi_params.lo_graph_cut = 9: lambda 0.14, the "GC" of GC-RANSAC; off by default): the refit's
-        # rows are the minimum cut of the spatial-coherence energy.  Same kernel, same batches as `value` / inlier_ratio_0.3.
-        variants["graph_cut_lo"] = dict(run_variant(b, thr, lo_graph_cut=9), note="config 2's batch with lo_graph_cut = 9")
-        variants["inlier_ratio_0.3_graph_cut_lo"] = dict(run_variant(S.make_batch(ids_v, N, inlier_ratio=0.3), thr, lo_graph_cut=9), note="lo_graph_cut = 9")
-        variants["seconds_incl_generation"] = round(time.time() - t0, 1)
-        out["variants"] = variants
-        # ---- graph level (BASELINE configs 3 / 4 / 5 on their surrogates AT SURVEY 8d's DENSITY; 1DSfM data is on neither box):
-        # the C++ host layer (tests/cpp/test_distributed.cpp: PoseGraphBuilder::estimateAndAverage / run + averageRotations)
-        # as a child process, its own wall clock and stage clocks, warm repetition; global rotation error after gauge
-        # alignment, AUC@5 of the estimated edges
-        out["graphs"] = graph_level(1, eng=eng, torch=torch)
-        import scene_drivers as SC
-        # ---- config 3 FROM FEATURES at its stated size (340 views x ~8000 keypoints x 128-d descriptors = 1.4 GB; the 20 next
-        # views of every view as candidates): PoseGraphBuilder::processFeatures -- descriptor matching / tracklet quick matching
-        # -> createCorrespondenceMatrix -> A* guesses -> estimatePose -> guided matching -> tracklets in HBM -- as a child
-        # process (tests/cpp/test_pipeline.cpp), warm repetition, its own wall clock and stage split
-        if os.path.exists(SC.PIPELINE_EXE):
-            t0 = time.time()
-            fviews, fposes, fcam, fsim, fpairs = S.make_feature_scene(340, 8000, band=20)
-            gen_f = time.time() - t0
-            with tempfile.TemporaryDirectory() as tmpd:
-                fin, fout = os.path.join(tmpd, "features.bin"), os.path.join(tmpd, "features.out")
-                SC.write_feature_scene(fin, fviews, fcam, fsim, fpairs, 512)
-                kp_mean = float(np.mean([len(v["xy"]) for v in fviews]))
-                del fviews
-                import subprocess
-                r = subprocess.run([SC.PIPELINE_EXE, fin, fout, "024"], capture_output=True, text=True, timeout=1200,
-                                   env=dict(os.environ, PGI_DRIVER_REPS="4"))
-                slow = [ln for ln in r.stderr.splitlines() if "[processFeatures] upload of" in ln]
-                feat = {"views": 340, "keypoints_per_view": round(kp_mean), "candidate_pairs": len(fpairs), "wave": 512,
-                        "descriptor_bytes": int(340 * kp_mean * 512), "generation_s": round(gen_f, 1)}
-                if r.returncode == 0:
-                    tim = SC.pipeline_timings(r.stdout)
-                    res = SC.parse_pipeline(open(fout, "rb").read(), 3)
-                    for (mode, label), (stf, ef) in zip(((0, "plain_every_pair_descriptor_matched"), (2, "astar_hashing_reference_guesses"),
-                                                         (4, "astar_hashing_rotation_guided")), res):
-                        kf = dict(zip(SC.PIPELINE_KEYS, stf))
-                        errf = np.array([S.rot_err_deg(ef[key][1], fposes[key[1]][0] @ fposes[key[0]][0].T) for key in ef])
-                        feat[label] = {"features_to_graph_s": tim[mode]["seconds"], "all_repetitions_s": tim[mode]["all_seconds"],
-                                       "repetition_reported": tim[mode]["repetition"],  # the median of the warm repetitions
-                                       "all_repetitions_stage_s": tim[mode]["all_stages"],
-                                       "stages_s": tim[mode]["stages"],
-                                       "pairs_per_s": round(len(fpairs) / tim[mode]["seconds"], 1), "edges": len(ef),
-                                       "descriptor_matching_runs": kf["matching_runs"], "tracklet_quick_matching_runs": kf["quick_matching_runs"],
-                                       "guided_matching_runs": kf["guided_matching_runs"], "tracks": kf["track_number"],
-                                       "poses_from_guess": kf["poses_from_guess"], "quirk_only_guesses": kf["quirk_only_guesses"],
-                                       "edge_rot_err_auc_at_5deg": round(S.auc_at(np.concatenate([errf, np.full(len(fpairs) - len(ef), np.inf)]), 5.0), 4),
-                                       "edge_rot_err_median_deg": round(float(np.median(errf)), 4)}
-                    gj, gname, gwhy = replay_profile("guided", None, None, L)
-                    feat["dominant_kernel"] = dict(
-                        {"kernel": (gj or {}).get("kernel", "guided_scan_flat_kernel").split(" (")[0], "bound": "latency (seven wavefronts per CU in the sum kernel; VALU 39 % busy); frac_hbm = ALGORITHMIC bytes / time of all kernels of the scan / 8 TB/s, traffic_* = the counters' bytes over the same time"},
-                        **({k: gj.get(k) for k in ("kernel_us_trace_avg", "scan_us_all_kernels", "companion_kernels", "dispatches", "share_of_gpu_time", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch",
-                                                    "traffic_over_algorithmic", "achieved_GBs", "frac_hbm", "traffic_GBs", "traffic_frac_hbm", "valu_issue_busy_frac", "wave_waiting_frac", "lane_utilisation", "vgprs", "spilled_vgprs")}
-                           if gj else {}),
-                        source=("replayed from %s; source hash matches the loaded build" % gname) if gj else "none: %s" % gwhy)
-                    if slow:  # the upload stage reports itself when it is far slower than PCIe allows (a shared box now and then)
-                        feat["slow_uploads"] = slow[:6]
-                else:
-                    feat["error"] = r.stderr[-500:]
-            out["config3_from_features"] = feat
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own CPU restatement (oracle/), NOT OpenCV (absent on this image),
